@@ -1,0 +1,87 @@
+"""ctypes binding of the C-ABI kernel library (``include/effi_mvs_hip.h``).
+
+The library is built in-tree by ``make -C effi_mvs_plus_amd/csrc`` (see ``__graft_entry__.build``).
+There is deliberately no fallback: if the shared object is missing, ``lib()`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libeffimvs_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "effi_mvs_hip.h")
+
+_vp, _i, _l = C.c_void_p, C.c_int, C.c_long
+
+# name -> argtypes (restype is int for all but effi_error_string)
+SIGNATURES = {
+    "effi_version": [],
+    "effi_compose_rel_proj_f32": [_vp, _i, _vp, _vp],
+    "effi_rel_proj_f32": [_vp, _vp, _vp, _vp],
+    "effi_planar_to_nhwc_f32": [_vp, _vp, _i, _i, _i, _vp],
+    "effi_homo_warp_f32": [_vp, _vp, _vp, _l, _l, _i, _i, _i, _i, _vp, _vp],
+    "effi_warpcorr_views_f32": [_vp, _vp, _i, _vp, _vp, _l, _l, _i, _i, _i, _i, _vp, _vp, _vp],
+    "effi_pixelwise_net_f32": [_vp, _vp, _i, _i, _i, _vp, _vp],
+    "effi_view_aggregate_f32": [_vp, _vp, _i, _i, _i, _vp, _vp],
+    "effi_warpcorr_dyn_f32": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "effi_conv3d_k3_f32": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "effi_deconv3d_k3_f32": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "effi_softmax_regress_conf_f32": [_vp, _vp, _l, _l, _i, _i, _vp, _vp, _vp],
+    "effi_vol_lookup1d_f32": [_vp, _l, _l, _i, _vp, _l, _l, _l, _i, _vp, _vp, _l, _i, _i, _vp, _vp],
+    "effi_getcost_f32": [_vp, _vp, _i, _i, _vp, _vp, _l, _l, _i, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _vp, _vp],
+    "effi_conv2d_f32": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp],
+    "effi_conv2d_c1k7_relu_f32": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "effi_convex_upsample2x_f32": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "effi_split_tanh_relu_f32": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "effi_depth_to_inv_f32": [_vp, _vp, _i, _i, _vp, _vp],
+    "effi_stage1_hypotheses_f32": [_vp, _i, _i, _vp, _vp, _vp],
+    "effi_upsample_nearest_f32": [_vp, _i, _i, _i, _i, _vp, _vp],
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class EffiLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raise if the HIP library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise EffiLibraryError(
+                f"{LIB_PATH} not found: build the gfx950 kernels first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C effi_mvs_plus_amd/csrc). "
+                "There is no CPU / eager fallback for the cost-volume path.")
+        handle = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError here = header/library mismatch
+            fn.argtypes = argtypes
+            fn.restype = _i
+        handle.effi_error_string.argtypes = [_i]
+        handle.effi_error_string.restype = C.c_char_p
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = lib().effi_error_string(code).decode()
+        raise EffiLibraryError(f"{what} failed with code {code}: {msg}")
+
+
+def declared_symbols():
+    """Names of every function the public header declares (used by the CPU-side export test)."""
+    import re
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(effi_[a-z0-9_]+)\s*\(", text)))

@@ -1,0 +1,68 @@
+// Shared device helpers for the gfx950 kernels.  Wave = 64 lanes; no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/effi_mvs_hip.h"
+
+#define EFFI_LAUNCH_CHECK()                                   \
+    do {                                                      \
+        if (hipGetLastError() != hipSuccess) return EFFI_ERR_LAUNCH; \
+    } while (0)
+
+static inline hipStream_t effi_s(effi_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int effi_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+struct EffiPtrList {            // by-value kernel argument: device pointers of the source views
+    const float* p[EFFI_MAX_VIEWS + 1];
+};
+struct EffiOutList {
+    float* p[EFFI_MAX_VIEWS + 1];
+};
+
+// ---- DPP cross-lane adds inside aligned groups of 2 / 4 / 8 lanes (full-rate VALU, no LDS) ----
+__device__ __forceinline__ float effi_dpp_f(float v, int ctrl_sel) {
+    int i = __float_as_int(v);
+    int r;
+    switch (ctrl_sel) {
+        case 0:  r = __builtin_amdgcn_update_dpp(0, i, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
+        case 1:  r = __builtin_amdgcn_update_dpp(0, i, 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
+        default: r = __builtin_amdgcn_update_dpp(0, i, 0x141, 0xF, 0xF, true); break;  // row_half_mirror
+    }
+    return __int_as_float(r);
+}
+
+template <int LPP>
+__device__ __forceinline__ float effi_group_sum(float v) {
+    static_assert(LPP == 1 || LPP == 2 || LPP == 4 || LPP == 8, "lanes per pixel");
+    if (LPP >= 2) v += effi_dpp_f(v, 0);
+    if (LPP >= 4) v += effi_dpp_f(v, 1);
+    if (LPP >= 8) v += effi_dpp_f(v, 2);
+    return v;
+}
+template <int LPP>
+__device__ __forceinline__ float effi_group_max(float v) {
+    if (LPP >= 2) v = fmaxf(v, effi_dpp_f(v, 0));
+    if (LPP >= 4) v = fmaxf(v, effi_dpp_f(v, 1));
+    if (LPP >= 8) v = fmaxf(v, effi_dpp_f(v, 2));
+    return v;
+}
+
+// XCD-aware block remap (8 XCDs, blocks dealt round-robin): consecutive logical tiles land on the
+// same XCD so that neighbouring tiles share that XCD's L2.  Bijective for any grid size.
+__device__ __forceinline__ int effi_xcd_remap(int bid, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+__device__ __forceinline__ float effi_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// scale_inv_depth (models/Effi_MVS_plus.py:138-148): normalised inverse depth -> (scaled, depth)
+__device__ __forceinline__ float effi_inv_to_depth(float inv, float lo, float hi) {
+    // min_disp = 1/max_depth with max_depth = 1/lo (models/Effi_MVS_plus.py:413-414): two reciprocals
+    const float max_depth = 1.0f / lo, min_depth = 1.0f / hi;
+    const float min_disp = 1.0f / max_depth, max_disp = 1.0f / min_depth;
+    float s = min_disp + (max_disp - min_disp) * inv;
+    s = fmaxf(s, 1e-4f);
+    return 1.0f / s;
+}

@@ -1,0 +1,317 @@
+// K9: 2-D convolutions of the GRU update block (models/update.py:14-15,36-38,73-81,109-112) as an
+// implicit GEMM on the fp32 matrix cores: M = pixels, N = output channels, K = (tap, input channel),
+// v_mfma_f32_16x16x4_f32 (exact fp32: bitwise a k-ordered fmaf chain, same rate as the vector ALU but
+// one VGPR per operand and no per-lane weight broadcast).
+//
+// A 256-thread block (4 waves) owns a 16x16 pixel tile and ALL output channels; wave v owns rows
+// 4v..4v+3 (4 M-tiles of 16 pixels) x NT N-tiles of 16 channels -> 4*NT accumulator tiles.
+//   A operand  (lane l: pixel l&15, k = l>>4): read from a halo'd LDS tile [16 ch][18][18] whose channel
+//              planes are padded to 336 floats (= 16 mod 32), so every ds_read_b32 is conflict-free;
+//              the next 16-channel chunk is fetched into registers while the current one is multiplied
+//              (double-buffered LDS, one barrier per chunk).
+//   B operand  (lane l: k = l>>4, cout l&15): weights are host-packed in exactly that lane order, so each
+//              k-step's B tile is ONE coalesced 256-byte global load (L1/L2 resident, shared by all blocks).
+// Epilogues (bias, activation, GRU gating, depth-head update) are fused; see EFFI_EPI_* in the header.
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct Conv2dArgs {
+    const float* src[EFFI_MAX_SRC];
+    int ch[EFFI_MAX_SRC];
+    int cin;                 // real input channels (sum of ch[])
+    int kgroups;             // ceil(cin / 4)
+    const float* wpack;      // [kgroups][KS*KS][NT][64]
+    const float* bias;       // [NT*16]
+    int cout, h, w, act, hd;
+    const float* aux0;
+    const float* aux1;
+    const float* disp_range;
+    int n_range;
+    float* out0;
+    float* out1;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    switch (act) {
+        case EFFI_ACT_RELU: return fmaxf(v, 0.0f);
+        case EFFI_ACT_SIGMOID: return effi_sigmoid(v);
+        case EFFI_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+template <int KS, int NT, int EPI>
+__global__ __launch_bounds__(256) void conv2d_mfma_kernel(const Conv2dArgs a) {
+    constexpr int R = KS / 2, TILE = 16, IW = TILE + 2 * R, CC = 16;
+    constexpr int PL = (KS == 3) ? 336 : 272;                 // plane stride, == 16 (mod 32)
+    constexpr int NE = CC * IW * IW;                          // elements staged per chunk
+    constexpr int NLD = (NE + 255) / 256;
+    __shared__ float lds[2][CC * PL];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int x0 = blockIdx.x * TILE, y0 = blockIdx.y * TILE;
+    const int h = a.h, w = a.w;
+    const long hw = (long)h * w;
+
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    float st[NLD];
+    auto fetch = [&](int chunk) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int e = tid + j * 256;
+            float v = 0.0f;
+            if (e < NE) {
+                const int c = e / (IW * IW);
+                const int r = e - c * (IW * IW);
+                const int yy = r / IW, xx = r - yy * IW;
+                const int gy = y0 - R + yy, gx = x0 - R + xx;
+                int cg = chunk * CC + c;
+                if (cg < a.cin && gy >= 0 && gy < h && gx >= 0 && gx < w) {
+                    const float* p;
+                    if (cg < a.ch[0]) p = a.src[0];
+                    else if ((cg -= a.ch[0]) < a.ch[1]) p = a.src[1];
+                    else { cg -= a.ch[1]; p = a.src[2]; }
+                    v = p[(long)cg * hw + (long)gy * w + gx];
+                }
+            }
+            st[j] = v;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int e = tid + j * 256;
+            if (e < NE) {
+                const int c = e / (IW * IW);
+                const int r = e - c * (IW * IW);
+                lds[buf][c * PL + r] = st[j];
+            }
+        }
+    };
+
+    const int nchunks = (a.kgroups + 3) / 4;
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nchunks) fetch(ch + 1);
+        const int kgn = min(4, a.kgroups - ch * 4);
+        for (int kq = 0; kq < kgn; ++kq) {
+            const float* ab = &lds[buf][(kq * 4 + lk) * PL + (wv * 4) * IW + li];
+            const float* __restrict__ wb = a.wpack + (long)(ch * 4 + kq) * (KS * KS) * NT * 64 + lane;
+#pragma unroll
+            for (int tap = 0; tap < KS * KS; ++tap) {
+                const int ky = tap / KS, kx = tap % KS;
+                float av[4], bv[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) bv[n] = wb[(tap * NT + n) * 64];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) av[m] = ab[(m + ky) * IW + kx];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[n], acc[m][n], 0, 0, 0);
+            }
+        }
+        if (ch + 1 < nchunks) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds pixels x = x0 + 4*lk + r (r = 0..3) of row y, channel 16*n + li
+    const int x = x0 + 4 * lk;
+    const bool vec = ((w & 3) == 0);
+    float lo = 0.0f, hi = 0.0f;
+    if (EPI == EFFI_EPI_HEAD) { lo = a.disp_range[0]; hi = a.disp_range[a.n_range - 1]; }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int y = y0 + wv * 4 + m;
+        if (y >= h || x >= w) continue;
+        const long pix = (long)y * w + x;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int co = n * 16 + li;
+            if (co >= a.cout) continue;
+            const float b = a.bias[co];
+            float v[4] = {acc[m][n][0] + b, acc[m][n][1] + b, acc[m][n][2] + b, acc[m][n][3] + b};
+            float* dst;
+            if (EPI == EFFI_EPI_PLAIN) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], a.act);
+                dst = a.out0 + (long)co * hw + pix;
+            } else if (EPI == EFFI_EPI_GRU_ZR) {
+                if (co < a.hd) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = effi_sigmoid(v[r]);
+                    dst = a.out0 + (long)co * hw + pix;
+                } else {
+                    const float* hp = a.aux0 + (long)(co - a.hd) * hw + pix;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = (x + r < w) ? effi_sigmoid(v[r]) * hp[r] : 0.0f;
+                    dst = a.out1 + (long)(co - a.hd) * hw + pix;
+                }
+            } else if (EPI == EFFI_EPI_GRU_Q) {
+                const float* hp = a.aux0 + (long)co * hw + pix;
+                const float* zp = a.aux1 + (long)co * hw + pix;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (x + r < w) {
+                        const float z = zp[r];
+                        v[r] = (1.0f - z) * hp[r] + z * tanhf(v[r]);
+                    }
+                }
+                dst = a.out0 + (long)co * hw + pix;
+            } else {  // EFFI_EPI_HEAD: single channel
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (x + r < w) v[r] = a.aux0[pix + r] + tanhf(v[r]);
+                dst = a.out0 + pix;
+                float* d2 = a.out1 + pix;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (x + r < w) d2[r] = effi_inv_to_depth(v[r], lo, hi);
+            }
+            if (vec) {
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (x + r < w) dst[r] = v[r];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 7x7 convolution of a single-channel map (convd1, models/update.py:76,90) + ReLU; vector ALUs.
+// ------------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void conv2d_c1k7_relu_kernel(const float* __restrict__ in,
+                                                               const float* __restrict__ wgt,
+                                                               const float* __restrict__ bias, int h, int w,
+                                                               float* __restrict__ out) {
+    constexpr int TXX = 32, TYY = 8, IWX = TXX + 6, IHY = TYY + 6;
+    __shared__ float tile[IHY * IWX];
+    const int tx = threadIdx.x % TXX, ty = threadIdx.x / TXX;
+    const int x0 = blockIdx.x * TXX, y0 = blockIdx.y * TYY;
+    for (int e = threadIdx.x; e < IHY * IWX; e += 256) {
+        const int yy = e / IWX, xx = e - yy * IWX;
+        const int gy = y0 - 3 + yy, gx = x0 - 3 + xx;
+        tile[e] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? in[(long)gy * w + gx] : 0.0f;
+    }
+    __syncthreads();
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = bias[c];
+#pragma unroll
+    for (int k = 0; k < 49; ++k) {
+        const float v = tile[(ty + k / 7) * IWX + tx + k % 7];
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[c] = fmaf(v, wgt[k * COUT + c], acc[c]);
+    }
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= w || y >= h) return;
+    const long hw = (long)h * w, pix = (long)y * w + x;
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) out[c * hw + pix] = fmaxf(acc[c], 0.0f);
+}
+
+template <int KS, int NT, int EPI>
+int launch2d(const Conv2dArgs& a, hipStream_t st) {
+    dim3 grid(effi_cdiv(a.w, 16), effi_cdiv(a.h, 16));
+    hipLaunchKernelGGL((conv2d_mfma_kernel<KS, NT, EPI>), grid, dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+}
+
+template <int KS, int EPI>
+int dispatch_nt(const Conv2dArgs& a, int nt, hipStream_t st) {
+    switch (nt) {
+        case 1: return launch2d<KS, 1, EPI>(a, st);
+        case 2: return launch2d<KS, 2, EPI>(a, st);
+        case 3: return launch2d<KS, 3, EPI>(a, st);
+        case 4: return launch2d<KS, 4, EPI>(a, st);
+        case 6: return launch2d<KS, 6, EPI>(a, st);
+        default: return EFFI_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace
+
+extern "C" int effi_conv2d_f32(const float* const* srcs, const int* src_channels, int n_src, const float* wpack,
+                               const float* bias, int cout, int ks, int h, int w, int epilogue, int act,
+                               const float* aux0, const float* aux1, const float* disp_range, int n_range,
+                               float* out0, float* out1, effi_stream_t stream) {
+    if (!srcs || !src_channels || n_src < 1 || n_src > EFFI_MAX_SRC || !wpack || !bias || !out0) return EFFI_ERR_BADARG;
+    if (cout < 1 || h < 1 || w < 1 || (ks != 1 && ks != 3)) return EFFI_ERR_BADARG;
+    Conv2dArgs a;
+    a.cin = 0;
+    for (int i = 0; i < EFFI_MAX_SRC; ++i) {
+        a.src[i] = (i < n_src) ? srcs[i] : nullptr;
+        a.ch[i] = (i < n_src) ? src_channels[i] : 0;
+        if (i < n_src && (!srcs[i] || src_channels[i] < 1)) return EFFI_ERR_BADARG;
+        a.cin += a.ch[i];
+    }
+    a.kgroups = (a.cin + 3) / 4;
+    a.wpack = wpack;
+    a.bias = bias;
+    a.cout = cout;
+    a.h = h;
+    a.w = w;
+    a.act = act;
+    a.hd = cout / 2;
+    a.aux0 = aux0;
+    a.aux1 = aux1;
+    a.disp_range = disp_range;
+    a.n_range = n_range;
+    a.out0 = out0;
+    a.out1 = out1;
+    const int nt = (cout + 15) / 16;
+    hipStream_t st = effi_s(stream);
+    switch (epilogue) {
+        case EFFI_EPI_PLAIN:
+            if (act < EFFI_ACT_NONE || act > EFFI_ACT_TANH) return EFFI_ERR_BADARG;
+            return ks == 3 ? dispatch_nt<3, EFFI_EPI_PLAIN>(a, nt, st) : dispatch_nt<1, EFFI_EPI_PLAIN>(a, nt, st);
+        case EFFI_EPI_GRU_ZR:
+            if (ks != 3 || !aux0 || !out1 || (cout % 32) != 0) return EFFI_ERR_BADARG;
+            if (nt == 2) return launch2d<3, 2, EFFI_EPI_GRU_ZR>(a, st);
+            if (nt == 4) return launch2d<3, 4, EFFI_EPI_GRU_ZR>(a, st);
+            if (nt == 6) return launch2d<3, 6, EFFI_EPI_GRU_ZR>(a, st);
+            return EFFI_ERR_UNSUPPORTED;
+        case EFFI_EPI_GRU_Q:
+            if (ks != 3 || !aux0 || !aux1 || (cout % 16) != 0) return EFFI_ERR_BADARG;
+            if (nt == 1) return launch2d<3, 1, EFFI_EPI_GRU_Q>(a, st);
+            if (nt == 2) return launch2d<3, 2, EFFI_EPI_GRU_Q>(a, st);
+            if (nt == 3) return launch2d<3, 3, EFFI_EPI_GRU_Q>(a, st);
+            return EFFI_ERR_UNSUPPORTED;
+        case EFFI_EPI_HEAD:
+            if (ks != 3 || cout != 1 || !aux0 || !out1 || !disp_range || n_range < 2) return EFFI_ERR_BADARG;
+            return launch2d<3, 1, EFFI_EPI_HEAD>(a, st);
+        default:
+            return EFFI_ERR_BADARG;
+    }
+}
+
+extern "C" int effi_conv2d_c1k7_relu_f32(const float* in, const float* weight, const float* bias, int cout, int h,
+                                         int w, float* out, effi_stream_t stream) {
+    if (!in || !weight || !bias || !out || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    dim3 grid(effi_cdiv(w, 32), effi_cdiv(h, 8));
+    hipStream_t st = effi_s(stream);
+    switch (cout) {
+        case 16: hipLaunchKernelGGL(conv2d_c1k7_relu_kernel<16>, grid, dim3(256), 0, st, in, weight, bias, h, w, out); break;
+        case 32: hipLaunchKernelGGL(conv2d_c1k7_relu_kernel<32>, grid, dim3(256), 0, st, in, weight, bias, h, w, out); break;
+        case 48: hipLaunchKernelGGL(conv2d_c1k7_relu_kernel<48>, grid, dim3(256), 0, st, in, weight, bias, h, w, out); break;
+        default: return EFFI_ERR_UNSUPPORTED;
+    }
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}

@@ -1,0 +1,289 @@
+// K5/K6: 3-D convolutions (kernel 3, padding 1) of the cost regulariser and the cross-scale
+// propagation blocks, BatchNorm folded into (weight, bias) by the host.
+// Reference: models/module.py:124-160 (Conv3d), :168-203 (Deconv3d), :439-463, :501-516.
+//
+// Direct convolution on the vector ALUs: channel counts are 1..32, so an implicit GEMM would have
+// N = Cout <= 32 and waste most of an MFMA tile; instead a 256-thread block (32 x 8 lanes in x,y)
+// stages a halo'd input tile of a few input channels in LDS, every thread keeps ZPT x COUT_T
+// accumulators in registers, each LDS value feeds >= 8 FMAs, and the weights (uniform across lanes)
+// arrive through the scalar cache as SGPR operands of v_fma.  Planar [C][D][h][w] layout: lanes run
+// along x, so tile loads and output stores are coalesced.
+#include "common.hpp"
+
+namespace {
+
+constexpr int TX = 32, TY = 8;
+
+struct SrcSet {                    // channel concatenation of up to EFFI_MAX_SRC planar tensors
+    const float* p[EFFI_MAX_SRC];
+    int ch[EFFI_MAX_SRC];
+};
+
+__device__ __forceinline__ const float* src_channel(const SrcSet& s, int c, long plane) {
+    // channel c of cat(s.p[0], s.p[1], s.p[2]) -> pointer to its [D][h][w] block
+    if (c < s.ch[0]) return s.p[0] + (long)c * plane;
+    c -= s.ch[0];
+    if (c < s.ch[1]) return s.p[1] + (long)c * plane;
+    c -= s.ch[1];
+    return s.p[2] + (long)c * plane;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward convolution, stride (SZ, SXY, SXY)
+// ------------------------------------------------------------------------------------------------
+template <int COUT_T, int SZ, int SXY>
+__global__ __launch_bounds__(256) void conv3d_k3_kernel(SrcSet src, int cin, const float* __restrict__ wgt,
+                                                        const float* __restrict__ bias, int cout,
+                                                        int D, int h, int w, int Do, int ho, int wo,
+                                                        int relu, const float* __restrict__ skip,
+                                                        float* __restrict__ out) {
+    constexpr int ZPT = (SXY == 1) ? 4 : ((SZ == 1) ? 4 : 2);
+    constexpr int CC = (SXY == 1) ? 4 : ((SZ == 1) ? 1 : 2);
+    constexpr int IZ = (ZPT - 1) * SZ + 3, IY = (TY - 1) * SXY + 3, IX = (TX - 1) * SXY + 3;
+    constexpr int PLANE = IZ * IY * IX;
+    __shared__ float tile[CC * PLANE];
+
+    const int tiles_x = (wo + TX - 1) / TX;
+    const int by = blockIdx.x / tiles_x, bx = blockIdx.x - by * tiles_x;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int ox = bx * TX + tx, oy = by * TY + ty, oz0 = blockIdx.y * ZPT;
+    const int co0 = blockIdx.z * COUT_T;
+    const int iz0 = oz0 * SZ - 1, iy0 = by * TY * SXY - 1, ix0 = bx * TX * SXY - 1;
+    const long in_plane = (long)D * h * w;
+
+    float acc[ZPT][COUT_T];
+#pragma unroll
+    for (int z = 0; z < ZPT; ++z)
+#pragma unroll
+        for (int c = 0; c < COUT_T; ++c) acc[z][c] = 0.0f;
+
+    for (int c0 = 0; c0 < cin; c0 += CC) {
+        const int ccn = min(CC, cin - c0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < ccn * PLANE; e += 256) {
+            const int c = e / PLANE;
+            int r = e - c * PLANE;
+            const int lz = r / (IY * IX);
+            r -= lz * (IY * IX);
+            const int ly = r / IX, lx = r - ly * IX;
+            const int gz = iz0 + lz, gy = iy0 + ly, gx = ix0 + lx;
+            float v = 0.0f;
+            if (gz >= 0 && gz < D && gy >= 0 && gy < h && gx >= 0 && gx < w)
+                v = src_channel(src, c0 + c, in_plane)[((long)gz * h + gy) * w + gx];
+            tile[e] = v;
+        }
+        __syncthreads();
+        for (int c = 0; c < ccn; ++c) {
+            const float* __restrict__ wc = wgt + (long)(c0 + c) * 27 * cout + co0;
+            const float* tc = tile + c * PLANE + (ty * SXY) * IX + tx * SXY;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    float col[IZ];
+#pragma unroll
+                    for (int z = 0; z < IZ; ++z) col[z] = tc[z * (IY * IX) + ky * IX + kx];
+#pragma unroll
+                    for (int kd = 0; kd < 3; ++kd) {
+                        const float* __restrict__ wk = wc + (kd * 9 + ky * 3 + kx) * cout;
+#pragma unroll
+                        for (int z = 0; z < ZPT; ++z)
+#pragma unroll
+                            for (int co = 0; co < COUT_T; ++co)
+                                acc[z][co] = fmaf(col[z * SZ + kd], wk[co], acc[z][co]);
+                    }
+                }
+        }
+    }
+
+    if (ox >= wo || oy >= ho) return;
+    const long out_plane = (long)Do * ho * wo;
+#pragma unroll
+    for (int z = 0; z < ZPT; ++z) {
+        const int oz = oz0 + z;
+        if (oz >= Do) break;
+        const long o = ((long)oz * ho + oy) * wo + ox;
+#pragma unroll
+        for (int co = 0; co < COUT_T; ++co) {
+            if (co0 + co >= cout) break;
+            float v = acc[z][co] + (bias ? bias[co0 + co] : 0.0f);
+            if (relu) v = fmaxf(v, 0.0f);
+            if (skip) v = v + skip[(long)(co0 + co) * out_plane + o];
+            out[(long)(co0 + co) * out_plane + o] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// transposed convolution, stride (SZ, 2, 2), padding 1, output_padding (SZ-1, 1, 1).
+// One thread per INPUT position: it produces the 2x2 (x SZ) output block that position owns, so every
+// lane does identical work (no parity divergence) and each of the 27 taps is used exactly once.
+// stride 2 along an axis:  out[2i]   = in[i]   * w[1]
+//                          out[2i+1] = in[i]   * w[2] + in[i+1] * w[0]
+// stride 1 along z:        out[z]    = sum_kd in[z + 1 - kd] * w[kd]
+// ------------------------------------------------------------------------------------------------
+template <int COUT_T, int SZ>
+__global__ __launch_bounds__(256) void deconv3d_k3_kernel(const float* __restrict__ in, int cin,
+                                                          const float* __restrict__ wgt,
+                                                          const float* __restrict__ bias, int cout,
+                                                          int D, int h, int w, int relu,
+                                                          const float* __restrict__ skip, float* __restrict__ out) {
+    constexpr int ZPT = (SZ == 2) ? 1 : 4;            // input z positions per thread
+    constexpr int OZ = (SZ == 2) ? 2 : ZPT;           // output z positions per thread
+    constexpr int CC = 4;
+    constexpr int IZ = (SZ == 2) ? 2 : ZPT + 2, IY = TY + 1, IX = TX + 1;
+    constexpr int PLANE = IZ * IY * IX;
+    __shared__ float tile[CC * PLANE];
+
+    const int tiles_x = (w + TX - 1) / TX;
+    const int by = blockIdx.x / tiles_x, bx = blockIdx.x - by * tiles_x;
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int ix = bx * TX + tx, iy = by * TY + ty, z0 = blockIdx.y * ZPT;
+    const int co0 = blockIdx.z * COUT_T;
+    const int iz0 = (SZ == 2) ? z0 : z0 - 1;
+    const long in_plane = (long)D * h * w;
+
+    float acc[OZ][2][2][COUT_T];
+#pragma unroll
+    for (int a = 0; a < OZ; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int d = 0; d < COUT_T; ++d) acc[a][b][c][d] = 0.0f;
+
+    for (int c0 = 0; c0 < cin; c0 += CC) {
+        const int ccn = min(CC, cin - c0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < ccn * PLANE; e += 256) {
+            const int c = e / PLANE;
+            int r = e - c * PLANE;
+            const int lz = r / (IY * IX);
+            r -= lz * (IY * IX);
+            const int ly = r / IX, lx = r - ly * IX;
+            const int gz = iz0 + lz, gy = by * TY + ly, gx = bx * TX + lx;
+            float v = 0.0f;
+            if (gz >= 0 && gz < D && gy < h && gx < w) v = in[(long)(c0 + c) * in_plane + ((long)gz * h + gy) * w + gx];
+            tile[e] = v;
+        }
+        __syncthreads();
+        for (int c = 0; c < ccn; ++c) {
+            const float* __restrict__ wc = wgt + (long)(c0 + c) * 27 * cout + co0;
+            const float* tc = tile + c * PLANE + ty * IX + tx;
+#pragma unroll
+            for (int lz = 0; lz < IZ; ++lz)
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const float v = tc[lz * (IY * IX) + dy * IX + dx];
+#pragma unroll
+                        for (int ay = 0; ay < 2; ++ay) {
+                            const int ky = (dy == 0) ? (ay == 0 ? 1 : 2) : (ay == 1 ? 0 : -1);
+                            if (ky < 0) continue;
+#pragma unroll
+                            for (int ax = 0; ax < 2; ++ax) {
+                                const int kx = (dx == 0) ? (ax == 0 ? 1 : 2) : (ax == 1 ? 0 : -1);
+                                if (kx < 0) continue;
+#pragma unroll
+                                for (int az = 0; az < OZ; ++az) {
+                                    int kd;
+                                    if (SZ == 2) kd = (lz == 0) ? (az == 0 ? 1 : 2) : (az == 1 ? 0 : -1);
+                                    else kd = az + 2 - lz;          // lz = az + 2 - kd
+                                    if (kd < 0 || kd > 2) continue;
+                                    const float* __restrict__ wk = wc + (kd * 9 + ky * 3 + kx) * cout;
+#pragma unroll
+                                    for (int co = 0; co < COUT_T; ++co)
+                                        acc[az][ay][ax][co] = fmaf(v, wk[co], acc[az][ay][ax][co]);
+                                }
+                            }
+                        }
+                    }
+        }
+    }
+
+    if (ix >= w || iy >= h) return;
+    const int Do = SZ * D, ho = 2 * h, wo = 2 * w;
+    const long out_plane = (long)Do * ho * wo;
+#pragma unroll
+    for (int az = 0; az < OZ; ++az) {
+        const int oz = (SZ == 2) ? 2 * z0 + az : z0 + az;
+        if (oz >= Do) break;
+#pragma unroll
+        for (int ay = 0; ay < 2; ++ay) {
+            const long o = ((long)oz * ho + 2 * iy + ay) * wo + 2 * ix;
+#pragma unroll
+            for (int co = 0; co < COUT_T; ++co) {
+                if (co0 + co >= cout) break;
+                const float b = bias ? bias[co0 + co] : 0.0f;
+                float v0 = acc[az][ay][0][co] + b, v1 = acc[az][ay][1][co] + b;
+                if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
+                const long oo = (long)(co0 + co) * out_plane + o;
+                if (skip) {
+                    const float2 s = *reinterpret_cast<const float2*>(skip + oo);
+                    v0 = v0 + s.x;
+                    v1 = v1 + s.y;
+                }
+                *reinterpret_cast<float2*>(out + oo) = make_float2(v0, v1);
+            }
+        }
+    }
+}
+
+template <int COUT_T, int SZ, int SXY>
+int launch_conv(const SrcSet& s, int cin, const float* wgt, const float* bias, int cout, int D, int h, int w,
+                int relu, const float* skip, float* out, hipStream_t st) {
+    constexpr int ZPT = (SXY == 1) ? 4 : ((SZ == 1) ? 4 : 2);
+    const int Do = (D - 1) / SZ + 1, ho = (h - 1) / SXY + 1, wo = (w - 1) / SXY + 1;
+    dim3 grid(effi_cdiv(wo, TX) * effi_cdiv(ho, TY), effi_cdiv(Do, ZPT), effi_cdiv(cout, COUT_T));
+    hipLaunchKernelGGL((conv3d_k3_kernel<COUT_T, SZ, SXY>), grid, dim3(256), 0, st, s, cin, wgt, bias, cout, D, h, w,
+                       Do, ho, wo, relu, skip, out);
+    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int effi_conv3d_k3_f32(const float* const* srcs, const int* src_channels, int n_src, const float* weight,
+                                  const float* bias, int cout, int D, int h, int w, int sz, int sxy, int relu,
+                                  const float* skip, float* out, effi_stream_t stream) {
+    if (!srcs || !src_channels || n_src < 1 || n_src > EFFI_MAX_SRC || !weight || !out) return EFFI_ERR_BADARG;
+    if (D < 1 || h < 1 || w < 1 || cout < 1) return EFFI_ERR_BADARG;
+    SrcSet s;
+    int cin = 0;
+    for (int i = 0; i < EFFI_MAX_SRC; ++i) {
+        s.p[i] = (i < n_src) ? srcs[i] : nullptr;
+        s.ch[i] = (i < n_src) ? src_channels[i] : 0;
+        if (i < n_src && (!srcs[i] || src_channels[i] < 1)) return EFFI_ERR_BADARG;
+        cin += s.ch[i];
+    }
+    hipStream_t st = effi_s(stream);
+    const bool c8 = (cout % 8 == 0);
+    if (!c8 && cout != 1) return EFFI_ERR_UNSUPPORTED;
+    if (sz == 1 && sxy == 1)
+        return c8 ? launch_conv<8, 1, 1>(s, cin, weight, bias, cout, D, h, w, relu, skip, out, st)
+                  : launch_conv<1, 1, 1>(s, cin, weight, bias, cout, D, h, w, relu, skip, out, st);
+    if (!c8) return EFFI_ERR_UNSUPPORTED;
+    if (sz == 2 && sxy == 2) return launch_conv<8, 2, 2>(s, cin, weight, bias, cout, D, h, w, relu, skip, out, st);
+    if (sz == 1 && sxy == 2) return launch_conv<8, 1, 2>(s, cin, weight, bias, cout, D, h, w, relu, skip, out, st);
+    return EFFI_ERR_UNSUPPORTED;
+}
+
+extern "C" int effi_deconv3d_k3_f32(const float* in, int cin, const float* weight, const float* bias, int cout, int D,
+                                    int h, int w, int sz, int relu, const float* skip, float* out,
+                                    effi_stream_t stream) {
+    if (!in || !weight || !out || cin < 1 || cout < 1 || D < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    hipStream_t st = effi_s(stream);
+    const int tiles = effi_cdiv(w, TX) * effi_cdiv(h, TY);
+    if (sz == 2 && cout % 8 == 0) {
+        hipLaunchKernelGGL((deconv3d_k3_kernel<8, 2>), dim3(tiles, D, cout / 8), dim3(256), 0, st, in, cin, weight, bias,
+                           cout, D, h, w, relu, skip, out);
+    } else if (sz == 1 && cout == 1) {
+        hipLaunchKernelGGL((deconv3d_k3_kernel<1, 1>), dim3(tiles, effi_cdiv(D, 4), 1), dim3(256), 0, st, in, cin, weight,
+                           bias, cout, D, h, w, relu, skip, out);
+    } else {
+        return EFFI_ERR_UNSUPPORTED;
+    }
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}

@@ -1,0 +1,359 @@
+// Per-pixel / element-wise kernels of the stage loop: layout change, hypothesis generation,
+// view aggregation, softmax + soft-argmin + confidence, 1-D volume lookups, convex upsampling.
+// All are HBM-bound streaming kernels: one thread per pixel, lanes along x (coalesced), 256-thread
+// blocks.  Compiled with -ffp-contract=off so that the element-wise formulas round exactly like the
+// reference's separate torch ops; fused multiply-adds are written explicitly where wanted.
+#include "common.hpp"
+
+namespace {
+
+constexpr int TPB = 256;
+
+// ------------------------------------------------------------------------------------------------
+// planar [C][HW] -> nhwc [HW][C] through an LDS tile of 64 pixels (coalesced on both sides)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void planar_to_nhwc_kernel(EffiPtrList srcs, EffiOutList dsts, int C, int HW) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // [C][65]
+    const float* __restrict__ src = srcs.p[blockIdx.y];
+    float* __restrict__ dst = dsts.p[blockIdx.y];
+    const long p0 = (long)blockIdx.x * 64;
+    const int n = C * 64;
+    for (int e = threadIdx.x; e < n; e += TPB) {
+        const int c = e >> 6, p = e & 63;
+        const long gp = p0 + p;
+        tile[c * 65 + p] = (gp < HW) ? src[(long)c * HW + gp] : 0.0f;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n; e += TPB) {
+        const int p = e / C, c = e - p * C;
+        const long gp = p0 + p;
+        if (gp < HW) dst[gp * C + c] = tile[c * 65 + p];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void split_tanh_relu_kernel(const float* __restrict__ ctx, int hd, int cd, int hw,
+                                       float* __restrict__ hidden, float* __restrict__ inp) {
+    const long n = (long)(hd + cd) * hw;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) {
+        const float v = ctx[i];
+        if (i < (long)hd * hw) hidden[i] = tanhf(v);
+        else inp[i - (long)hd * hw] = fmaxf(v, 0.0f);
+    }
+}
+
+__global__ void depth_to_inv_kernel(const float* __restrict__ depth, const float* __restrict__ disp_range,
+                                    int n_range, int n, float* __restrict__ inv) {
+    const float lo = disp_range[0], hi = disp_range[n_range - 1];
+    // depth_to_disp(depth, depth_min_, depth_max_) with depth_max_ = 1/lo, depth_min_ = 1/hi
+    const float max_depth = 1.0f / lo, min_depth = 1.0f / hi;
+    const float min_disp = 1.0f / max_depth, max_disp = 1.0f / min_depth;
+    const float den = (max_disp - min_disp) + 1e-10f;
+    for (int i = blockIdx.x * TPB + threadIdx.x; i < n; i += gridDim.x * TPB) {
+        const float s = 1.0f / depth[i];
+        inv[i] = (s - min_disp) / den;
+    }
+}
+
+__global__ void stage1_hypotheses_kernel(const float* __restrict__ disp_range, int n_range, int D,
+                                         float* __restrict__ depths, float* __restrict__ intervals) {
+    const float lo = disp_range[0], hi = disp_range[n_range - 1];
+    const float step = (hi - lo) / (float)(D - 1);               // models/module.py:578-583
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        const float s = lo + (float)d * step;
+        depths[d] = 1.0f / s;                                    // models/Effi_MVS_plus.py:473-474
+    }
+    if (threadIdx.x < 3) {
+        const float base = (hi - lo) / (float)n_range;           // models/Effi_MVS_plus.py:424
+        const float ratio = (threadIdx.x == 0) ? 4.0f : (threadIdx.x == 1 ? 2.0f : 1.0f);   // :316
+        intervals[threadIdx.x] = base * ratio;
+    } else if (threadIdx.x == 3) {
+        intervals[3] = 1.0f / hi;                                // depth_min_ (:414)
+    } else if (threadIdx.x == 4) {
+        intervals[4] = 1.0f / lo;                                // depth_max_ (:413)
+    }
+}
+
+__global__ void upsample_nearest_kernel(const float* __restrict__ in, int C, int h, int w, int f,
+                                        float* __restrict__ out) {
+    const int W = w * f, H = h * f;
+    const long n = (long)C * H * W;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long)gridDim.x * TPB) {
+        const int x = (int)(i % W);
+        const long t = i / W;
+        const int y = (int)(t % H);
+        const int c = (int)(t / H);
+        out[i] = in[((long)c * h + y / f) * w + x / f];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: sim = sum_v sim_v * w_v / (sum_v w_v + 1e-6)      (models/Effi_MVS_plus.py:48-53,67)
+// ------------------------------------------------------------------------------------------------
+__global__ void view_aggregate_kernel(const float* __restrict__ sim_views, const float* __restrict__ weights,
+                                      int S, int D, int hw, float* __restrict__ out) {
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= hw) return;
+    float wv[EFFI_MAX_VIEWS];
+    float wsum = 0.0f;
+#pragma unroll
+    for (int v = 0; v < EFFI_MAX_VIEWS; ++v) {          // constant trip count keeps wv[] in registers
+        wv[v] = (v < S) ? weights[(long)v * hw + p] : 0.0f;
+        if (v < S) wsum = wsum + wv[v];
+    }
+    const float den = wsum + 1e-6f;
+    const int d0 = blockIdx.y * 8;
+    for (int d = d0; d < min(D, d0 + 8); ++d) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int v = 0; v < EFFI_MAX_VIEWS; ++v)
+            if (v < S) acc = acc + sim_views[((long)v * D + d) * hw + p] * wv[v];
+        out[(long)d * hw + p] = acc / den;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7: softmax over D, depth regression, 4-window confidence (models/Effi_MVS_plus.py:79-88)
+// ------------------------------------------------------------------------------------------------
+__global__ void softmax_regress_conf_kernel(const float* __restrict__ logits, const float* __restrict__ depth,
+                                            long dds, long dps, int D, int hw,
+                                            float* __restrict__ out_depth, float* __restrict__ out_conf) {
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= hw) return;
+    float m = -INFINITY;
+    for (int d = 0; d < D; ++d) m = fmaxf(m, logits[(long)d * hw + p]);
+    float sum = 0.0f;
+    for (int d = 0; d < D; ++d) sum = sum + expf(logits[(long)d * hw + p] - m);
+    float dep = 0.0f, idxf = 0.0f;
+    for (int d = 0; d < D; ++d) {
+        const float pr = expf(logits[(long)d * hw + p] - m) / sum;
+        dep = dep + pr * depth[d * dds + p * dps];
+        idxf = idxf + pr * (float)d;
+    }
+    int idx = (int)idxf;                       // .long(): truncation
+    idx = max(0, min(D - 1, idx));
+    float s4 = 0.0f;                           // pad (1,2) + avg_pool3d(4) * 4 == sum over idx-1 .. idx+2
+    for (int k = idx - 1; k <= idx + 2; ++k) {
+        const float pr = (k >= 0 && k < D) ? expf(logits[(long)k * hw + p] - m) / sum : 0.0f;
+        s4 = s4 + pr;
+    }
+    out_depth[p] = dep;
+    out_conf[p] = 4.0f * (s4 / 4.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8: 1-D lookup in a per-pixel vector (pro_bilinear_sampler, models/Effi_MVS_plus.py:102-134)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lookup1d(const float* __restrict__ vol, long dstride, int Dp,
+                                          float q_depth, float dmin, float dmax) {
+    const float scaled = 1.0f / q_depth;                               // depth_to_disp, :156-164
+    const float min_disp = 1.0f / dmax, max_disp = 1.0f / dmin;
+    const float disp = (scaled - min_disp) / ((max_disp - min_disp) + 1e-10f);
+    const float dm1 = (float)(Dp - 1);
+    const float t = disp * dm1;                                        // :123
+    const float g = 2.0f * t / dm1 - 1.0f;                             // :107
+    float ix = ((g + 1.0f) / 2.0f) * dm1;                              // grid_sample, align_corners=True
+    ix = fminf(fmaxf(ix, -2.0f), dm1 + 2.0f);                          // neutral: both taps stay out of range
+    const float x0f = floorf(ix);
+    const int x0 = (int)x0f;
+    const float w1 = ix - x0f;
+    const float w0 = (x0f + 1.0f) - ix;
+    float r = 0.0f;
+    if (x0 >= 0 && x0 <= Dp - 1) r = vol[x0 * dstride] * w0;
+    if (x0 + 1 >= 0 && x0 + 1 <= Dp - 1) r = r + vol[(x0 + 1) * dstride] * w1;
+    return r;
+}
+
+__global__ void vol_lookup1d_kernel(const float* __restrict__ vol, long vds, long vps, int Dp,
+                                    const float* __restrict__ query, long qds, long qys, long qxs, int nq,
+                                    const float* __restrict__ dmin, const float* __restrict__ dmax, long rps,
+                                    int h, int w, float* __restrict__ out) {
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= h * w) return;
+    const int y = p / w, x = p - y * w;
+    const float lo = dmin[p * rps], hi = dmax[p * rps];
+    const float* v = vol + p * vps;
+    for (int k = 0; k < nq; ++k) {
+        const float q = query[k * qds + y * qys + x * qxs];
+        out[(long)k * h * w + p] = lookup1d(v, vds, Dp, q, lo, hi);
+    }
+}
+
+// GetCost.forward (models/Effi_MVS_plus.py:257-303) behind scale_inv_depth (:138-148)
+__global__ void getcost_kernel(const float* __restrict__ inv_depth, const float* __restrict__ disp_range,
+                               int n_range, int input_is_depth, const float* __restrict__ interval,
+                               const float* __restrict__ cur_vol, long cds, long cps, int Dcur,
+                               const float* __restrict__ reg_vol, long rds, long rps_, int Dreg,
+                               const float* __restrict__ dmin, const float* __restrict__ dmax, long range_ps,
+                               int nq, int hw, float* __restrict__ cost) {
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= hw) return;
+    const float itv = interval[0];
+    float depth = inv_depth[p];
+    if (!input_is_depth) depth = effi_inv_to_depth(depth, disp_range[0], disp_range[n_range - 1]);
+    const float dv = 1.0f / depth;                                     // :272
+    const float half = (float)(nq / 2) * itv;                          // module.py:558-560
+    const float smin = fmaxf(dv - half, 1e-4f);
+    const float smax = fminf(fmaxf(dv + half, 1e-4f), 1e4f);
+    const float step = (smax - smin) / (float)(nq - 1);
+    const float rlo = dmin[p * range_ps], rhi = dmax[p * range_ps];
+    for (int k = 0; k < nq; ++k) {
+        const float s = fmaxf(smin + (float)k * step, 1e-5f);          // module.py:566-570
+        const float qd = 1.0f / s;                                     // :285
+        cost[(long)k * hw + p] = lookup1d(cur_vol + p * cps, cds, Dcur, qd, rlo, rhi);
+        cost[(long)(nq + k) * hw + p] = lookup1d(reg_vol + p * rps_, rds, Dreg, qd, rlo, rhi);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K10: convex upsampling x2 (models/Effi_MVS_plus.py:167-178) + scale_inv_depth
+// ------------------------------------------------------------------------------------------------
+__global__ void convex_upsample2x_kernel(const float* __restrict__ inv, const float* __restrict__ mask,
+                                         const float* __restrict__ disp_range, int n_range, int h, int w,
+                                         float* __restrict__ out_inv, float* __restrict__ out_depth) {
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= h * w) return;
+    const int y = p / w, x = p - y * w;
+    const long hw = (long)h * w;
+    float nb[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+        nb[k] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? inv[(long)yy * w + xx] : 0.0f;   // F.unfold zero pad
+    }
+    float lo = 0.0f, hi = 0.0f;
+    if (out_depth) { lo = disp_range[0]; hi = disp_range[n_range - 1]; }
+    const int W2 = 2 * w;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {            // r = ry*2 + rx; mask channel = k*4 + r
+        float mv[9], m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            mv[k] = mask[(long)(k * 4 + r) * hw + p];
+            m = fmaxf(m, mv[k]);
+        }
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            mv[k] = expf(mv[k] - m);
+            sum = sum + mv[k];
+        }
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc = acc + (mv[k] / sum) * nb[k];
+        const long o = (long)(2 * y + (r >> 1)) * W2 + 2 * x + (r & 1);
+        if (out_inv) out_inv[o] = acc;
+        if (out_depth) out_depth[o] = effi_inv_to_depth(acc, lo, hi);
+    }
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" int effi_planar_to_nhwc_f32(const float* const* srcs, float* const* dsts, int n, int C, int HW,
+                                       effi_stream_t stream) {
+    if (!srcs || !dsts || n < 1 || n > EFFI_MAX_VIEWS + 1 || C < 1 || C > 128 || HW < 1) return EFFI_ERR_BADARG;
+    EffiPtrList s;
+    EffiOutList d;
+    for (int i = 0; i < n; ++i) {
+        if (!srcs[i] || !dsts[i]) return EFFI_ERR_BADARG;
+        s.p[i] = srcs[i];
+        d.p[i] = dsts[i];
+    }
+    hipLaunchKernelGGL(planar_to_nhwc_kernel, dim3(effi_cdiv(HW, 64), n), dim3(TPB), (size_t)C * 65 * sizeof(float),
+                       effi_s(stream), s, d, C, HW);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_split_tanh_relu_f32(const float* ctx, int hd, int cd, int hw, float* hidden, float* inp,
+                                        effi_stream_t stream) {
+    if (!ctx || !hidden || !inp || hd < 1 || cd < 1 || hw < 1) return EFFI_ERR_BADARG;
+    const long n = (long)(hd + cd) * hw;
+    hipLaunchKernelGGL(split_tanh_relu_kernel, dim3(min(effi_cdiv(n, TPB), 4096)), dim3(TPB), 0, effi_s(stream),
+                       ctx, hd, cd, hw, hidden, inp);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_depth_to_inv_f32(const float* depth, const float* disp_range, int n_range, int n, float* inv,
+                                     effi_stream_t stream) {
+    if (!depth || !disp_range || !inv || n_range < 2 || n < 1) return EFFI_ERR_BADARG;
+    hipLaunchKernelGGL(depth_to_inv_kernel, dim3(min(effi_cdiv(n, TPB), 4096)), dim3(TPB), 0, effi_s(stream),
+                       depth, disp_range, n_range, n, inv);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_stage1_hypotheses_f32(const float* disp_range, int n_range, int D, float* depths,
+                                          float* intervals, effi_stream_t stream) {
+    if (!disp_range || !depths || !intervals || n_range < 2 || D < 2) return EFFI_ERR_BADARG;
+    hipLaunchKernelGGL(stage1_hypotheses_kernel, dim3(1), dim3(128), 0, effi_s(stream), disp_range, n_range, D,
+                       depths, intervals);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_upsample_nearest_f32(const float* in, int C, int h, int w, int f, float* out,
+                                         effi_stream_t stream) {
+    if (!in || !out || C < 1 || h < 1 || w < 1 || f < 1) return EFFI_ERR_BADARG;
+    const long n = (long)C * h * f * w * f;
+    hipLaunchKernelGGL(upsample_nearest_kernel, dim3(min(effi_cdiv(n, TPB), 8192)), dim3(TPB), 0, effi_s(stream),
+                       in, C, h, w, f, out);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_view_aggregate_f32(const float* sim_views, const float* weights, int S, int D, int hw,
+                                       float* out, effi_stream_t stream) {
+    if (!sim_views || !weights || !out || S < 1 || S > EFFI_MAX_VIEWS || D < 1 || hw < 1) return EFFI_ERR_BADARG;
+    hipLaunchKernelGGL(view_aggregate_kernel, dim3(effi_cdiv(hw, TPB), effi_cdiv(D, 8)), dim3(TPB), 0, effi_s(stream),
+                       sim_views, weights, S, D, hw, out);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_softmax_regress_conf_f32(const float* logits, const float* depth, long dds, long dps, int D,
+                                             int hw, float* out_depth, float* out_conf, effi_stream_t stream) {
+    if (!logits || !depth || !out_depth || !out_conf || D < 1 || hw < 1) return EFFI_ERR_BADARG;
+    hipLaunchKernelGGL(softmax_regress_conf_kernel, dim3(effi_cdiv(hw, TPB)), dim3(TPB), 0, effi_s(stream), logits,
+                       depth, dds, dps, D, hw, out_depth, out_conf);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_vol_lookup1d_f32(const float* vol, long vds, long vps, int Dp, const float* query, long qds,
+                                     long qys, long qxs, int nq, const float* dmin, const float* dmax, long rps,
+                                     int h, int w, float* out, effi_stream_t stream) {
+    if (!vol || !query || !dmin || !dmax || !out || Dp < 2 || nq < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    hipLaunchKernelGGL(vol_lookup1d_kernel, dim3(effi_cdiv((long)h * w, TPB)), dim3(TPB), 0, effi_s(stream), vol, vds,
+                       vps, Dp, query, qds, qys, qxs, nq, dmin, dmax, rps, h, w, out);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_getcost_f32(const float* inv_depth, const float* disp_range, int n_range, int input_is_depth,
+                                const float* interval,
+                                const float* cur_vol, long cds, long cps, int Dcur, const float* reg_vol, long rds,
+                                long rps, int Dreg, const float* dmin, const float* dmax, long range_ps, int nq, int h,
+                                int w, float* cost, effi_stream_t stream) {
+    if (!inv_depth || !interval || !cur_vol || !reg_vol || !dmin || !dmax || !cost) return EFFI_ERR_BADARG;
+    if (!input_is_depth && (!disp_range || n_range < 2)) return EFFI_ERR_BADARG;
+    if ( Dcur < 2 || Dreg < 2 || nq < 2 || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    hipLaunchKernelGGL(getcost_kernel, dim3(effi_cdiv((long)h * w, TPB)), dim3(TPB), 0, effi_s(stream), inv_depth,
+                       disp_range, n_range, input_is_depth, interval, cur_vol, cds, cps, Dcur, reg_vol, rds, rps, Dreg, dmin, dmax,
+                       range_ps, nq, h * w, cost);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_convex_upsample2x_f32(const float* inv_depth, const float* mask, const float* disp_range,
+                                          int n_range, int h, int w, float* out_inv, float* out_depth,
+                                          effi_stream_t stream) {
+    if (!inv_depth || !mask || (!out_inv && !out_depth) || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    if (out_depth && (!disp_range || n_range < 2)) return EFFI_ERR_BADARG;
+    hipLaunchKernelGGL(convex_upsample2x_kernel, dim3(effi_cdiv((long)h * w, TPB)), dim3(TPB), 0, effi_s(stream),
+                       inv_depth, mask, disp_range, n_range, h, w, out_inv, out_depth);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}

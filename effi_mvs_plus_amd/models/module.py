@@ -1,0 +1,315 @@
+"""Drop-in mirror of the reference's ``models/module.py`` for the cost-volume hot path.
+
+Same public names, constructor/forward signatures and state-dict keys as the reference
+(``models/module.py`` in bdwsq1996/Effi-MVS-plus), so its checkpoints load with ``strict=True`` and its
+drivers call these classes unchanged; the arithmetic runs in the gfx950 kernels behind
+``include/effi_mvs_hip.h``.  Inference only (eval mode, fp32, CUDA tensors): anything else raises --
+there is no eager fallback on this path.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops, packing
+
+
+def _require_eval(mod):
+    if mod.training:
+        raise NotImplementedError(
+            f"{type(mod).__name__}: the HIP path implements inference (eval mode) only; backward kernels are "
+            "the next scope row (SURVEY.md section 8(f) n2). Call model.eval().")
+
+
+def _stack(ts):
+    """Re-attach the batch dimension (a view when B == 1)."""
+    return ts[0].unsqueeze(0) if len(ts) == 1 else torch.stack(ts)
+
+
+def _triple(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
+
+
+# =============================================================================================
+# 3-D conv wrappers (reference: models/module.py:124-166 Conv3d, :168-209 Deconv3d)
+# =============================================================================================
+class Conv3d(nn.Module):
+    """nn.Conv3d (bias iff no BN) -> BatchNorm3d -> ReLU, kernel 3 / padding 1, stride 1 or 2 per axis.
+
+    State-dict keys: ``conv.weight`` [, ``conv.bias``], ``bn.{weight,bias,running_mean,running_var,
+    num_batches_tracked}`` -- identical to the reference.
+    """
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, relu=True, bn=True, bn_momentum=0.1,
+                 init_method="xavier", **kwargs):
+        super().__init__()
+        self.out_channels = out_channels
+        self.kernel_size = kernel_size
+        self.stride = stride
+        self.conv = nn.Conv3d(in_channels, out_channels, kernel_size, stride=stride, bias=(not bn), **kwargs)
+        self.bn = nn.BatchNorm3d(out_channels, momentum=bn_momentum) if bn else None
+        self.relu = relu
+        self._cache = packing.PackCache()
+
+    def _packed(self):
+        t = [self.conv.weight, self.conv.bias]
+        if self.bn is not None:
+            t += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
+        return self._cache.get(t, lambda: packing.pack_conv3d(self.conv, self.bn))
+
+    def run(self, srcs, skip=None):
+        """srcs: list of unbatched planar [Ci,D,h,w] tensors (channel concatenation) -> [cout,Do,ho,wo]."""
+        _require_eval(self)
+        if _triple(self.conv.kernel_size) != (3, 3, 3) or _triple(self.conv.padding) != (1, 1, 1):
+            raise NotImplementedError("Conv3d: only kernel 3 / padding 1 is instantiated on the HIP path")
+        w, b = self._packed()
+        return ops.conv3d_k3(srcs, w, b, self.out_channels, stride=_triple(self.conv.stride), relu=self.relu, skip=skip)
+
+    def forward(self, x):
+        return _stack([self.run([x[i].contiguous()]) for i in range(x.shape[0])])
+
+
+class Deconv3d(nn.Module):
+    """nn.ConvTranspose3d -> BatchNorm3d -> ReLU; kernel 3, padding 1, stride (s,2,2), output_padding (s-1,1,1)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, relu=True, bn=True, bn_momentum=0.1,
+                 init_method="xavier", **kwargs):
+        super().__init__()
+        self.out_channels = out_channels
+        self.stride = stride
+        self.conv = nn.ConvTranspose3d(in_channels, out_channels, kernel_size, stride=stride, bias=(not bn), **kwargs)
+        self.bn = nn.BatchNorm3d(out_channels, momentum=bn_momentum) if bn else None
+        self.relu = relu
+        self._cache = packing.PackCache()
+
+    def _packed(self):
+        t = [self.conv.weight, self.conv.bias]
+        if self.bn is not None:
+            t += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
+        return self._cache.get(t, lambda: packing.pack_deconv3d(self.conv, self.bn))
+
+    def run(self, x, skip=None):
+        _require_eval(self)
+        st, pad, op = _triple(self.conv.stride), _triple(self.conv.padding), _triple(self.conv.output_padding)
+        if _triple(self.conv.kernel_size) != (3, 3, 3) or pad != (1, 1, 1) or st[1:] != (2, 2) or \
+                op != (st[0] - 1, 1, 1) or st[0] not in (1, 2):
+            raise NotImplementedError("Deconv3d: only k3 / p1 / stride (s,2,2) / output_padding (s-1,1,1) is instantiated")
+        w, b = self._packed()
+        return ops.deconv3d_k3(x, w, b, self.out_channels, sz=st[0], relu=self.relu, skip=skip)
+
+    def forward(self, x):
+        return _stack([self.run(x[i].contiguous()) for i in range(x.shape[0])])
+
+
+# =============================================================================================
+# 2-D wrappers used by the view-weight net and by the (stock, out-of-scope) FPN
+# =============================================================================================
+class ConvBnReLU(nn.Module):
+    """3x3 conv (no bias) + BN + ReLU (reference: models/module.py:213-220).  Holds parameters for the
+    fused view-weight kernel; called on its own it runs the stock torch ops (it is not on the hot path
+    individually)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, pad=1):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
+        self.bn = nn.BatchNorm2d(out_channels)
+
+    def forward(self, x):
+        return F.relu(self.bn(self.conv(x)), inplace=True)
+
+
+class Conv2d(nn.Module):
+    """2-D conv + BN + ReLU block of the feature pyramid (reference: models/module.py:32-75)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, relu=True, bn=True, bn_momentum=0.1,
+                 norm_type="BN", init_method="xavier", **kwargs):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, bias=(not bn), **kwargs)
+        self.kernel_size = kernel_size
+        self.stride = stride
+        if not bn:
+            self.bn = None
+        elif norm_type == "IN":
+            self.bn = nn.InstanceNorm2d(out_channels, momentum=bn_momentum)
+        else:
+            self.bn = nn.BatchNorm2d(out_channels, momentum=bn_momentum)
+        self.relu = relu
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.bn is not None:
+            x = self.bn(x)
+        return F.relu(x, inplace=True) if self.relu else x
+
+
+class P_1to8_FeatureNet_Fast(nn.Module):
+    """Feature / context pyramid (reference: models/module.py:346-412).  OUT OF SCOPE for the HIP path
+    (SURVEY.md section 8(f) n1): stock PyTorch-ROCm convolutions, kept only so that the full model is callable
+    with the reference's checkpoints.  Outputs {stage1: 1/8, stage2: 1/4, stage3: 1/2 resolution}."""
+
+    def __init__(self, base_channels=8, in_channel=[8, 16, 32, 64], out_channel=[32, 16, 8], stage_channel=True):
+        super().__init__()
+        self.base_channels = base_channels
+        c0, c1, c2, c3 = in_channel
+
+        def level(cin, cout):
+            return nn.Sequential(Conv2d(cin, cout, 5, stride=2, padding=2), Conv2d(cout, cout, 3, 1, padding=1),
+                                 Conv2d(cout, cout, 3, 1, padding=1))
+
+        self.conv0 = nn.Sequential(Conv2d(3, c0, 3, 1, padding=1), Conv2d(c0, c0, 3, 1, padding=1))
+        self.conv1 = level(c0, c1)
+        self.conv2 = level(c1, c2)
+        self.conv3 = level(c2, c3)
+        o1, o2, o3 = (out_channel[0], out_channel[1], out_channel[2]) if stage_channel else (out_channel[1],) * 3
+        self.out1 = nn.Conv2d(c3, o1, 1, bias=False)
+        self.inner1 = nn.Conv2d(c2, c3, 1, bias=True)
+        self.inner2 = nn.Conv2d(c1, c3, 1, bias=True)
+        self.out2 = nn.Conv2d(c3, o2, 3, padding=1, bias=False)
+        self.out3 = nn.Conv2d(c3, o3, 3, padding=1, bias=False)
+        self.out_channels = [c3, c1, c0]
+
+    def forward(self, x):
+        l1 = self.conv1(self.conv0(x))
+        l2 = self.conv2(l1)
+        top = self.conv3(l2)
+        outputs = {"stage1": self.out1(top)}
+        top = F.interpolate(top, scale_factor=2, mode="nearest") + self.inner1(l2)
+        outputs["stage2"] = self.out2(top)
+        top = F.interpolate(top, scale_factor=2, mode="nearest") + self.inner2(l1)
+        outputs["stage3"] = self.out3(top)
+        return outputs
+
+
+# =============================================================================================
+# a4: 3-D U-Net regulariser (reference: models/module.py:435-463)
+# =============================================================================================
+class CostRegNet_2_sample_FPN3D_Fast(nn.Module):
+    def __init__(self, in_channels, base_channels):
+        super().__init__()
+        b = base_channels
+        self.conv0 = Conv3d(in_channels, b, padding=1)
+        self.conv1 = Conv3d(b, b, padding=1)
+        self.conv2 = Conv3d(b, b * 2, stride=2, padding=1)
+        self.conv3 = Conv3d(b * 2, b * 2, padding=1)
+        self.conv4 = Conv3d(b * 2, b * 4, stride=2, padding=1)
+        self.conv5 = Conv3d(b * 4, b * 4, padding=1)
+        self.conv6 = Deconv3d(b * 4, b * 2, stride=2, padding=1, output_padding=1)
+        self.conv7 = Deconv3d(b * 2, b, stride=2, padding=1, output_padding=1)
+        self.prob = nn.Conv3d(b, 1, 3, stride=1, padding=1, bias=False)
+        self._prob_cache = packing.PackCache()
+
+    def run(self, vol):
+        """vol planar [cin,D,h,w] -> (prob [1,D,h,w], pro [b,D,h,w]); skip adds are fused into the
+        transposed-conv epilogues (added after their ReLU, models/module.py:460-461)."""
+        _require_eval(self)
+        _, D, h, w = vol.shape
+        if D % 4 or h % 4 or w % 4:
+            raise ValueError(f"cost volume dims {D}x{h}x{w} must be multiples of 4 (two stride-2 levels)")
+        c1 = self.conv1.run([self.conv0.run([vol])])
+        c3 = self.conv3.run([self.conv2.run([c1])])
+        x = self.conv5.run([self.conv4.run([c3])])
+        x = self.conv6.run(x, skip=c3)
+        pro = self.conv7.run(x, skip=c1)
+        wp, _ = self._prob_cache.get([self.prob.weight], lambda: packing.pack_conv3d(self.prob, None))
+        prob = ops.conv3d_k3([pro], wp, None, 1, stride=(1, 1, 1), relu=False)
+        return prob, pro
+
+    def forward(self, x):
+        outs = [self.run(x[i].contiguous()) for i in range(x.shape[0])]
+        return _stack([o[0] for o in outs]), _stack([o[1] for o in outs])
+
+
+# =============================================================================================
+# a9: cross-scale propagation block (reference: models/module.py:501-516)
+# =============================================================================================
+class cost_up_small(nn.Module):
+    def __init__(self, in_channels, base_channels, IGEV_cost_channel=1):
+        super().__init__()
+        self.IGEV_cost_channel = IGEV_cost_channel
+        self.conv0 = Conv3d(in_channels, base_channels, stride=(1, 2, 2), padding=1)
+        self.conv_cost = Conv3d(self.IGEV_cost_channel, base_channels, padding=1)
+        self.conv1 = Conv3d(base_channels * 2, base_channels, padding=1)
+        self.conv2 = Deconv3d(base_channels, self.IGEV_cost_channel, stride=(1, 2, 2), padding=1,
+                              output_padding=(0, 1, 1))
+
+    def run(self, x, prior):
+        """x [cin,D,h,w], prior [1,D,h/2,w/2] -> (conv2 [1,D,h,w], conv1 [b,D,h/2,w/2]); the channel
+        concatenation of models/module.py:513 is read in place from the two tensors."""
+        a = self.conv0.run([x])
+        b = self.conv_cost.run([prior])
+        c1 = self.conv1.run([a, b])
+        return self.conv2.run(c1), c1
+
+    def forward(self, x, IGEV_cost):
+        outs = [self.run(x[i].contiguous(), IGEV_cost[i].contiguous()) for i in range(x.shape[0])]
+        return _stack([o[0] for o in outs]), _stack([o[1] for o in outs])
+
+
+# =============================================================================================
+# a1: homography warp (reference: models/module.py:303-344)
+# =============================================================================================
+def homo_warping_new(src_fea, src_proj, ref_proj, depth_values):
+    """src_fea [B,C,H,W]; src_proj/ref_proj [B,4,4]; depth_values [B,D] or [B,D,H,W] -> [B,C,D*H,W].
+
+    Materialises the warped volume for API parity; the fused cost-volume kernels never do.
+    """
+    B, C_, H, W = src_fea.shape
+    D = depth_values.shape[1]
+    outs = []
+    for b in range(B):
+        nhwc = ops.to_nhwc([src_fea[b]])[0]
+        rt = ops.rel_proj(src_proj[b].contiguous(), ref_proj[b].contiguous())
+        dv = depth_values[b]
+        outs.append(ops.homo_warp(nhwc, rt, dv if dv.dim() == 1 else dv, D).view(C_, D * H, W))
+    return _stack(outs)
+
+
+# =============================================================================================
+# a6/a7: small tensor helpers kept for API parity (plain tensor algebra, device agnostic)
+# =============================================================================================
+def depth_regression(p, depth_values):
+    """sum_D p * depth_values (reference: models/module.py:518-524)."""
+    if depth_values.dim() <= 2:
+        depth_values = depth_values.view(*depth_values.shape, 1, 1)
+    return torch.sum(p * depth_values, 1)
+
+
+def get_cur_depth_range_samples(cur_depth, ndepth, depth_inteval_pixel, shape, max_depth=192.0, min_depth=0.0):
+    """Per-pixel hypotheses around cur_depth (reference: models/module.py:554-570).  The fused stage-2/3
+    kernel generates these in registers; this tensor form exists for callers that want the samples."""
+    half = ndepth // 2 * depth_inteval_pixel
+    lo = (cur_depth - half).clamp(min=1e-4)
+    hi = (cur_depth + half).clamp(min=1e-4, max=1e4)
+    assert cur_depth.shape == torch.Size(shape), "cur_depth:{}, input shape:{}".format(cur_depth.shape, shape)
+    step = (hi - lo) / (ndepth - 1)
+    idx = torch.arange(0, ndepth, device=cur_depth.device, dtype=cur_depth.dtype).reshape(1, -1, 1, 1)
+    return (lo.unsqueeze(1) + idx * step.unsqueeze(1)).clamp(min=1e-5)
+
+
+def get_depth_range_samples(cur_depth, ndepth, depth_inteval_pixel, device, dtype, shape, max_depth=192.0,
+                            min_depth=0.0):
+    """(B,D) input: uniform samples between first and last entry, repeated over the map;
+    (B,H,W) input: per-pixel samples (reference: models/module.py:572-591)."""
+    if cur_depth.dim() == 2:
+        lo, hi = cur_depth[:, 0], cur_depth[:, -1]
+        step = (hi - lo) / (ndepth - 1)
+        idx = torch.arange(0, ndepth, device=device, dtype=dtype).reshape(1, -1)
+        s = lo.unsqueeze(1) + idx * step.unsqueeze(1)
+        return s.unsqueeze(-1).unsqueeze(-1).repeat(1, 1, shape[1], shape[2])
+    return get_cur_depth_range_samples(cur_depth, ndepth, depth_inteval_pixel, shape, max_depth, min_depth)
+
+
+def mvs_loss(inputs, depth_gt_ms, mask_ms, dloss, depth_values=[425, 935], loss_rate=0.9):
+    """Smooth-L1 over the cascade's outputs with geometric weights (reference: models/module.py:526-552).
+    Training-side consumer of the path's outputs; plain tensor algebra."""
+    total = torch.tensor(0.0, dtype=torch.float32, device=mask_ms["stage1"].device, requires_grad=False)
+    per_output = {}
+    n = len(inputs)
+    for i, est in enumerate(inputs):
+        key = "stage{}".format(dloss[i])
+        valid = mask_ms[key] > 0.5
+        li = F.smooth_l1_loss(est[valid], depth_gt_ms[key][valid], reduction="mean")
+        per_output["l{}".format(i)] = li
+        total = total + (1.0 if i == 0 else loss_rate ** (n - i - 1)) * li
+    return total, per_output

@@ -1,0 +1,223 @@
+"""Drop-in mirror of the reference's ``models/update.py`` (GRU update block) on the HIP path.
+
+Class names, constructor / forward signatures, return structures and state-dict keys follow
+``models/update.py`` of bdwsq1996/Effi-MVS-plus.  All 2-D convolutions run on the fp32 matrix cores
+(``effi_conv2d_f32``), with bias / activation / GRU gating / depth update fused into their epilogues and
+channel concatenations (``torch.cat`` at update.py:41-42,46,92,94) read in place from their parts.
+Inference only.
+"""
+from __future__ import annotations
+
+import functools
+
+import torch
+import torch.nn as nn
+
+from .. import ops, packing
+from .module import _require_eval
+
+
+def _pack(cache, conv, scale=1.0):
+    return cache.get([conv.weight, conv.bias], lambda: packing.pack_conv2d_mfma(conv.weight, conv.bias, scale))
+
+
+def _unbatched(t):
+    """Iterate a [B,...] tensor as contiguous unbatched slices."""
+    return [t[i].contiguous() for i in range(t.shape[0])]
+
+
+def _stack(ts):
+    """Re-attach the batch dimension (a view when B == 1)."""
+    return ts[0].unsqueeze(0) if len(ts) == 1 else torch.stack(ts)
+
+
+class DepthHead(nn.Module):
+    """3x3 conv -> ReLU -> 3x3 conv (1 channel) -> act (reference: models/update.py:10-27)."""
+
+    def __init__(self, input_dim=256, hidden_dim=128, scale=False):
+        super().__init__()
+        self.scale = scale
+        self.conv1 = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.conv2 = nn.Conv2d(hidden_dim, 1, 3, padding=1)
+        self.relu = nn.ReLU(inplace=True)
+        self.dropout = nn.Dropout2d(p=0.1)
+        self._c1, self._c2 = packing.PackCache(), packing.PackCache()
+
+    def run_hidden(self, net, out=None):
+        w, b = _pack(self._c1, self.conv1)
+        return ops.conv2d([net], w, b, self.conv1.out_channels, 3, act=ops.ACT_RELU, out0=out)
+
+    def run_update(self, hidden, inv_depth, disp_range):
+        """Fused tail: inv_new = inv_depth + tanh(conv2(hidden)); also the depth it scales to."""
+        w, b = _pack(self._c2, self.conv2)
+        return ops.conv2d([hidden], w, b, 1, 3, epilogue=ops.EPI_HEAD, aux0=inv_depth, disp_range=disp_range)
+
+    def forward(self, x_d, act_fn=torch.tanh):
+        _require_eval(self)
+        w, b = _pack(self._c2, self.conv2)
+        outs = []
+        for x in _unbatched(x_d):
+            hid = self.run_hidden(x)
+            if act_fn is torch.tanh:
+                outs.append(ops.conv2d([hid], w, b, 1, 3, act=ops.ACT_TANH))
+            else:
+                outs.append(act_fn(ops.conv2d([hid], w, b, 1, 3, act=ops.ACT_NONE)))
+        return _stack(outs)
+
+
+class ConvGRU(nn.Module):
+    """z, r = sigmoid(conv([h,x])); q = tanh(conv([r*h, x])); h' = (1-z)h + zq  (reference: update.py:33-49).
+    convz and convr share their input and run as ONE convolution with 2*hidden output channels whose
+    epilogue writes z and r*h; convq's epilogue applies the gate."""
+
+    def __init__(self, hidden_dim=128, input_dim=192 + 128):
+        super().__init__()
+        self.convz = nn.Conv2d(hidden_dim + input_dim, hidden_dim, 3, padding=1)
+        self.convr = nn.Conv2d(hidden_dim + input_dim, hidden_dim, 3, padding=1)
+        self.convq = nn.Conv2d(hidden_dim + input_dim, hidden_dim, 3, padding=1)
+        self._czr, self._cq = packing.PackCache(), packing.PackCache()
+
+    def _packed_zr(self):
+        t = [self.convz.weight, self.convz.bias, self.convr.weight, self.convr.bias]
+        return self._czr.get(t, lambda: packing.pack_conv2d_mfma(
+            torch.cat([self.convz.weight, self.convr.weight], 0), torch.cat([self.convz.bias, self.convr.bias], 0)))
+
+    def run(self, h, xs, z_buf=None, rh_buf=None, out=None):
+        hd = self.convz.out_channels
+        if hd % 16:
+            raise NotImplementedError("ConvGRU: hidden_dim must be a multiple of 16 on the HIP path")
+        wzr, bzr = self._packed_zr()
+        z, rh = ops.conv2d([h] + xs, wzr, bzr, 2 * hd, 3, epilogue=ops.EPI_GRU_ZR, aux0=h, out0=z_buf, out1=rh_buf)
+        wq, bq = _pack(self._cq, self.convq)
+        return ops.conv2d([rh] + xs, wq, bq, hd, 3, epilogue=ops.EPI_GRU_Q, aux0=h, aux1=z, out0=out)
+
+    def forward(self, h, *x_list):
+        _require_eval(self)
+        if len(x_list) > 2:
+            raise NotImplementedError("ConvGRU: at most two input tensors besides h")
+        xs = [_unbatched(x) for x in x_list]
+        return _stack([self.run(hb, [x[i] for x in xs]) for i, hb in enumerate(_unbatched(h))])
+
+
+class ProjectionInput(nn.Module):
+    """Encoder of (inverse depth, cost lookup, context) (reference: models/update.py:69-99)."""
+
+    def __init__(self, cost_dim, hidden_dim, context_dim, out_chs, depth_num=1, G=8):
+        super().__init__()
+        self.convc1 = nn.Conv2d(cost_dim, hidden_dim, 1, padding=0)
+        self.convc2 = nn.Conv2d(hidden_dim, hidden_dim, 3, padding=1)
+        self.convd1 = nn.Conv2d(depth_num, hidden_dim, 7, padding=3)
+        self.convd2 = nn.Conv2d(hidden_dim, hidden_dim, 3, padding=1)
+        self.convd = nn.Conv2d(hidden_dim + hidden_dim, hidden_dim - context_dim, 3, padding=1)
+        self.convc = nn.Conv2d(hidden_dim, hidden_dim, 1, padding=0)
+        self.out_chs = hidden_dim
+        self.dropout = nn.Dropout2d(p=0.1)
+        self._caches = {k: packing.PackCache() for k in ("c1", "c2", "d1", "d2", "d", "c")}
+
+    def run(self, disp, cost, context, bufs=None):
+        """disp [1,h,w], cost [2*nq,h,w], context [cd,h,w] -> [hidden,h,w].  ``bufs``: optional dict of
+        scratch tensors reused across GRU iterations."""
+        hd = self.convc1.out_channels
+        if self.convd1.in_channels != 1:
+            raise NotImplementedError("ProjectionInput: depth_num must be 1 on the HIP path")
+        g = (lambda k: bufs.get(k)) if bufs is not None else (lambda k: None)
+        w, b = _pack(self._caches["c1"], self.convc1)
+        cor = ops.conv2d([cost], w, b, hd, 1, act=ops.ACT_RELU, out0=g("cor1"))
+        w, b = _pack(self._caches["c2"], self.convc2)
+        cor = ops.conv2d([cor], w, b, hd, 3, act=ops.ACT_RELU, out0=g("cor2"))
+        w7, b7 = self._caches["d1"].get([self.convd1.weight, self.convd1.bias],
+                                        lambda: packing.pack_conv2d_c1k7(self.convd1.weight, self.convd1.bias))
+        dfm = ops.conv2d_c1k7_relu(disp, w7, b7, hd, out=g("dfm1"))
+        w, b = _pack(self._caches["d2"], self.convd2)
+        dfm = ops.conv2d([dfm], w, b, hd, 3, act=ops.ACT_RELU, out0=g("dfm2"))
+        w, b = _pack(self._caches["d"], self.convd)
+        mix = ops.conv2d([cor, dfm], w, b, self.convd.out_channels, 3, act=ops.ACT_NONE, out0=g("mix"))
+        w, b = _pack(self._caches["c"], self.convc)
+        return ops.conv2d([mix, context], w, b, hd, 1, act=ops.ACT_RELU, out0=g("enc"))
+
+    def forward(self, disp, cost, context):
+        _require_eval(self)
+        d, c, x = _unbatched(disp), _unbatched(cost), _unbatched(context)
+        return _stack([self.run(d[i], c[i], x[i]) for i in range(len(d))])
+
+
+class BasicUpdateBlock(nn.Module):
+    """seq_len x {cost lookup -> encoder -> ConvGRU -> depth head}; the last iteration also emits the
+    36-channel convex-upsampling mask (reference: models/update.py:101-141)."""
+
+    def __init__(self, hidden_dim=128, cost_dim=256, ratio=8, context_dim=64, UpMask=False, Inverse=False,
+                 cost_num=1, G=8):
+        super().__init__()
+        self.encoder = ProjectionInput(cost_dim=cost_dim * cost_num, hidden_dim=hidden_dim, context_dim=context_dim,
+                                       out_chs=hidden_dim, G=G)
+        self.depth_gru = ConvGRU(hidden_dim=hidden_dim, input_dim=self.encoder.out_chs)
+        self.depth_head = DepthHead(hidden_dim, hidden_dim=hidden_dim, scale=False)
+        self.UpMask = UpMask
+        self.Inverse = Inverse
+        self.mask = nn.Sequential(nn.Conv2d(hidden_dim, hidden_dim * 2, 3, padding=1), nn.ReLU(inplace=True),
+                                  nn.Conv2d(hidden_dim * 2, ratio * ratio * 9, 1, padding=0))
+        self._m0, self._m2 = packing.PackCache(), packing.PackCache()
+        self.last_depths = None     # depths of the last forward's iterations (filled on the fused path)
+
+    def run_mask(self, net):
+        """0.25 * mask(net); the factor is folded into the 1x1 conv's weights and bias (exact: power of two)."""
+        w, b = _pack(self._m0, self.mask[0])
+        hid = ops.conv2d([net], w, b, self.mask[0].out_channels, 3, act=ops.ACT_RELU)
+        w, b = _pack(self._m2, self.mask[2], scale=0.25)
+        return ops.conv2d([hid], w, b, self.mask[2].out_channels, 1, act=ops.ACT_NONE)
+
+    # -- fused path: the cost lookup is our GetCost and scale_inv_depth is the global-range rescale ------
+    def run_fused(self, net, lookup, inv_depth, context, seq_len, disp_range):
+        """Unbatched tensors; ``lookup(inv_depth, out)`` fills the [2*nq,h,w] cost for a normalised
+        inverse-depth map.  Returns (net, mask_list, inv_list, depth_list)."""
+        hd = net.shape[0]
+        h, w = net.shape[-2:]
+        dev = net.device
+        mk = lambda c: torch.empty(c, h, w, device=dev, dtype=torch.float32)
+        bufs = {"cor1": mk(hd), "cor2": mk(hd), "dfm1": mk(hd), "dfm2": mk(hd),
+                "mix": mk(self.encoder.convd.out_channels), "enc": mk(hd)}
+        z_buf, rh_buf, head_buf, cost_buf = mk(hd), mk(hd), mk(hd), None
+        inv_list, mask_list, depth_list = [], [], []
+        for i in range(seq_len):
+            cost_buf = lookup(inv_depth, cost_buf)
+            x = self.encoder.run(inv_depth, cost_buf, context, bufs)
+            net = self.depth_gru.run(net, [x], z_buf, rh_buf)          # fresh tensor: callers keep every state
+            hid = self.depth_head.run_hidden(net, head_buf)
+            inv_depth, depth = self.depth_head.run_update(hid, inv_depth, disp_range)
+            inv_list.append(inv_depth)
+            depth_list.append(depth)
+            mask_list.append(self.run_mask(net) if (self.UpMask and i == seq_len - 1) else inv_depth)
+        return net, mask_list, inv_list, depth_list
+
+    def forward(self, net, depth_cost_func, inv_depth, context, seq_len=4, scale_inv_depth=None):
+        _require_eval(self)
+        from .Effi_MVS_plus import GetCost, disp_to_depth     # late import (module cycle)
+        B = net.shape[0]
+        fused = (isinstance(depth_cost_func, functools.partial) and isinstance(depth_cost_func.func, GetCost)
+                 and isinstance(scale_inv_depth, functools.partial) and scale_inv_depth.func is disp_to_depth
+                 and hasattr(scale_inv_depth, "effi_disp_range"))
+        nets, masks, invs, depths = [], [], [], []
+        for b in range(B):
+            nb, ib, cb = net[b].contiguous(), inv_depth[b].contiguous(), context[b].contiguous()
+            if fused:
+                lookup = depth_cost_func.func.make_lookup(b, disp_range=scale_inv_depth.effi_disp_range,
+                                                          **depth_cost_func.keywords)
+                n, m, iv, dp = self.run_fused(nb, lookup, ib, cb, seq_len, scale_inv_depth.effi_disp_range[b])
+            else:
+                # generic callables: same kernels, but the lookup goes through the public GetCost signature
+                n, m, iv, dp = nb, [], [], None
+                cur = ib
+                for i in range(seq_len):
+                    depth = scale_inv_depth(cur.unsqueeze(0))[1]
+                    cost = depth_cost_func(depth, iter=i)[0].contiguous()
+                    x = self.encoder.run(cur, cost, cb)
+                    n = self.depth_gru.run(n, [x])
+                    cur = cur + self.depth_head(n.unsqueeze(0))[0]
+                    iv.append(cur)
+                    m.append(self.run_mask(n) if (self.UpMask and i == seq_len - 1) else cur)
+            nets.append(n), masks.append(m), invs.append(iv), depths.append(dp)
+        self.last_depths = None if depths[0] is None else [_stack([d[i] for d in depths]) for i in range(seq_len)]
+        net_out = _stack(nets)
+        mask_list = [_stack([m[i] for m in masks]) for i in range(seq_len)]
+        inv_list = [_stack([v[i] for v in invs]) for i in range(seq_len)]
+        return net_out, mask_list, inv_list

@@ -1,0 +1,356 @@
+"""Tensor-level wrappers over the C ABI.  PyTorch is used for device memory and the current stream only.
+
+All functions take fp32 CUDA (ROCm) tensors without a batch dimension and enqueue on the current
+stream.  CPU tensors raise: there is no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import EffiLibraryError, check
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
+EPI_PLAIN, EPI_GRU_ZR, EPI_GRU_Q, EPI_HEAD = 0, 1, 2, 3
+MAX_VIEWS = 12
+
+
+def _t(x: torch.Tensor, name: str, contiguous=True) -> torch.Tensor:
+    if not isinstance(x, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if not x.is_cuda:
+        raise EffiLibraryError(f"{name}: CPU tensor passed to the HIP path (no CPU fallback exists)")
+    if x.dtype != torch.float32:
+        raise TypeError(f"{name}: fp32 only (got {x.dtype}); the reference path is fp32 (models/module.py:318)")
+    if contiguous and not x.is_contiguous():
+        raise ValueError(f"{name}: must be contiguous")
+    return x
+
+
+def _p(x):
+    return C.c_void_p(x.data_ptr()) if x is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+def _int_array(vals):
+    return (C.c_int * len(vals))(*vals)
+
+
+# ---------------------------------------------------------------------------------------------
+def compose_rel_proj(pairs: torch.Tensor) -> torch.Tensor:
+    """pairs [N,2,4,4] -> rt [N-1,12]  (K.[R|t] then P_src . P_ref^-1)."""
+    _t(pairs, "pairs")
+    n = pairs.shape[0]
+    rt = torch.empty(n - 1, 12, device=pairs.device, dtype=torch.float32)
+    check(_lib.lib().effi_compose_rel_proj_f32(_p(pairs), n, _p(rt), _stream()), "effi_compose_rel_proj_f32")
+    return rt
+
+
+def rel_proj(src_proj: torch.Tensor, ref_proj: torch.Tensor) -> torch.Tensor:
+    _t(src_proj, "src_proj"), _t(ref_proj, "ref_proj")
+    rt = torch.empty(12, device=src_proj.device, dtype=torch.float32)
+    check(_lib.lib().effi_rel_proj_f32(_p(src_proj), _p(ref_proj), _p(rt), _stream()), "effi_rel_proj_f32")
+    return rt
+
+
+def to_nhwc(feats):
+    """list of planar [C,h,w] maps -> list of channel-last [h,w,C] maps.  A map that is already
+    channel-last in memory (torch.channels_last) is passed through without a copy."""
+    out, todo_src, todo_dst = [None] * len(feats), [], []
+    for i, f in enumerate(feats):
+        _t(f, "feature", contiguous=False)
+        C_, h, w = f.shape
+        if f.permute(1, 2, 0).is_contiguous() and C_ > 1:
+            out[i] = f.permute(1, 2, 0)
+        else:
+            if not f.is_contiguous():
+                raise ValueError("feature map must be planar-contiguous or channels-last")
+            d = torch.empty(h, w, C_, device=f.device, dtype=torch.float32)
+            out[i] = d
+            todo_src.append(f)
+            todo_dst.append(d)
+    if todo_src:
+        C_, h, w = todo_src[0].shape
+        for k in range(0, len(todo_src), MAX_VIEWS + 1):
+            s, d = todo_src[k:k + MAX_VIEWS + 1], todo_dst[k:k + MAX_VIEWS + 1]
+            check(_lib.lib().effi_planar_to_nhwc_f32(_ptr_array(s), _ptr_array(d), len(s), C_, h * w, _stream()),
+                  "effi_planar_to_nhwc_f32")
+    return out
+
+
+def _depth_strides(depth: torch.Tensor, D, h, w):
+    """depth hypotheses given as [D] (uniform), [D,h,w] contiguous, or an expanded [D,h,w] view."""
+    if depth.dim() == 1:
+        return depth, 1, 0
+    if depth.stride(1) == 0 and depth.stride(2) == 0:
+        return depth, depth.stride(0), 0
+    if not depth.is_contiguous():
+        depth = depth.contiguous()
+    return depth, h * w, 1
+
+
+def homo_warp(src_nhwc, rt, depth, D):
+    h, w, Cc = src_nhwc.shape
+    _t(src_nhwc, "src_nhwc"), _t(rt, "rt"), _t(depth, "depth", contiguous=False)
+    depth, dds, dps = _depth_strides(depth, D, h, w)
+    out = torch.empty(Cc, D, h, w, device=src_nhwc.device, dtype=torch.float32)
+    check(_lib.lib().effi_homo_warp_f32(_p(src_nhwc), _p(rt), _p(depth), dds, dps, Cc, h, w, D, _p(out), _stream()),
+          "effi_homo_warp_f32")
+    return out
+
+
+def warpcorr_views(ref_nhwc, srcs_nhwc, rt, depth, D):
+    """-> (sim_views [S,D,h,w], entropy [S,h,w])."""
+    h, w, Cc = ref_nhwc.shape
+    S = len(srcs_nhwc)
+    _t(ref_nhwc, "ref_nhwc"), _t(rt, "rt"), _t(depth, "depth", contiguous=False)
+    for s in srcs_nhwc:
+        _t(s, "src_nhwc")
+        if tuple(s.shape) != (h, w, Cc):
+            raise ValueError("source / reference feature shapes differ")
+    if rt.shape[0] != S:
+        raise ValueError("Different number of images and projection matrices")
+    depth, dds, dps = _depth_strides(depth, D, h, w)
+    sim = torch.empty(S, D, h, w, device=ref_nhwc.device, dtype=torch.float32)
+    ent = torch.empty(S, h, w, device=ref_nhwc.device, dtype=torch.float32)
+    check(_lib.lib().effi_warpcorr_views_f32(_p(ref_nhwc), _ptr_array(srcs_nhwc), S, _p(rt), _p(depth), dds, dps,
+                                              Cc, h, w, D, _p(sim), _p(ent), _stream()), "effi_warpcorr_views_f32")
+    return sim, ent
+
+
+def pixelwise_net(entropy, params):
+    n, h, w = entropy.shape
+    _t(entropy, "entropy"), _t(params, "params")
+    out = torch.empty_like(entropy)
+    check(_lib.lib().effi_pixelwise_net_f32(_p(entropy), _p(params), n, h, w, _p(out), _stream()),
+          "effi_pixelwise_net_f32")
+    return out
+
+
+def view_aggregate(sim_views, weights):
+    S, D, h, w = sim_views.shape
+    _t(sim_views, "sim_views"), _t(weights, "weights")
+    out = torch.empty(D, h, w, device=sim_views.device, dtype=torch.float32)
+    check(_lib.lib().effi_view_aggregate_f32(_p(sim_views), _p(weights), S, D, h * w, _p(out), _stream()),
+          "effi_view_aggregate_f32")
+    return out
+
+
+def warpcorr_dyn(ref_nhwc, srcs_nhwc, rt, cur_depth, interval, view_w, D):
+    """cur_depth [h,w]; interval: 1-element tensor; view_w [S,h>>k,w>>k] -> (sim [D,h,w], samples [D,h,w])."""
+    h, w, Cc = ref_nhwc.shape
+    S = len(srcs_nhwc)
+    _t(ref_nhwc, "ref_nhwc"), _t(rt, "rt"), _t(cur_depth, "cur_depth"), _t(interval, "interval"), _t(view_w, "view_w")
+    for s in srcs_nhwc:
+        _t(s, "src_nhwc")
+    if view_w.shape[0] != S or rt.shape[0] != S:
+        raise ValueError("view weights / projections / sources disagree on the number of views")
+    vh, vw = view_w.shape[1], view_w.shape[2]
+    shift = 0
+    while (vh << shift) < h:
+        shift += 1
+    if (vh << shift) != h or (vw << shift) != w:
+        raise ValueError(f"view weights {vh}x{vw} are not a power-of-two downsampling of {h}x{w}")
+    sim = torch.empty(D, h, w, device=ref_nhwc.device, dtype=torch.float32)
+    samples = torch.empty(D, h, w, device=ref_nhwc.device, dtype=torch.float32)
+    check(_lib.lib().effi_warpcorr_dyn_f32(_p(ref_nhwc), _ptr_array(srcs_nhwc), S, _p(rt), _p(cur_depth), _p(interval),
+                                            _p(view_w), shift, Cc, h, w, D, _p(sim), _p(samples), _stream()),
+          "effi_warpcorr_dyn_f32")
+    return sim, samples
+
+
+def conv3d_k3(srcs, weight, bias, cout, stride=(1, 1, 1), relu=True, skip=None):
+    """srcs: list of planar [Ci,D,h,w]; weight packed [cin,27,cout]; -> [cout,Do,ho,wo]."""
+    for s in srcs:
+        _t(s, "conv3d input")
+    _, D, h, w = srcs[0].shape
+    sz, sxy = int(stride[0]), int(stride[1])
+    Do, ho, wo = (D - 1) // sz + 1, (h - 1) // sxy + 1, (w - 1) // sxy + 1
+    out = torch.empty(cout, Do, ho, wo, device=srcs[0].device, dtype=torch.float32)
+    if skip is not None:
+        _t(skip, "skip")
+        assert skip.shape == out.shape
+    check(_lib.lib().effi_conv3d_k3_f32(_ptr_array(srcs), _int_array([s.shape[0] for s in srcs]), len(srcs),
+                                         _p(weight), _p(bias), cout, D, h, w, sz, sxy, int(relu), _p(skip), _p(out),
+                                         _stream()), "effi_conv3d_k3_f32")
+    return out
+
+
+def deconv3d_k3(x, weight, bias, cout, sz=2, relu=True, skip=None):
+    _t(x, "deconv3d input")
+    cin, D, h, w = x.shape
+    out = torch.empty(cout, sz * D, 2 * h, 2 * w, device=x.device, dtype=torch.float32)
+    if skip is not None:
+        _t(skip, "skip")
+        assert skip.shape == out.shape, f"skip {tuple(skip.shape)} vs out {tuple(out.shape)}"
+    check(_lib.lib().effi_deconv3d_k3_f32(_p(x), cin, _p(weight), _p(bias), cout, D, h, w, sz, int(relu), _p(skip),
+                                           _p(out), _stream()), "effi_deconv3d_k3_f32")
+    return out
+
+
+def softmax_regress_conf(logits, depth):
+    """logits [D,h,w]; depth [D] / [D,h,w] -> (depth [h,w], confidence [h,w])."""
+    D, h, w = logits.shape
+    _t(logits, "logits"), _t(depth, "depth", contiguous=False)
+    depth, dds, dps = _depth_strides(depth, D, h, w)
+    od = torch.empty(h, w, device=logits.device, dtype=torch.float32)
+    oc = torch.empty(h, w, device=logits.device, dtype=torch.float32)
+    check(_lib.lib().effi_softmax_regress_conf_f32(_p(logits), _p(depth), dds, dps, D, h * w, _p(od), _p(oc), _stream()),
+          "effi_softmax_regress_conf_f32")
+    return od, oc
+
+
+def _vol_strides(vol, h, w):
+    """Per-pixel D-vector volume as planar [D,h,w] or pixel-major [h*w,1,1,D] (the reference's `pro`)."""
+    _t(vol, "volume", contiguous=False)
+    if vol.dim() == 3:
+        if not vol.is_contiguous():
+            vol = vol.contiguous()
+        return vol, h * w, 1, vol.shape[0]
+    if vol.dim() == 4 and vol.shape[0] == h * w:
+        return vol, vol.stride(3), vol.stride(0), vol.shape[3]
+    raise ValueError(f"unsupported volume shape {tuple(vol.shape)}")
+
+
+def _range_ptr(r, h, w):
+    """depth-range bound: scalar-like tensor (global) or per-pixel [.., h, w] map."""
+    _t(r, "range", contiguous=False)
+    if r.numel() == 1:
+        return r.reshape(1), 0
+    if r.numel() == h * w:
+        return r.reshape(h, w).contiguous(), 1
+    raise ValueError(f"depth range with {r.numel()} elements does not match {h}x{w}")
+
+
+def vol_lookup1d(vol, query, dmin, dmax, h, w):
+    """query [nq, h', w'] with (h', w') == (h, w) or exactly 2x (read nearest-downsampled)."""
+    vol, vds, vps, Dp = _vol_strides(vol, h, w)
+    _t(query, "query")
+    nq, qh, qw = query.shape
+    if (qh, qw) == (h, w):
+        qys, qxs = qw, 1
+    elif (qh // 2, qw // 2) == (h, w):
+        qys, qxs = 2 * qw, 2        # F.interpolate(nearest) to half size picks the even samples
+    else:
+        raise ValueError("query resolution must equal the volume's or be twice it")
+    dmin_t, rps = _range_ptr(dmin, h, w)
+    dmax_t, rps2 = _range_ptr(dmax, h, w)
+    if rps != rps2:
+        raise ValueError("depth_min / depth_max must both be global or both per-pixel")
+    out = torch.empty(nq, h, w, device=query.device, dtype=torch.float32)
+    check(_lib.lib().effi_vol_lookup1d_f32(_p(vol), vds, vps, Dp, _p(query), qh * qw, qys, qxs, nq, _p(dmin_t),
+                                            _p(dmax_t), rps, h, w, _p(out), _stream()), "effi_vol_lookup1d_f32")
+    return out
+
+
+def getcost(x, disp_range, interval, cur_vol, reg_vol, dmin, dmax, nq, h, w, input_is_depth=False, out=None):
+    _t(x, "inv_depth"), _t(interval, "interval")
+    cur_vol, cds, cps, Dc = _vol_strides(cur_vol, h, w)
+    reg_vol, rds, rps, Dr = _vol_strides(reg_vol, h, w)
+    dmin_t, gps = _range_ptr(dmin, h, w)
+    dmax_t, gps2 = _range_ptr(dmax, h, w)
+    if gps != gps2:
+        raise ValueError("depth_min / depth_max must both be global or both per-pixel")
+    if out is None:
+        out = torch.empty(2 * nq, h, w, device=x.device, dtype=torch.float32)
+    n_range = 0 if disp_range is None else disp_range.numel()
+    check(_lib.lib().effi_getcost_f32(_p(x), _p(disp_range), n_range, int(input_is_depth), _p(interval),
+                                       _p(cur_vol), cds, cps, Dc, _p(reg_vol), rds, rps, Dr, _p(dmin_t), _p(dmax_t), gps,
+                                       nq, h, w, _p(out), _stream()), "effi_getcost_f32")
+    return out
+
+
+def conv2d(srcs, wpack, bias, cout, ks, epilogue=EPI_PLAIN, act=ACT_NONE, aux0=None, aux1=None, disp_range=None,
+           out0=None, out1=None):
+    for s in srcs:
+        _t(s, "conv2d input")
+    h, w = srcs[0].shape[-2:]
+    dev = srcs[0].device
+    if out0 is None:
+        if epilogue == EPI_GRU_ZR:
+            out0 = torch.empty(cout // 2, h, w, device=dev, dtype=torch.float32)
+        elif epilogue == EPI_HEAD:
+            out0 = torch.empty(1, h, w, device=dev, dtype=torch.float32)
+        else:
+            out0 = torch.empty(cout, h, w, device=dev, dtype=torch.float32)
+    if out1 is None and epilogue == EPI_GRU_ZR:
+        out1 = torch.empty(cout // 2, h, w, device=dev, dtype=torch.float32)
+    if out1 is None and epilogue == EPI_HEAD:
+        out1 = torch.empty(1, h, w, device=dev, dtype=torch.float32)
+    n_range = 0 if disp_range is None else disp_range.numel()
+    check(_lib.lib().effi_conv2d_f32(_ptr_array(srcs), _int_array([s.shape[0] for s in srcs]), len(srcs), _p(wpack),
+                                      _p(bias), cout, ks, h, w, epilogue, act, _p(aux0), _p(aux1), _p(disp_range),
+                                      n_range, _p(out0), _p(out1), _stream()), "effi_conv2d_f32")
+    return (out0, out1) if out1 is not None else out0
+
+
+def conv2d_c1k7_relu(x, weight, bias, cout, out=None):
+    _t(x, "conv7 input")
+    h, w = x.shape[-2:]
+    if out is None:
+        out = torch.empty(cout, h, w, device=x.device, dtype=torch.float32)
+    check(_lib.lib().effi_conv2d_c1k7_relu_f32(_p(x), _p(weight), _p(bias), cout, h, w, _p(out), _stream()),
+          "effi_conv2d_c1k7_relu_f32")
+    return out
+
+
+def convex_upsample2x(inv_depth, mask, disp_range=None, want_inv=True):
+    """-> (inv [2h,2w] or None, depth [2h,2w] or None); depth needs ``disp_range``."""
+    _t(inv_depth, "inv_depth"), _t(mask, "mask")
+    h, w = inv_depth.shape[-2:]
+    if mask.shape[0] != 36:
+        raise NotImplementedError("convex upsampling is instantiated for ratio 2 (36 mask channels)")
+    out_inv = torch.empty(2 * h, 2 * w, device=mask.device, dtype=torch.float32) if want_inv else None
+    out_depth = None
+    n_range = 0
+    if disp_range is not None:
+        _t(disp_range, "disp_range")
+        n_range = disp_range.numel()
+        out_depth = torch.empty(2 * h, 2 * w, device=mask.device, dtype=torch.float32)
+    check(_lib.lib().effi_convex_upsample2x_f32(_p(inv_depth), _p(mask), _p(disp_range), n_range, h, w,
+                                                 _p(out_inv), _p(out_depth), _stream()), "effi_convex_upsample2x_f32")
+    return out_inv, out_depth
+
+
+def split_tanh_relu(ctx, hd, cd):
+    _t(ctx, "context")
+    _, h, w = ctx.shape
+    hid = torch.empty(hd, h, w, device=ctx.device, dtype=torch.float32)
+    inp = torch.empty(cd, h, w, device=ctx.device, dtype=torch.float32)
+    check(_lib.lib().effi_split_tanh_relu_f32(_p(ctx), hd, cd, h * w, _p(hid), _p(inp), _stream()),
+          "effi_split_tanh_relu_f32")
+    return hid, inp
+
+
+def depth_to_inv(depth, disp_range):
+    _t(depth, "depth"), _t(disp_range, "disp_range")
+    out = torch.empty_like(depth)
+    check(_lib.lib().effi_depth_to_inv_f32(_p(depth), _p(disp_range), disp_range.numel(), depth.numel(), _p(out),
+                                            _stream()), "effi_depth_to_inv_f32")
+    return out
+
+
+def stage1_hypotheses(disp_range, D):
+    _t(disp_range, "disp_range")
+    depths = torch.empty(D, device=disp_range.device, dtype=torch.float32)
+    intervals = torch.empty(5, device=disp_range.device, dtype=torch.float32)   # 3 intervals, depth_min_, depth_max_
+    check(_lib.lib().effi_stage1_hypotheses_f32(_p(disp_range), disp_range.numel(), D, _p(depths), _p(intervals),
+                                                 _stream()), "effi_stage1_hypotheses_f32")
+    return depths, intervals
+
+
+def upsample_nearest(x, f):
+    _t(x, "map")
+    Cc, h, w = x.shape
+    out = torch.empty(Cc, h * f, w * f, device=x.device, dtype=torch.float32)
+    check(_lib.lib().effi_upsample_nearest_f32(_p(x), Cc, h, w, f, _p(out), _stream()), "effi_upsample_nearest_f32")
+    return out

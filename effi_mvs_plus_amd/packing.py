@@ -1,0 +1,103 @@
+"""Host-side weight preparation: BatchNorm folding and re-ordering into the layouts the kernels read.
+
+Runs once per weight version (cached per module, invalidated when a parameter is replaced or
+modified in place, e.g. by ``load_state_dict`` / ``.to()``); it is set-up work, not part of the
+timed path.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def params_key(*tensors):
+    """Cheap fingerprint of a set of parameters/buffers: storage address + in-place version."""
+    return tuple((t.data_ptr(), t._version, t.device) for t in tensors if t is not None)
+
+
+class PackCache:
+    """Per-module cache of packed weights keyed by ``params_key``."""
+
+    def __init__(self):
+        self._key = None
+        self._val = None
+
+    def get(self, tensors, builder):
+        key = params_key(*tensors)
+        if key != self._key:
+            with torch.no_grad():
+                self._val = builder()
+            self._key = key
+        return self._val
+
+
+def bn_scale_shift(bn):
+    """Eval-mode BatchNorm as y = x*scale + shift (models/module.py:148,191,217; eps = bn.eps)."""
+    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    shift = bn.bias - bn.running_mean * scale
+    return scale, shift
+
+
+def pack_conv3d(conv, bn):
+    """nn.Conv3d [cout,cin,3,3,3] (+BN) -> (weight [cin,27,cout], bias [cout] or None)."""
+    w = conv.weight
+    bias = conv.bias
+    if bn is not None:
+        scale, shift = bn_scale_shift(bn)
+        w = w * scale.view(-1, 1, 1, 1, 1)
+        bias = shift if bias is None else bias * scale + shift
+    cout, cin = w.shape[0], w.shape[1]
+    wp = w.permute(1, 2, 3, 4, 0).reshape(cin, 27, cout).contiguous().float()
+    return wp, (None if bias is None else bias.contiguous().float())
+
+
+def pack_deconv3d(conv, bn):
+    """nn.ConvTranspose3d [cin,cout,3,3,3] (+BN) -> (weight [cin,27,cout], bias [cout] or None)."""
+    w = conv.weight
+    bias = conv.bias
+    if bn is not None:
+        scale, shift = bn_scale_shift(bn)
+        w = w * scale.view(1, -1, 1, 1, 1)
+        bias = shift if bias is None else bias * scale + shift
+    cin, cout = w.shape[0], w.shape[1]
+    wp = w.permute(0, 2, 3, 4, 1).reshape(cin, 27, cout).contiguous().float()
+    return wp, (None if bias is None else bias.contiguous().float())
+
+
+def pack_conv2d_mfma(weight, bias, scale=1.0):
+    """[cout,cin,ks,ks] (+bias [cout]) -> (wpack [ceil(cin/4), ks*ks, ceil(cout/16), 64], bias [16*NT]).
+
+    Lane order of the v_mfma_f32_16x16x4_f32 B operand: lane = k*16 + j holds W[cout=16n+j][cin=4g+k].
+    """
+    cout, cin, ks, _ = weight.shape
+    nt, kg = (cout + 15) // 16, (cin + 3) // 4
+    w = torch.zeros(nt * 16, kg * 4, ks * ks, device=weight.device, dtype=torch.float32)
+    w[:cout, :cin] = weight.reshape(cout, cin, ks * ks).float() * scale
+    w = w.view(nt, 16, kg, 4, ks * ks).permute(2, 4, 0, 3, 1).contiguous()     # [kg, tap, nt, k, j]
+    b = torch.zeros(nt * 16, device=weight.device, dtype=torch.float32)
+    if bias is not None:
+        b[:cout] = bias.float() * scale
+    return w.view(kg, ks * ks, nt, 64), b
+
+
+def pack_conv2d_c1k7(weight, bias):
+    """[cout,1,7,7] -> ([49,cout], [cout])."""
+    cout = weight.shape[0]
+    return weight.reshape(cout, 49).t().contiguous().float(), bias.contiguous().float()
+
+
+def pack_pixelwise_net(seq):
+    """ConvBnReLU x3 + Conv2d(8,1,1) -> one fp32 block:
+    w0[9][16] b0[16] | w1[16][9][16] b1[16] | w2[16][9][8] b2[8] | w3[8] b3[1]  (3x3 layers [cin][tap][cout])."""
+    parts = []
+    for i in range(3):
+        conv, bn = seq[i].conv, seq[i].bn
+        scale, shift = bn_scale_shift(bn)
+        w = conv.weight * scale.view(-1, 1, 1, 1)                          # [cout,cin,3,3]
+        cout, cin = w.shape[0], w.shape[1]
+        parts.append(w.permute(1, 2, 3, 0).reshape(cin * 9 * cout))         # [cin][tap][cout]
+        parts.append(shift.reshape(-1))
+    parts.append(seq[3].weight.reshape(-1))
+    parts.append(seq[3].bias.reshape(-1))
+    blk = torch.cat([p.float() for p in parts]).contiguous()
+    assert blk.numel() == 144 + 16 + 2304 + 16 + 1152 + 8 + 8 + 1, blk.numel()
+    return blk

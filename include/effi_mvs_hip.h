@@ -1,0 +1,194 @@
+/*
+ * effi_mvs_hip.h -- C ABI of the MI355X (gfx950) kernels for the Effi-MVS+ cost-volume hot path.
+ *
+ * The reference (bdwsq1996/Effi-MVS-plus) is pure Python/PyTorch: it has no FFI of its own.  What a
+ * binding for this path would bind is the set of operator call sites listed in SURVEY.md section 2.1
+ * (K1..K11); every entry point below names the reference lines it replaces.  Paths are relative to
+ * the reference repository root.
+ *
+ * Conventions (all entry points):
+ *   - plain C, no torch / HIP types in the signatures; `stream` is a hipStream_t passed as void*.
+ *   - every pointer is a DEVICE pointer owned by the caller unless the comment says "host".
+ *   - returns 0 (EFFI_OK) or a negative error code; never throws, allocates, frees or synchronises.
+ *   - re-entrant; work is enqueued on `stream` of the current device; graph-capture safe.
+ *   - tensors are fp32, batch size 1 per call (the host loops over the batch); layouts are spelled
+ *     out per argument.  "planar" = [C][H][W] (torch NCHW with N=1), "nhwc" = [H][W][C].
+ */
+#ifndef EFFI_MVS_HIP_H
+#define EFFI_MVS_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EFFI_OK               0
+#define EFFI_ERR_BADARG      -1   /* null pointer, non-positive size, unsupported channel count ... */
+#define EFFI_ERR_UNSUPPORTED -2   /* shape outside what the kernels are instantiated for */
+#define EFFI_ERR_LAUNCH      -3   /* hipGetLastError() != hipSuccess after the launch */
+
+#define EFFI_MAX_VIEWS 12         /* source views per call (T&T script uses num_view=11 -> 10 sources) */
+#define EFFI_MAX_SRC    3         /* concatenated input tensors of one 2-D / 3-D convolution */
+
+typedef void* effi_stream_t;
+
+/* activation / epilogue selectors for effi_conv2d_f32 */
+#define EFFI_ACT_NONE    0
+#define EFFI_ACT_RELU    1
+#define EFFI_ACT_SIGMOID 2
+#define EFFI_ACT_TANH    3
+#define EFFI_EPI_PLAIN   0   /* out0 = act(conv + bias) */
+#define EFFI_EPI_GRU_ZR  1   /* channels [0,hd): out0 = sigmoid(.) (= z);  [hd,2hd): out1 = sigmoid(.) * aux0 (= r*h) */
+#define EFFI_EPI_GRU_Q   2   /* q = tanh(.);  out0 = (1 - aux1) * aux0 + aux1 * q   (aux0 = h, aux1 = z) */
+#define EFFI_EPI_HEAD    3   /* 1 channel: out0 = aux0 + tanh(.) (inverse depth);  out1 = 1/clamp(lo+(hi-lo)*out0, 1e-4) */
+
+int effi_version(void);
+const char* effi_error_string(int code);
+
+/* ---- K11: projection algebra ------------------------------------------------------------------
+ * models/Effi_MVS_plus.py:34-37,217-220 (K.[R|t]) and models/module.py:314-316 (src . ref^-1).
+ * pairs: [n_views][2][4][4] ([v][0] = extrinsic, [v][1][:3][:3] = intrinsic); view 0 = reference.
+ * rt_out: [n_views-1][12] = 9 row-major rotation entries then 3 translation entries of
+ * P_src . P_ref^-1.  Computed in fp64 on the device, rounded once to fp32 (numerics). */
+int effi_compose_rel_proj_f32(const float* pairs, int n_views, float* rt_out, effi_stream_t stream);
+/* Same for matrices that are already composed (the argument form of homo_warping_new,
+ * models/module.py:303-316).  src_proj, ref_proj: [4][4]; rt_out: [12]. */
+int effi_rel_proj_f32(const float* src_proj, const float* ref_proj, float* rt_out, effi_stream_t stream);
+
+/* ---- layout: planar [C][HW] -> nhwc [HW][C] for n tensors (feature maps arrive NCHW from the FPN,
+ * models/module.py:400-409).  srcs/dsts: HOST arrays of n device pointers, n <= EFFI_MAX_VIEWS+1. */
+int effi_planar_to_nhwc_f32(const float* const* srcs, float* const* dsts, int n, int C, int HW,
+                            effi_stream_t stream);
+
+/* ---- K1/K2: homography warp, full warped volume (API parity for homo_warping_new,
+ * models/module.py:303-344; the fused kernels below never materialise this volume).
+ * src_nhwc [h][w][C]; rt [12]; depth: hypothesis d of pixel p at depth[d*depth_dstride + p*depth_pstride]
+ * (pstride 0 = same hypotheses for every pixel); out planar [C][D][h][w].  C in {8,16,32}. */
+int effi_homo_warp_f32(const float* src_nhwc, const float* rt, const float* depth, long depth_dstride,
+                       long depth_pstride, int C, int h, int w, int D, float* out, effi_stream_t stream);
+
+/* ---- K1+K2+K3 (+ entropy of K4), stage 1: per-view correlation volume.
+ * models/Effi_MVS_plus.py:38-40 (warp, mean_c(warped*ref)), :43-44 (softmax over D, entropy).
+ * ref_nhwc [h][w][C]; src_nhwc: HOST array of S device pointers; rt [S][12]; depth as above;
+ * sim_views [S][D][h][w]; entropy [S][h][w]. */
+int effi_warpcorr_views_f32(const float* ref_nhwc, const float* const* src_nhwc, int S, const float* rt,
+                            const float* depth, long depth_dstride, long depth_pstride,
+                            int C, int h, int w, int D, float* sim_views, float* entropy,
+                            effi_stream_t stream);
+
+/* ---- K4: view-weight net, fused 3x(3x3 conv+BN+ReLU) -> 1x1 conv -> sigmoid.
+ * models/Effi_MVS_plus.py:361-362, models/module.py:213-220.  BN is folded by the host.
+ * entropy [n][h][w] -> weight [n][h][w].  params: packed fp32 block, every 3x3 layer stored
+ * [cin][tap][cout]:  w0[9][16] b0[16] | w1[16][9][16] b1[16] | w2[16][9][8] b2[8] | w3[8] b3[1]. */
+int effi_pixelwise_net_f32(const float* entropy, const float* params, int n, int h, int w, float* weight,
+                           effi_stream_t stream);
+
+/* ---- K3: view-weighted aggregation  sim = sum_v sim_v*w_v / (sum_v w_v + 1e-6).
+ * models/Effi_MVS_plus.py:48-53,67.  sim_views [S][D][hw]; weights [S][hw]; out [D][hw]. */
+int effi_view_aggregate_f32(const float* sim_views, const float* weights, int S, int D, int hw, float* out,
+                            effi_stream_t stream);
+
+/* ---- K1+K2+K3 + hypothesis generation, stages 2/3: dynamic correlation volume.
+ * models/Effi_MVS_plus.py:184-251 (GetCost_initvolume.forward, Inverse=True) and
+ * models/module.py:554-570 (get_cur_depth_range_samples, in inverse depth).
+ * cur_depth [h][w]; interval: device pointer to ONE float (inverse-depth step);
+ * view_w [S][h>>vw_shift][w>>vw_shift] (nearest-upsampled on the fly: F.interpolate nearest,
+ * models/Effi_MVS_plus.py:497); sim [D][h][w]; samples [D][h][w] (depth hypotheses). */
+int effi_warpcorr_dyn_f32(const float* ref_nhwc, const float* const* src_nhwc, int S, const float* rt,
+                          const float* cur_depth, const float* interval, const float* view_w, int vw_shift,
+                          int C, int h, int w, int D, float* sim, float* samples, effi_stream_t stream);
+
+/* ---- K5/K6: 3-D convolutions, kernel 3, padding 1, BN folded into (weight, bias) by the host.
+ * models/module.py:124-160 (Conv3d), :168-203 (Deconv3d), :439-452, :505-508.
+ * Input = channel concatenation of n_src planar tensors [Ci][D][h][w] (torch.cat, module.py:513).
+ * weight: [cin][kd][ky][kx][cout] (host-packed from [cout][cin][3][3][3]); bias [cout] or NULL.
+ * stride (sz,sxy,sxy) with sz in {1,2}, sxy in {1,2}; out planar [cout][Do][ho][wo],
+ * Do = (D-1)/sz+1 etc.  out = relu?(conv + bias) (+ skip, added AFTER the ReLU: module.py:460-461). */
+int effi_conv3d_k3_f32(const float* const* srcs, const int* src_channels, int n_src,
+                       const float* weight, const float* bias, int cout,
+                       int D, int h, int w, int sz, int sxy, int relu, const float* skip,
+                       float* out, effi_stream_t stream);
+/* Transposed 3-D convolution, kernel 3, padding 1, stride (sz,2,2), output_padding (sz-1,1,1):
+ * out dims (sz*D, 2h, 2w).  models/module.py:448-450 (sz=2), :508 (sz=1).
+ * in planar [cin][D][h][w]; weight [cin][kd][ky][kx][cout] (host-packed from torch's
+ * [cin][cout][3][3][3]); out = relu?(deconv + bias) (+ skip). */
+int effi_deconv3d_k3_f32(const float* in, int cin, const float* weight, const float* bias, int cout,
+                         int D, int h, int w, int sz, int relu, const float* skip,
+                         float* out, effi_stream_t stream);
+
+/* ---- K7: softmax over D, soft-argmin depth, 4-window confidence.
+ * models/Effi_MVS_plus.py:79-88, models/module.py:518-524.
+ * logits [D][hw]; depth hypotheses as in effi_homo_warp_f32; out_depth [hw]; out_conf [hw]. */
+int effi_softmax_regress_conf_f32(const float* logits, const float* depth, long depth_dstride,
+                                  long depth_pstride, int D, int hw, float* out_depth, float* out_conf,
+                                  effi_stream_t stream);
+
+/* ---- K8: 1-D volume lookup (pro_bilinear_sampler), models/Effi_MVS_plus.py:102-134,151-164.
+ * vol: value k of pixel p at vol[k*vol_dstride + p*vol_pstride], Dp entries per pixel, (h,w) pixels.
+ * query: depth q of pixel (y,x) at query[q*q_dstride + y*q_ystride + x*q_xstride]  (strides let the
+ * caller read a nearest-downsampled view of a finer map, models/Effi_MVS_plus.py:514).
+ * dmin/dmax: depth range of the volume, element of pixel p at dmin[p*range_pstride] (0 = global).
+ * out [nq][h][w]. */
+int effi_vol_lookup1d_f32(const float* vol, long vol_dstride, long vol_pstride, int Dp,
+                          const float* query, long q_dstride, long q_ystride, long q_xstride, int nq,
+                          const float* dmin, const float* dmax, long range_pstride,
+                          int h, int w, float* out, effi_stream_t stream);
+
+/* ---- K8 inside the GRU loop: GetCost.forward, models/Effi_MVS_plus.py:257-303 with
+ * models/Effi_MVS_plus.py:138-148 (scale_inv_depth) applied first.
+ * inv_depth [h][w]: normalised inverse depth (input_is_depth = 0; scale_inv_depth is applied in the
+ * kernel) or the depth map itself (input_is_depth = 1, the argument form of GetCost.forward);
+ * disp_range: device pointer to depth_values[0..n-1] (ascending inverse depths, uses [0] and
+ * [n_range-1]; unused when input_is_depth); interval: device pointer to one float;
+ * cur_vol / reg_vol with strides as above; dmin/dmax as above; cost out [2*nq][h][w]
+ * = cat(lookup(cur_vol), lookup(reg_vol)) at nq hypotheses (inv +/- (nq/2)*interval). */
+int effi_getcost_f32(const float* inv_depth, const float* disp_range, int n_range, int input_is_depth,
+                     const float* interval,
+                     const float* cur_vol, long cur_dstride, long cur_pstride, int Dcur,
+                     const float* reg_vol, long reg_dstride, long reg_pstride, int Dreg,
+                     const float* dmin, const float* dmax, long range_pstride, int nq,
+                     int h, int w, float* cost, effi_stream_t stream);
+
+/* ---- K9: 2-D convolutions of the update block on the fp32 MFMA path (v_mfma_f32_16x16x4_f32).
+ * models/update.py:14-15,36-38,73-81,109-112.  ks in {1,3}, padding ks/2, stride 1.
+ * Input = concatenation of n_src planar tensors.  wpack: host-packed
+ * [ceil(cin/4)][ks*ks][ceil(cout/16)][64] (lane order of the MFMA B operand); bias [16*ceil(cout/16)].
+ * epilogue: EFFI_EPI_*; act used by EFFI_EPI_PLAIN; aux0/aux1/out1 per the EFFI_EPI_* comments;
+ * disp_range (EPI_HEAD only): device pointer to depth_values, n_range entries. */
+int effi_conv2d_f32(const float* const* srcs, const int* src_channels, int n_src,
+                    const float* wpack, const float* bias, int cout, int ks, int h, int w,
+                    int epilogue, int act, const float* aux0, const float* aux1,
+                    const float* disp_range, int n_range,
+                    float* out0, float* out1, effi_stream_t stream);
+/* 7x7, one input channel (convd1, models/update.py:76,90): in [h][w]; weight [49][cout]
+ * (host-packed), bias [cout]; out planar [cout][h][w] = relu(conv + bias).  cout in {16,32,48}. */
+int effi_conv2d_c1k7_relu_f32(const float* in, const float* weight, const float* bias, int cout,
+                              int h, int w, float* out, effi_stream_t stream);
+
+/* ---- K10: convex upsampling x2 (upsample_depth, models/Effi_MVS_plus.py:167-178) fused with
+ * scale_inv_depth (:138-148).  inv_depth [h][w]; mask [36][h][w] (already scaled by 0.25);
+ * out_inv [2h][2w] (or NULL); out_depth [2h][2w] (or NULL, then disp_range may be NULL too). */
+int effi_convex_upsample2x_f32(const float* inv_depth, const float* mask, const float* disp_range,
+                               int n_range, int h, int w, float* out_inv, float* out_depth,
+                               effi_stream_t stream);
+
+/* ---- small fused element-wise steps of the stage loop --------------------------------------------
+ * models/Effi_MVS_plus.py:445-450: hidden = tanh(ctx[:hd]), inp = relu(ctx[hd:hd+cd]); ctx [hd+cd][hw]. */
+int effi_split_tanh_relu_f32(const float* ctx, int hd, int cd, int hw, float* hidden, float* inp,
+                             effi_stream_t stream);
+/* models/Effi_MVS_plus.py:538 (depth_to_disp with the global range): inv = (1/d - lo)/((hi-lo)+1e-10). */
+int effi_depth_to_inv_f32(const float* depth, const float* disp_range, int n_range, int n, float* inv,
+                          effi_stream_t stream);
+/* models/Effi_MVS_plus.py:464-474: D uniform hypotheses in inverse depth between disp_range[0] and
+ * disp_range[n_range-1], returned as depths [D]; also writes intervals[0..4]: the per-stage
+ * inverse-depth intervals ratio[s]*(hi-lo)/n_range for s<3 (:424,466,502), then depth_min_ = 1/hi
+ * and depth_max_ = 1/lo (:413-414). */
+int effi_stage1_hypotheses_f32(const float* disp_range, int n_range, int D, float* depths,
+                               float* intervals, effi_stream_t stream);
+/* nearest-neighbour integer upsampling of a planar map (F.interpolate nearest, :479,497):
+ * in [C][h][w] -> out [C][h*f][w*f]. */
+int effi_upsample_nearest_f32(const float* in, int C, int h, int w, int f, float* out, effi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EFFI_MVS_HIP_H */

@@ -1,0 +1,152 @@
+"""GPU parity of the whole cascade (the path bench.py times) against the golden vectors generated from
+the reference and against the CPU oracle, in the normalised units of SURVEY.md section 8(d):
+
+    mean |d_hip - d_ref| / (depth_max - depth_min) <= 1e-3   for each of the 13 outputs, p99 <= 5e-3
+    (max is not gated: floor / clamp / out-of-bounds discontinuities), confidence mean abs <= 1e-3.
+
+The reference's own fp32-vs-fp64 noise in these units is 3e-6 .. 8e-6, so a healthy build lands near 1e-5.
+"""
+import pytest
+import torch
+
+from common import build_model, check_close, load_golden, t
+from effi_mvs_plus_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RANGE = synth.DEPTH_MAX_MM - synth.DEPTH_MIN_MM
+
+
+def _norm_err(got, want):
+    d = (got.detach().double().cpu() - want.double()).abs() / RANGE
+    return d.mean().item(), torch.quantile(d.flatten(), 0.99).item(), d.max().item()
+
+
+def _features_on_cpu(sd, imgs):
+    from oracle import effi_oracle as O
+    with torch.no_grad():
+        feats = [O.feature_net(sd, "feature", imgs[:, v]) for v in range(imgs.size(1))]
+        ctx = O.feature_net(sd, "cnet_depth", imgs[:, 0])
+    return feats, ctx
+
+
+@pytest.mark.parametrize("tag", ["small", "mid"])
+def test_cascade_vs_golden(tag):
+    g = load_golden(f"g11_full_{tag}.npz")
+    H, W, N = int(g["H"]), int(g["W"]), int(g["N"])
+    nd = ",".join(str(int(x)) for x in g["ndepths"])
+    net, sd = build_model(nd, seed=int(g["weight_seed"]), device=DEV)
+    imgs, pm, dv = synth.synth_sample(H, W, N, seed=int(g["img_seed"]))
+    feats, ctx = _features_on_cpu(sd, imgs)          # identical features on both sides: isolates the hot path
+    with torch.no_grad():
+        out = net.forward_hot([{k: t(v, DEV) for k, v in f.items()} for f in feats], {k: t(v, DEV) for k, v in ctx.items()},
+                              {k: t(v, DEV) for k, v in pm.items()}, t(dv, DEV), want_intermediates=True)
+    assert len(out["depth"]) == 13
+    for k in ("view_weights", "reg_volume1", "cur_volume1", "reg_volume2", "cur_volume2", "reg_volume3", "cur_volume3"):
+        if "inter_" + k in g:
+            check_close(f"[{tag}] {k}", out["intermediates"][k], g["inter_" + k], rtol=1e-3, atol=1e-3, frac_ok=0.99)
+    worst = 0.0
+    for i, d in enumerate(out["depth"]):
+        want = g[f"depth{i:02d}"]
+        assert tuple(d.shape) == tuple(want.shape)
+        mean, p99, mx = _norm_err(d, want)
+        print(f"[cascade {tag}] depth[{i:2d}] {tuple(d.shape)} normalised err: mean={mean:.3e} p99={p99:.3e} max={mx:.3e}")
+        assert mean <= 1e-3 and p99 <= 5e-3, f"depth[{i}] outside the stated fp32 tolerance"
+        worst = max(worst, mean)
+    conf_err = (out["photometric_confidence"].cpu() - g["photometric_confidence"]).abs().mean().item()
+    print(f"[cascade {tag}] confidence mean abs err = {conf_err:.3e}; worst depth mean = {worst:.3e}")
+    assert conf_err <= 1e-3
+
+
+def test_cascade_vs_oracle_and_fp64_noise_floor():
+    """The HIP result is as close to the fp64 evaluation of the reference graph as the reference's own
+    fp32 result is (so the remaining difference is rounding, not arithmetic)."""
+    from oracle import effi_oracle as O
+    net, sd = build_model("48,8,8", seed=3, device=DEV)
+    imgs, pm, dv = synth.synth_sample(192, 256, 4, seed=11)
+    feats, ctx = _features_on_cpu(sd, imgs)
+    with torch.no_grad():
+        ora32 = O.hot_path(sd, feats, ctx, pm, dv)
+        sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+        ora64 = O.hot_path(sd64, [{k: v.double() for k, v in f.items()} for f in feats], {k: v.double() for k, v in ctx.items()},
+                           {k: v.double() for k, v in pm.items()}, dv.double())
+        out = net.forward_hot([{k: t(v, DEV) for k, v in f.items()} for f in feats], {k: t(v, DEV) for k, v in ctx.items()},
+                              {k: t(v, DEV) for k, v in pm.items()}, t(dv, DEV))
+    for i in (0, 4, 8, 12):
+        hip64 = _norm_err(out["depth"][i], ora64["depth"][i])[0]
+        ref64 = _norm_err(ora32["depth"][i], ora64["depth"][i])[0]
+        hip32 = _norm_err(out["depth"][i], ora32["depth"][i])[0]
+        print(f"[noise floor] depth[{i:2d}] mean normalised err: hip-vs-fp64={hip64:.3e} ref32-vs-fp64={ref64:.3e} hip-vs-ref32={hip32:.3e}")
+        assert hip32 <= 1e-3
+        assert hip64 <= max(10 * ref64, 1e-4)
+
+
+def test_full_forward_including_fpn():
+    """model(imgs, proj_matrices, depth_values) exactly as the reference's drivers call it
+    (test_dtu_dypcd.py:439); FPN runs in stock PyTorch-ROCm, so features differ by MIOpen rounding."""
+    g = load_golden("g11_full_small.npz")
+    net, sd = build_model("8,8,8", seed=int(g["weight_seed"]), device=DEV)
+    imgs, pm, dv = synth.synth_sample(int(g["H"]), int(g["W"]), int(g["N"]), seed=int(g["img_seed"]))
+    with torch.no_grad():
+        out = net(imgs.to(DEV), {k: v.to(DEV) for k, v in pm.items()}, dv.to(DEV))
+    assert set(out) == {"depth", "photometric_confidence"} and len(out["depth"]) == 13
+    for i, d in enumerate(out["depth"]):
+        mean, p99, _ = _norm_err(d, g[f"depth{i:02d}"])
+        assert mean <= 1e-3 and p99 <= 5e-3, (i, mean, p99)
+    assert tuple(out["photometric_confidence"].shape) == tuple(g["photometric_confidence"].shape)
+
+
+def test_training_mode_and_cpu_are_refused():
+    from effi_mvs_plus_amd._lib import EffiLibraryError
+    net, _ = build_model("8,8,8", seed=1, device=DEV)
+    imgs, pm, dv = synth.synth_sample(64, 96, 3, seed=0)
+    net.train()
+    with pytest.raises(NotImplementedError):
+        net(imgs.to(DEV), {k: v.to(DEV) for k, v in pm.items()}, dv.to(DEV))
+    net.eval().cpu()
+    with pytest.raises(EffiLibraryError):
+        net(imgs, pm, dv)
+
+
+def test_size_independent_properties_at_full_resolution():
+    """cfg3 shape (1600x1184, S=4, 48,8,8): too large for the CPU oracle in a test, so check properties
+    the domain offers: determinism, finite outputs inside the depth range, hypotheses ordered, and
+    invariance of the cost volume to a permutation of the source views (aggregation is a weighted mean)."""
+    from effi_mvs_plus_amd import ops
+    net, sd = build_model("48,8,8", seed=5, device=DEV)
+    H, W, N = 1184, 1600, 5
+    g = torch.Generator().manual_seed(0)
+    feats = []
+    for v in range(N):
+        feats.append({"stage1": torch.randn(1, 32, H // 8, W // 8, generator=g).to(DEV),
+                      "stage2": torch.randn(1, 16, H // 4, W // 4, generator=g).to(DEV),
+                      "stage3": torch.randn(1, 8, H // 2, W // 2, generator=g).to(DEV)})
+    ctx = {"stage1": torch.randn(1, 60, H // 8, W // 8, generator=g).to(DEV),
+           "stage2": torch.randn(1, 40, H // 4, W // 4, generator=g).to(DEV),
+           "stage3": torch.randn(1, 20, H // 2, W // 2, generator=g).to(DEV)}
+    _, pm, dv = synth.synth_sample(32, 32, N, seed=0)
+    pm = synth.synth_cameras(H, W, N)
+    pm = {k: v.to(DEV) for k, v in pm.items()}
+    dv = dv.to(DEV)
+    with torch.no_grad():
+        a = net.forward_hot(feats, ctx, pm, dv)
+        b = net.forward_hot(feats, ctx, pm, dv)
+    assert [tuple(d.shape) for d in a["depth"]] == [(1, 148, 200)] * 4 + [(1, 296, 400)] * 4 + [(1, 592, 800)] * 4 + [(1, 1184, 1600)]
+    for x, y in zip(a["depth"], b["depth"]):
+        assert torch.equal(x, y), "the path must be deterministic (no atomics, fixed reduction order)"
+        assert torch.isfinite(x).all()
+    d0 = a["depth"][0]
+    assert d0.min() >= synth.DEPTH_MIN_MM - 1e-2 and d0.max() <= synth.DEPTH_MAX_MM + 1e-2   # convex combination of hypotheses
+    assert a["photometric_confidence"].min() >= 0 and a["photometric_confidence"].max() <= 1 + 1e-5
+    # permutation invariance of the stage-2 dynamic volume w.r.t. source-view order
+    maps = [f["stage2"][0] for f in feats]
+    nhwc = ops.to_nhwc(maps)
+    rt = ops.compose_rel_proj(pm["stage2"][0].contiguous())
+    cur = a["depth"][4][0].contiguous()
+    itv = torch.full((1,), 1e-5, device=DEV)
+    vw = torch.rand(4, 148, 200, device=DEV)
+    s1, smp = ops.warpcorr_dyn(nhwc[0], nhwc[1:], rt, cur, itv, vw, 8)
+    perm = [2, 0, 3, 1]
+    s2, _ = ops.warpcorr_dyn(nhwc[0], [nhwc[1 + p] for p in perm], rt[perm].contiguous(), cur, itv, vw[perm].contiguous(), 8)
+    check_close("view-permutation invariance", s2, s1, rtol=1e-4, atol=1e-5)
+    assert (smp[:-1] >= smp[1:]).all(), "depth hypotheses must be ordered far -> near (ascending inverse depth)"
