@@ -17,6 +17,47 @@ EPI_PLAIN, EPI_GRU_ZR, EPI_GRU_Q, EPI_HEAD = 0, 1, 2, 3
 MAX_VIEWS = 12
 
 
+class KernelProfile:
+    """Optional per-launch timing (HIP events on the launching stream) used by bench.py for the roofline
+    line: ``keys`` selects which launches are bracketed (None = all); ``records`` collects
+    (key, algorithmic work, start event, end event)."""
+
+    def __init__(self, keys=None):
+        self.keys = None if keys is None else set(keys)
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for key, work, e0, e1 in self.records:
+            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += work.get("flops", 0.0)
+            d["bytes"] += work.get("bytes", 0.0)
+        return out
+
+
+_PROF = None
+
+
+def set_profile(p):
+    global _PROF
+    _PROF = p
+
+
+def _call(key, work, fn, *args):
+    p = _PROF
+    if p is None or (p.keys is not None and key not in p.keys):
+        return fn(*args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn(*args)
+    e1.record()
+    p.records.append((key, work(), e0, e1))
+    return rc
+
+
 def _t(x: torch.Tensor, name: str, contiguous=True) -> torch.Tensor:
     if not isinstance(x, torch.Tensor):
         raise TypeError(f"{name}: expected a tensor")
@@ -122,8 +163,9 @@ def warpcorr_views(ref_nhwc, srcs_nhwc, rt, depth, D):
     depth, dds, dps = _depth_strides(depth, D, h, w)
     sim = torch.empty(S, D, h, w, device=ref_nhwc.device, dtype=torch.float32)
     ent = torch.empty(S, h, w, device=ref_nhwc.device, dtype=torch.float32)
-    check(_lib.lib().effi_warpcorr_views_f32(_p(ref_nhwc), _ptr_array(srcs_nhwc), S, _p(rt), _p(depth), dds, dps,
-                                              Cc, h, w, D, _p(sim), _p(ent), _stream()), "effi_warpcorr_views_f32")
+    work = lambda: {"flops": S * D * h * w * (10.0 * Cc + 20), "bytes": 4.0 * h * w * (S * Cc + Cc + S * D + S)}
+    check(_call(f"warpcorr_views_c{Cc}", work, _lib.lib().effi_warpcorr_views_f32, _p(ref_nhwc), _ptr_array(srcs_nhwc), S,
+                _p(rt), _p(depth), dds, dps, Cc, h, w, D, _p(sim), _p(ent), _stream()), "effi_warpcorr_views_f32")
     return sim, ent
 
 
@@ -162,8 +204,9 @@ def warpcorr_dyn(ref_nhwc, srcs_nhwc, rt, cur_depth, interval, view_w, D):
         raise ValueError(f"view weights {vh}x{vw} are not a power-of-two downsampling of {h}x{w}")
     sim = torch.empty(D, h, w, device=ref_nhwc.device, dtype=torch.float32)
     samples = torch.empty(D, h, w, device=ref_nhwc.device, dtype=torch.float32)
-    check(_lib.lib().effi_warpcorr_dyn_f32(_p(ref_nhwc), _ptr_array(srcs_nhwc), S, _p(rt), _p(cur_depth), _p(interval),
-                                            _p(view_w), shift, Cc, h, w, D, _p(sim), _p(samples), _stream()),
+    work = lambda: {"flops": S * D * h * w * (10.0 * Cc + 20), "bytes": 4.0 * h * w * (S * Cc + Cc + 2 * D + 1 + S / 4.0 ** shift)}
+    check(_call(f"warpcorr_dyn_c{Cc}", work, _lib.lib().effi_warpcorr_dyn_f32, _p(ref_nhwc), _ptr_array(srcs_nhwc), S, _p(rt),
+                _p(cur_depth), _p(interval), _p(view_w), shift, Cc, h, w, D, _p(sim), _p(samples), _stream()),
           "effi_warpcorr_dyn_f32")
     return sim, samples
 
@@ -179,9 +222,12 @@ def conv3d_k3(srcs, weight, bias, cout, stride=(1, 1, 1), relu=True, skip=None):
     if skip is not None:
         _t(skip, "skip")
         assert skip.shape == out.shape
-    check(_lib.lib().effi_conv3d_k3_f32(_ptr_array(srcs), _int_array([s.shape[0] for s in srcs]), len(srcs),
-                                         _p(weight), _p(bias), cout, D, h, w, sz, sxy, int(relu), _p(skip), _p(out),
-                                         _stream()), "effi_conv3d_k3_f32")
+    cin = sum(s.shape[0] for s in srcs)
+    work = lambda: {"flops": 2.0 * 27 * cin * cout * Do * ho * wo,
+                    "bytes": 4.0 * (cin * D * h * w + cout * Do * ho * wo * (2 if skip is not None else 1))}
+    check(_call(f"conv3d_c{'8' if cout % 8 == 0 else '1'}_s{sz}{sxy}", work, _lib.lib().effi_conv3d_k3_f32, _ptr_array(srcs),
+                _int_array([s.shape[0] for s in srcs]), len(srcs), _p(weight), _p(bias), cout, D, h, w, sz, sxy, int(relu),
+                _p(skip), _p(out), _stream()), "effi_conv3d_k3_f32")
     return out
 
 
@@ -192,8 +238,10 @@ def deconv3d_k3(x, weight, bias, cout, sz=2, relu=True, skip=None):
     if skip is not None:
         _t(skip, "skip")
         assert skip.shape == out.shape, f"skip {tuple(skip.shape)} vs out {tuple(out.shape)}"
-    check(_lib.lib().effi_deconv3d_k3_f32(_p(x), cin, _p(weight), _p(bias), cout, D, h, w, sz, int(relu), _p(skip),
-                                           _p(out), _stream()), "effi_deconv3d_k3_f32")
+    work = lambda: {"flops": 2.0 * 27 * cin * cout * D * h * w,
+                    "bytes": 4.0 * (cin * D * h * w + cout * sz * D * 4 * h * w * (2 if skip is not None else 1))}
+    check(_call(f"deconv3d_c{cout if cout == 1 else 8}_s{sz}", work, _lib.lib().effi_deconv3d_k3_f32, _p(x), cin, _p(weight),
+                _p(bias), cout, D, h, w, sz, int(relu), _p(skip), _p(out), _stream()), "effi_deconv3d_k3_f32")
     return out
 
 
@@ -287,9 +335,11 @@ def conv2d(srcs, wpack, bias, cout, ks, epilogue=EPI_PLAIN, act=ACT_NONE, aux0=N
     if out1 is None and epilogue == EPI_HEAD:
         out1 = torch.empty(1, h, w, device=dev, dtype=torch.float32)
     n_range = 0 if disp_range is None else disp_range.numel()
-    check(_lib.lib().effi_conv2d_f32(_ptr_array(srcs), _int_array([s.shape[0] for s in srcs]), len(srcs), _p(wpack),
-                                      _p(bias), cout, ks, h, w, epilogue, act, _p(aux0), _p(aux1), _p(disp_range),
-                                      n_range, _p(out0), _p(out1), _stream()), "effi_conv2d_f32")
+    cin = sum(s.shape[0] for s in srcs)
+    work = lambda: {"flops": 2.0 * h * w * cin * cout * ks * ks, "bytes": 4.0 * h * w * (cin + cout)}
+    check(_call(f"conv2d_k{ks}_nt{(cout + 15) // 16}_epi{epilogue}", work, _lib.lib().effi_conv2d_f32, _ptr_array(srcs),
+                _int_array([s.shape[0] for s in srcs]), len(srcs), _p(wpack), _p(bias), cout, ks, h, w, epilogue, act,
+                _p(aux0), _p(aux1), _p(disp_range), n_range, _p(out0), _p(out1), _stream()), "effi_conv2d_f32")
     return (out0, out1) if out1 is not None else out0
 
 
