@@ -193,6 +193,180 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(const Conv2dArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// v2 (used whenever w % 4 == 0): both operands come from LDS inside the k-loop.
+//   * chunk = 8 input channels (2 k-groups): A tile [8][TR+2][24] floats (columns x0-4 .. x0+19, so every
+//     row is fetched as 6 aligned float4) and the chunk's B fragments [2][KS*KS][NT][64].
+//   * the next chunk's A/B are prefetched into registers with branch-free float4 loads that stay in
+//     flight during the whole multiply phase (no vmcnt wait in the inner loop: B is no longer a global
+//     load), then written to LDS between two barriers.
+//   * the 2*KS*KS k-steps of a chunk are fully unrolled with double-buffered fragments.
+//   * MR = rows per wave (1, 2 or 4): small images use small MR so the grid still covers the 256 CUs.
+// ------------------------------------------------------------------------------------------------
+template <int KS, int NT, int MR, int EPI>
+__global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a) {
+    constexpr int R = KS / 2, TR = 4 * MR, AR = TR + 2 * R;
+    constexpr int AW = (KS == 3) ? 24 : 16, AQ = AW / 4, XOFF = (KS == 3) ? 3 : 0, XLEFT = (KS == 3) ? 4 : 0;
+    constexpr int PL0 = AR * AW;
+    constexpr int PLA = PL0 + ((16 - (PL0 % 32)) + 32) % 32;          // channel-plane stride == 16 (mod 32)
+    constexpr int CC = 8, T = 2 * KS * KS;
+    constexpr int NA = CC * AR * AQ;                                    // float4 per A chunk
+    constexpr int NA4 = (NA + 255) / 256;
+    constexpr int NB = T * NT * 16;                                     // float4 per B chunk
+    constexpr int NB4 = (NB + 255) / 256;
+    __shared__ __attribute__((aligned(16))) float lds_a[CC * PLA];
+    __shared__ __attribute__((aligned(16))) float lds_b[T * NT * 64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int x0 = blockIdx.x * 16, y0 = blockIdx.y * TR;
+    const int h = a.h, w = a.w;
+    const long hw = (long)h * w;
+
+    // per-thread constants of the A prefetch: element -> (channel in chunk, offset inside a channel map)
+    int a_c[NA4], a_off[NA4], a_lds[NA4];
+#pragma unroll
+    for (int j = 0; j < NA4; ++j) {
+        const int f = min(tid + j * 256, NA - 1);
+        const int c = f / (AR * AQ);
+        const int r = f - c * (AR * AQ);
+        const int row = r / AQ, q = r - row * AQ;
+        const int gy = y0 - R + row, gx = x0 - XLEFT + 4 * q;
+        a_c[j] = c;
+        a_off[j] = ((tid + j * 256 < NA) & (gy >= 0) & (gy < h) & (gx >= 0) & (gx < w)) ? gy * w + gx : -1;
+        a_lds[j] = c * PLA + row * AW + 4 * q;
+    }
+
+    f32x4 acc[MR][NT];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    float4 pa[NA4], pb[NB4];
+    const int nchunks = (a.kgroups + 1) / 2;
+    const long wchunk = (long)T * NT * 64;                              // floats of wpack per chunk
+    const long wtotal = (long)a.kgroups * KS * KS * NT * 64;
+
+    auto prefetch = [&](int ch) {
+#pragma unroll
+        for (int j = 0; j < NA4; ++j) {
+            int cg = ch * CC + a_c[j];
+            const bool ok = (a_off[j] >= 0) & (cg < a.cin);
+            const float* p = a.src[0];
+            if (cg >= a.ch[0]) {
+                cg -= a.ch[0];
+                p = a.src[1];
+                if (cg >= a.ch[1]) { cg -= a.ch[1]; p = a.src[2]; }
+            }
+            const float4 t = *reinterpret_cast<const float4*>(ok ? p + (long)cg * hw + a_off[j] : a.wpack);
+            pa[j] = ok ? t : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int j = 0; j < NB4; ++j) {
+            const long f = (long)ch * wchunk + 4L * (tid + j * 256);
+            const bool ok = (tid + j * 256 < NB) & (f < wtotal);     // odd k-group count: the tail is zero
+            const float4 t = *reinterpret_cast<const float4*>(a.wpack + (ok ? f : 0));
+            pb[j] = ok ? t : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int j = 0; j < NA4; ++j)
+            if (tid + j * 256 < NA) *reinterpret_cast<float4*>(&lds_a[a_lds[j]]) = pa[j];
+#pragma unroll
+        for (int j = 0; j < NB4; ++j)
+            if (tid + j * 256 < NB) *reinterpret_cast<float4*>(&lds_b[4 * (tid + j * 256)]) = pb[j];
+    };
+
+    prefetch(0);
+    stash();
+    __syncthreads();
+    const float* ab = &lds_a[lk * PLA + (wv * MR) * AW + li + XOFF];
+    const float* bb = &lds_b[lane];
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if (ch + 1 < nchunks) prefetch(ch + 1);
+        float af[2][MR], bf[2][NT];
+        auto frag = [&](int t, int s) {
+            const int kg = t / (KS * KS), tap = t % (KS * KS), ky = tap / KS, kx = tap % KS;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bf[s][n] = bb[(t * NT + n) * 64];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) af[s][m] = ab[kg * 4 * PLA + (m + ky) * AW + kx];
+        };
+        frag(0, 0);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            if (t + 1 < T) frag(t + 1, (t + 1) & 1);
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t & 1][m], bf[t & 1][n], acc[m][n], 0, 0, 0);
+        }
+        if (ch + 1 < nchunks) {
+            __syncthreads();
+            stash();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (same lane map as v1): pixels x = x0 + 4*lk + r of row y, channel 16*n + li
+    const int x = x0 + 4 * lk;
+    float lo = 0.0f, hi = 0.0f;
+    if (EPI == EFFI_EPI_HEAD) { lo = a.disp_range[0]; hi = a.disp_range[a.n_range - 1]; }
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        const int y = y0 + wv * MR + m;
+        if (y >= h || x >= w) continue;
+        const long pix = (long)y * w + x;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int co = n * 16 + li;
+            if (co >= a.cout) continue;
+            const float b = a.bias[co];
+            float v[4] = {acc[m][n][0] + b, acc[m][n][1] + b, acc[m][n][2] + b, acc[m][n][3] + b};
+            float* dst;
+            if (EPI == EFFI_EPI_PLAIN) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], a.act);
+                dst = a.out0 + (long)co * hw + pix;
+            } else if (EPI == EFFI_EPI_GRU_ZR) {
+                if (co < a.hd) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = effi_sigmoid(v[r]);
+                    dst = a.out0 + (long)co * hw + pix;
+                } else {
+                    const float4 hv = *reinterpret_cast<const float4*>(a.aux0 + (long)(co - a.hd) * hw + pix);
+                    v[0] = effi_sigmoid(v[0]) * hv.x;
+                    v[1] = effi_sigmoid(v[1]) * hv.y;
+                    v[2] = effi_sigmoid(v[2]) * hv.z;
+                    v[3] = effi_sigmoid(v[3]) * hv.w;
+                    dst = a.out1 + (long)(co - a.hd) * hw + pix;
+                }
+            } else if (EPI == EFFI_EPI_GRU_Q) {
+                const float4 hv = *reinterpret_cast<const float4*>(a.aux0 + (long)co * hw + pix);
+                const float4 zv = *reinterpret_cast<const float4*>(a.aux1 + (long)co * hw + pix);
+                v[0] = (1.0f - zv.x) * hv.x + zv.x * tanhf(v[0]);
+                v[1] = (1.0f - zv.y) * hv.y + zv.y * tanhf(v[1]);
+                v[2] = (1.0f - zv.z) * hv.z + zv.z * tanhf(v[2]);
+                v[3] = (1.0f - zv.w) * hv.w + zv.w * tanhf(v[3]);
+                dst = a.out0 + (long)co * hw + pix;
+            } else {  // EFFI_EPI_HEAD
+                const float4 iv = *reinterpret_cast<const float4*>(a.aux0 + pix);
+                v[0] = iv.x + tanhf(v[0]);
+                v[1] = iv.y + tanhf(v[1]);
+                v[2] = iv.z + tanhf(v[2]);
+                v[3] = iv.w + tanhf(v[3]);
+                dst = a.out0 + pix;
+                *reinterpret_cast<float4*>(a.out1 + pix) = make_float4(effi_inv_to_depth(v[0], lo, hi), effi_inv_to_depth(v[1], lo, hi),
+                                                                       effi_inv_to_depth(v[2], lo, hi), effi_inv_to_depth(v[3], lo, hi));
+            }
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 7x7 convolution of a single-channel map (convd1, models/update.py:76,90) + ReLU; vector ALUs.
 // ------------------------------------------------------------------------------------------------
 template <int COUT>
@@ -226,8 +400,22 @@ __global__ __launch_bounds__(256) void conv2d_c1k7_relu_kernel(const float* __re
     for (int c = 0; c < COUT; ++c) out[c * hw + pix] = fmaxf(acc[c], 0.0f);
 }
 
+template <int KS, int NT, int MR, int EPI>
+int launch2d_v2(const Conv2dArgs& a, hipStream_t st) {
+    dim3 grid(effi_cdiv(a.w, 16), effi_cdiv(a.h, 4 * MR));
+    hipLaunchKernelGGL((conv2d_mfma_v2_kernel<KS, NT, MR, EPI>), grid, dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+}
+
 template <int KS, int NT, int EPI>
 int launch2d(const Conv2dArgs& a, hipStream_t st) {
+    if ((a.w & 3) == 0) {
+        // rows per wave: the largest of {4, 2, 1} that still yields >= 2 workgroups per CU (256 CUs)
+        const long cols = effi_cdiv(a.w, 16);
+        if (cols * effi_cdiv(a.h, 16) >= 512 || KS == 1 && cols * effi_cdiv(a.h, 16) >= 256) return launch2d_v2<KS, NT, 4, EPI>(a, st);
+        if (cols * effi_cdiv(a.h, 8) >= 512 || KS == 1) return launch2d_v2<KS, NT, 2, EPI>(a, st);
+        return launch2d_v2<KS, NT, (KS == 3 ? 1 : 2), EPI>(a, st);
+    }
     dim3 grid(effi_cdiv(a.w, 16), effi_cdiv(a.h, 16));
     hipLaunchKernelGGL((conv2d_mfma_kernel<KS, NT, EPI>), grid, dim3(256), 0, st, a);
     return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;

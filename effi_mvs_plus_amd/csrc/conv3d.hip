@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(SrcSet src, int cin, con
     constexpr int CC = (SXY == 1) ? 4 : ((SZ == 1) ? 1 : 2);
     constexpr int IZ = (ZPT - 1) * SZ + 3, IY = (TY - 1) * SXY + 3, IX = (TX - 1) * SXY + 3;
     constexpr int PLANE = IZ * IY * IX;
+    constexpr int PSZ = IY * IX, NPL = (PSZ + 255) / 256;   // plane size, fill slots per thread and plane
     __shared__ float tile[CC * PLANE];
 
     const int tiles_x = (wo + TX - 1) / TX;
@@ -51,6 +52,15 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(SrcSet src, int cin, con
     const int iz0 = oz0 * SZ - 1, iy0 = by * TY * SXY - 1, ix0 = bx * TX * SXY - 1;
     const long in_plane = (long)D * h * w;
 
+    int poff[NPL];                            // offset of this thread's fill elements inside a z-slice, -1 = padding
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int e = threadIdx.x + k * 256;
+        const int ly = e / IX, lx = e - ly * IX;
+        const int gy = iy0 + ly, gx = ix0 + lx;
+        poff[k] = ((e < PSZ) & (gy >= 0) & (gy < h) & (gx >= 0) & (gx < w)) ? gy * w + gx : -1;
+    }
+
     float acc[ZPT][COUT_T];
 #pragma unroll
     for (int z = 0; z < ZPT; ++z)
@@ -60,17 +70,29 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(SrcSet src, int cin, con
     for (int c0 = 0; c0 < cin; c0 += CC) {
         const int ccn = min(CC, cin - c0);
         __syncthreads();
-        for (int e = threadIdx.x; e < ccn * PLANE; e += 256) {
-            const int c = e / PLANE;
-            int r = e - c * PLANE;
-            const int lz = r / (IY * IX);
-            r -= lz * (IY * IX);
-            const int ly = r / IX, lx = r - ly * IX;
-            const int gz = iz0 + lz, gy = iy0 + ly, gx = ix0 + lx;
-            float v = 0.0f;
-            if (gz >= 0 && gz < D && gy >= 0 && gy < h && gx >= 0 && gx < w)
-                v = src_channel(src, c0 + c, in_plane)[((long)gz * h + gy) * w + gx];
-            tile[e] = v;
+        // tile fill: per channel, all IZ x NPL loads are issued before the first LDS write; the in-plane
+        // offsets were computed once per block, so a load costs a couple of VALU ops
+        for (int c = 0; c < ccn; ++c) {
+            const float* __restrict__ cp = src_channel(src, c0 + c, in_plane);
+            float v[IZ][NPL];
+#pragma unroll
+            for (int lz = 0; lz < IZ; ++lz) {
+                const int gz = iz0 + lz;
+                const bool zok = (gz >= 0) & (gz < D);
+                const float* __restrict__ zp = cp + (zok ? (long)gz * h * w : 0);
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) {
+                    const float t = zp[max(poff[k], 0)];
+                    v[lz][k] = (zok & (poff[k] >= 0)) ? t : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int lz = 0; lz < IZ; ++lz)
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) {
+                    const int e = threadIdx.x + k * 256;
+                    if (e < PSZ) tile[c * PLANE + lz * PSZ + e] = v[lz][k];
+                }
         }
         __syncthreads();
         for (int c = 0; c < ccn; ++c) {
@@ -133,6 +155,7 @@ __global__ __launch_bounds__(256) void deconv3d_k3_kernel(const float* __restric
     constexpr int CC = 4;
     constexpr int IZ = (SZ == 2) ? 2 : ZPT + 2, IY = TY + 1, IX = TX + 1;
     constexpr int PLANE = IZ * IY * IX;
+    constexpr int PSZ = IY * IX, NPL = (PSZ + 255) / 256;
     __shared__ float tile[CC * PLANE];
 
     const int tiles_x = (w + TX - 1) / TX;
@@ -142,6 +165,15 @@ __global__ __launch_bounds__(256) void deconv3d_k3_kernel(const float* __restric
     const int co0 = blockIdx.z * COUT_T;
     const int iz0 = (SZ == 2) ? z0 : z0 - 1;
     const long in_plane = (long)D * h * w;
+
+    int poff[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int e = threadIdx.x + k * 256;
+        const int ly = e / IX, lx = e - ly * IX;
+        const int gy = by * TY + ly, gx = bx * TX + lx;
+        poff[k] = ((e < PSZ) & (gy < h) & (gx < w)) ? gy * w + gx : -1;
+    }
 
     float acc[OZ][2][2][COUT_T];
 #pragma unroll
@@ -156,16 +188,27 @@ __global__ __launch_bounds__(256) void deconv3d_k3_kernel(const float* __restric
     for (int c0 = 0; c0 < cin; c0 += CC) {
         const int ccn = min(CC, cin - c0);
         __syncthreads();
-        for (int e = threadIdx.x; e < ccn * PLANE; e += 256) {
-            const int c = e / PLANE;
-            int r = e - c * PLANE;
-            const int lz = r / (IY * IX);
-            r -= lz * (IY * IX);
-            const int ly = r / IX, lx = r - ly * IX;
-            const int gz = iz0 + lz, gy = by * TY + ly, gx = bx * TX + lx;
-            float v = 0.0f;
-            if (gz >= 0 && gz < D && gy < h && gx < w) v = in[(long)(c0 + c) * in_plane + ((long)gz * h + gy) * w + gx];
-            tile[e] = v;
+        for (int c = 0; c < ccn; ++c) {
+            const float* __restrict__ cp = in + (long)(c0 + c) * in_plane;
+            float v[IZ][NPL];
+#pragma unroll
+            for (int lz = 0; lz < IZ; ++lz) {
+                const int gz = iz0 + lz;
+                const bool zok = (gz >= 0) & (gz < D);
+                const float* __restrict__ zp = cp + (zok ? (long)gz * h * w : 0);
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) {
+                    const float t = zp[max(poff[k], 0)];
+                    v[lz][k] = (zok & (poff[k] >= 0)) ? t : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int lz = 0; lz < IZ; ++lz)
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) {
+                    const int e = threadIdx.x + k * 256;
+                    if (e < PSZ) tile[c * PLANE + lz * PSZ + e] = v[lz][k];
+                }
         }
         __syncthreads();
         for (int c = 0; c < ccn; ++c) {

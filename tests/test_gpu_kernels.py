@@ -362,6 +362,44 @@ def test_conv2d_generic(ks, cins, cout, act):
     check_close(f"conv2d k{ks} {cins}->{cout} act{act} (w=28)", got2, want2, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("h,w", [(36, 60), (256, 256), (256, 512)])      # rows-per-wave 1, 2 and 4 of the v2 kernel
+@pytest.mark.parametrize("hd,cd", [(16, 4), (48, 12)])
+def test_update_convs_at_tile_configs(O, h, w, hd, cd):
+    """ConvGRU / encoder / heads against the oracle at image sizes that select every tiling of the
+    MFMA kernel (the golden fixtures are small and only reach the 1-row-per-wave variant)."""
+    import contextlib
+    import io
+    from effi_mvs_plus_amd.models.update import BasicUpdateBlock
+    g = torch.Generator().manual_seed(hd * 1000 + h)
+    with contextlib.redirect_stdout(io.StringIO()):
+        blk = BasicUpdateBlock(hidden_dim=hd, cost_dim=3, ratio=2, context_dim=cd, UpMask=True, Inverse=True, cost_num=2).eval()
+    sd = synth.randomize_state_dict(blk.state_dict(), seed=5)
+    blk.load_state_dict(sd)
+    sd = {"b." + k: v for k, v in sd.items()}
+    blk = blk.to(DEV)
+    net_h = torch.tanh(torch.randn(1, hd, h, w, generator=g))
+    x = torch.relu(torch.randn(1, hd, h, w, generator=g))
+    inv = torch.rand(1, 1, h, w, generator=g)
+    cost = torch.randn(1, 6, h, w, generator=g)
+    ctx = torch.relu(torch.randn(1, cd, h, w, generator=g))
+    check_close(f"ConvGRU hd={hd} {h}x{w}", blk.depth_gru(t(net_h, DEV), t(x, DEV)), O.conv_gru(sd, "b.depth_gru", net_h, x),
+                rtol=1e-4, atol=2e-5)
+    check_close(f"ProjectionInput hd={hd} {h}x{w}", blk.encoder(t(inv, DEV), t(cost, DEV), t(ctx, DEV)),
+                O.projection_input(sd, "b.encoder", inv, cost, ctx), rtol=1e-4, atol=2e-5)
+    check_close(f"DepthHead hd={hd} {h}x{w}", blk.depth_head(t(net_h, DEV)), O.depth_head(sd, "b.depth_head", net_h),
+                rtol=1e-4, atol=2e-5)
+    check_close(f"mask head hd={hd} {h}x{w}", blk.run_mask(t(net_h[0], DEV)), O.mask_head(sd, "b.mask", net_h)[0],
+                rtol=1e-4, atol=2e-5)
+    # fused depth-head tail: inv + tanh(conv2(relu(conv1(net)))) and the depth it scales to
+    dv = torch.linspace(1 / 935.0, 1 / 425.0, 384)
+    hid = blk.depth_head.run_hidden(t(net_h[0], DEV))
+    inv_new, depth = blk.depth_head.run_update(hid, t(inv[0], DEV), t(dv, DEV))
+    want_inv = inv + O.depth_head(sd, "b.depth_head", net_h)
+    check_close(f"head update hd={hd} {h}x{w}", inv_new, want_inv[0], rtol=1e-4, atol=2e-5)
+    want_depth = O.disp_to_depth(want_inv, torch.tensor(425.0), torch.tensor(935.0))[1]
+    check_close(f"head depth hd={hd} {h}x{w}", depth, want_depth[0], rtol=1e-4, atol=2e-2)
+
+
 def test_cpu_tensor_fails_loudly():
     from effi_mvs_plus_amd import ops
     from effi_mvs_plus_amd._lib import EffiLibraryError

@@ -81,6 +81,23 @@ def test_cascade_vs_oracle_and_fp64_noise_floor():
         assert hip64 <= max(10 * ref64, 1e-4)
 
 
+def test_cascade_vs_oracle_large_tiles():
+    """768x1024 image: stage 3 (384x512) selects the 4-rows-per-wave conv tiling, stage 2 the 2-row one."""
+    from oracle import effi_oracle as O
+    net, sd = build_model("16,8,8", seed=9, device=DEV)
+    imgs, pm, dv = synth.synth_sample(768, 1024, 3, seed=2)
+    feats, ctx = _features_on_cpu(sd, imgs)
+    with torch.no_grad():
+        want = O.hot_path(sd, feats, ctx, pm, dv, ndepths=(16, 8, 8))
+        out = net.forward_hot([{k: t(v, DEV) for k, v in f.items()} for f in feats], {k: t(v, DEV) for k, v in ctx.items()},
+                              {k: t(v, DEV) for k, v in pm.items()}, t(dv, DEV))
+    for i, d in enumerate(out["depth"]):
+        mean, p99, mx = _norm_err(d, want["depth"][i])
+        print(f"[cascade large] depth[{i:2d}] {tuple(d.shape)} normalised err: mean={mean:.3e} p99={p99:.3e} max={mx:.3e}")
+        assert mean <= 1e-3 and p99 <= 5e-3
+    assert (out["photometric_confidence"].cpu() - want["photometric_confidence"]).abs().mean() <= 1e-3
+
+
 def test_full_forward_including_fpn():
     """model(imgs, proj_matrices, depth_values) exactly as the reference's drivers call it
     (test_dtu_dypcd.py:439); FPN runs in stock PyTorch-ROCm, so features differ by MIOpen rounding."""
