@@ -12,6 +12,8 @@
 //   B operand  (lane l: k = l>>4, cout l&15): weights are host-packed in exactly that lane order, so each
 //              k-step's B tile is ONE coalesced 256-byte global load (L1/L2 resident, shared by all blocks).
 // Epilogues (bias, activation, GRU gating, depth-head update) are fused; see EFFI_EPI_* in the header.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -193,22 +195,25 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(const Conv2dArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// v2 (used whenever w % 4 == 0): both operands come from LDS inside the k-loop.
-//   * chunk = 8 input channels (2 k-groups): A tile [8][TR+2][24] floats (columns x0-4 .. x0+19, so every
-//     row is fetched as 6 aligned float4) and the chunk's B fragments [2][KS*KS][NT][64].
-//   * the next chunk's A/B are prefetched into registers with branch-free float4 loads that stay in
-//     flight during the whole multiply phase (no vmcnt wait in the inner loop: B is no longer a global
-//     load), then written to LDS between two barriers.
-//   * the 2*KS*KS k-steps of a chunk are fully unrolled with double-buffered fragments.
+// v3 (used whenever w % 4 == 0): both operands come from LDS inside the k-loop, workgroups are persistent.
+//   * chunk = CC input channels (CC/4 k-groups; 16 when the accumulators leave room, else 8):
+//     A tile [CC][TR+2][24] floats (columns x0-4 .. x0+19, so every row is fetched as 6 aligned float4)
+//     and the chunk's B fragments [CC/4][KS*KS][NT][64].
+//   * work items are (tile, chunk) pairs; while item i is multiplied, item i+1 (the next chunk, or the
+//     FIRST chunk of the workgroup's next tile) is prefetched into registers with branch-free float4
+//     loads that stay in flight during the whole multiply phase (no vmcnt wait in the k-loop), and is
+//     written to LDS between two barriers.  A workgroup walks tiles blockIdx.x, +gridDim.x, ... so the
+//     global-load latency of a tile's first chunk is exposed only once per workgroup.
+//   * the k-steps of a chunk are fully unrolled with double-buffered fragments.
 //   * MR = rows per wave (1, 2 or 4): small images use small MR so the grid still covers the 256 CUs.
 // ------------------------------------------------------------------------------------------------
-template <int KS, int NT, int MR, int EPI>
-__global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a) {
+template <int KS, int NT, int MR, int EPI, int CC, bool PERSIST>
+__global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a, int tiles_x, int ntiles) {
     constexpr int R = KS / 2, TR = 4 * MR, AR = TR + 2 * R;
     constexpr int AW = (KS == 3) ? 24 : 16, AQ = AW / 4, XOFF = (KS == 3) ? 3 : 0, XLEFT = (KS == 3) ? 4 : 0;
     constexpr int PL0 = AR * AW;
     constexpr int PLA = PL0 + ((16 - (PL0 % 32)) + 32) % 32;          // channel-plane stride == 16 (mod 32)
-    constexpr int CC = 8, T = 2 * KS * KS;
+    constexpr int KG = CC / 4, T = KG * KS * KS;
     constexpr int NA = CC * AR * AQ;                                    // float4 per A chunk
     constexpr int NA4 = (NA + 255) / 256;
     constexpr int NB = T * NT * 16;                                     // float4 per B chunk
@@ -218,39 +223,50 @@ __global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const int x0 = blockIdx.x * 16, y0 = blockIdx.y * TR;
     const int h = a.h, w = a.w;
     const long hw = (long)h * w;
+    // XCD-aware tile order (non-persistent launches): workgroups are dealt round-robin to the 8 XCDs, so
+    // logical tiles are assigned such that each XCD owns a contiguous run of tiles -- x/y-neighbouring tiles,
+    // whose halo rows share cache lines, then hit the same L2 instead of re-fetching over the fabric.
+    int tile = PERSIST ? (int)blockIdx.x : effi_xcd_remap(blockIdx.x, gridDim.x);
+    if (tile >= ntiles) return;
 
-    // per-thread constants of the A prefetch: element -> (channel in chunk, offset inside a channel map)
-    int a_c[NA4], a_off[NA4], a_lds[NA4];
+    // per-thread state of the A prefetch: LDS slot and global offset (inside one channel map) of each of
+    // this thread's float4 elements; the offset depends on the tile and is refreshed by setup().  Channel /
+    // row / column are re-derived from the element index where needed (a few integer ops) rather than
+    // kept in registers.
+    int a_lds[NA4], a_off[NA4];
 #pragma unroll
     for (int j = 0; j < NA4; ++j) {
         const int f = min(tid + j * 256, NA - 1);
         const int c = f / (AR * AQ);
         const int r = f - c * (AR * AQ);
-        const int row = r / AQ, q = r - row * AQ;
-        const int gy = y0 - R + row, gx = x0 - XLEFT + 4 * q;
-        a_c[j] = c;
-        a_off[j] = ((tid + j * 256 < NA) & (gy >= 0) & (gy < h) & (gx >= 0) & (gx < w)) ? gy * w + gx : -1;
-        a_lds[j] = c * PLA + row * AW + 4 * q;
+        const int row = r / AQ;
+        a_lds[j] = c * PLA + row * AW + 4 * (r - row * AQ);
     }
-
-    f32x4 acc[MR][NT];
+    auto setup = [&](int t, int& x0, int& y0) {
+        const int ty_ = t / tiles_x;
+        x0 = (t - ty_ * tiles_x) * 16;
+        y0 = ty_ * TR;
 #pragma unroll
-    for (int m = 0; m < MR; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int j = 0; j < NA4; ++j) {
+            const int f = min(tid + j * 256, NA - 1);
+            const int r = f % (AR * AQ);
+            const int row = r / AQ;
+            const int gy = y0 - R + row, gx = x0 - XLEFT + 4 * (r - row * AQ);
+            a_off[j] = ((tid + j * 256 < NA) & (gy >= 0) & (gy < h) & (gx >= 0) & (gx < w)) ? gy * w + gx : -1;
+        }
+    };
 
     float4 pa[NA4], pb[NB4];
-    const int nchunks = (a.kgroups + 1) / 2;
+    const int nchunks = (a.kgroups + KG - 1) / KG;
     const long wchunk = (long)T * NT * 64;                              // floats of wpack per chunk
     const long wtotal = (long)a.kgroups * KS * KS * NT * 64;
 
     auto prefetch = [&](int ch) {
 #pragma unroll
         for (int j = 0; j < NA4; ++j) {
-            int cg = ch * CC + a_c[j];
+            int cg = ch * CC + min(tid + j * 256, NA - 1) / (AR * AQ);
             const bool ok = (a_off[j] >= 0) & (cg < a.cin);
             const float* p = a.src[0];
             if (cg >= a.ch[0]) {
@@ -264,7 +280,7 @@ __global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a)
 #pragma unroll
         for (int j = 0; j < NB4; ++j) {
             const long f = (long)ch * wchunk + 4L * (tid + j * 256);
-            const bool ok = (tid + j * 256 < NB) & (f < wtotal);     // odd k-group count: the tail is zero
+            const bool ok = (tid + j * 256 < NB) & (f < wtotal);     // partial last chunk: the tail is zero
             const float4 t = *reinterpret_cast<const float4*>(a.wpack + (ok ? f : 0));
             pb[j] = ok ? t : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
@@ -278,91 +294,122 @@ __global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a)
             if (tid + j * 256 < NB) *reinterpret_cast<float4*>(&lds_b[4 * (tid + j * 256)]) = pb[j];
     };
 
+    int x0, y0;                       // tile being multiplied
+    setup(tile, x0, y0);
     prefetch(0);
     stash();
     __syncthreads();
     const float* ab = &lds_a[lk * PLA + (wv * MR) * AW + li + XOFF];
     const float* bb = &lds_b[lane];
-    for (int ch = 0; ch < nchunks; ++ch) {
-        if (ch + 1 < nchunks) prefetch(ch + 1);
-        float af[2][MR], bf[2][NT];
-        auto frag = [&](int t, int s) {
-            const int kg = t / (KS * KS), tap = t % (KS * KS), ky = tap / KS, kx = tap % KS;
-#pragma unroll
-            for (int n = 0; n < NT; ++n) bf[s][n] = bb[(t * NT + n) * 64];
-#pragma unroll
-            for (int m = 0; m < MR; ++m) af[s][m] = ab[kg * 4 * PLA + (m + ky) * AW + kx];
-        };
-        frag(0, 0);
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            if (t + 1 < T) frag(t + 1, (t + 1) & 1);
-#pragma unroll
-            for (int m = 0; m < MR; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t & 1][m], bf[t & 1][n], acc[m][n], 0, 0, 0);
-        }
-        if (ch + 1 < nchunks) {
-            __syncthreads();
-            stash();
-            __syncthreads();
-        }
-    }
-
-    // ---- epilogue (same lane map as v1): pixels x = x0 + 4*lk + r of row y, channel 16*n + li
-    const int x = x0 + 4 * lk;
     float lo = 0.0f, hi = 0.0f;
     if (EPI == EFFI_EPI_HEAD) { lo = a.disp_range[0]; hi = a.disp_range[a.n_range - 1]; }
+
+    while (true) {
+        f32x4 acc[MR][NT];
 #pragma unroll
-    for (int m = 0; m < MR; ++m) {
-        const int y = y0 + wv * MR + m;
-        if (y >= h || x >= w) continue;
-        const long pix = (long)y * w + x;
+        for (int m = 0; m < MR; ++m)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int co = n * 16 + li;
-            if (co >= a.cout) continue;
-            const float b = a.bias[co];
-            float v[4] = {acc[m][n][0] + b, acc[m][n][1] + b, acc[m][n][2] + b, acc[m][n][3] + b};
-            float* dst;
-            if (EPI == EFFI_EPI_PLAIN) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], a.act);
-                dst = a.out0 + (long)co * hw + pix;
-            } else if (EPI == EFFI_EPI_GRU_ZR) {
-                if (co < a.hd) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = effi_sigmoid(v[r]);
-                    dst = a.out0 + (long)co * hw + pix;
-                } else {
-                    const float4 hv = *reinterpret_cast<const float4*>(a.aux0 + (long)(co - a.hd) * hw + pix);
-                    v[0] = effi_sigmoid(v[0]) * hv.x;
-                    v[1] = effi_sigmoid(v[1]) * hv.y;
-                    v[2] = effi_sigmoid(v[2]) * hv.z;
-                    v[3] = effi_sigmoid(v[3]) * hv.w;
-                    dst = a.out1 + (long)(co - a.hd) * hw + pix;
-                }
-            } else if (EPI == EFFI_EPI_GRU_Q) {
-                const float4 hv = *reinterpret_cast<const float4*>(a.aux0 + (long)co * hw + pix);
-                const float4 zv = *reinterpret_cast<const float4*>(a.aux1 + (long)co * hw + pix);
-                v[0] = (1.0f - zv.x) * hv.x + zv.x * tanhf(v[0]);
-                v[1] = (1.0f - zv.y) * hv.y + zv.y * tanhf(v[1]);
-                v[2] = (1.0f - zv.z) * hv.z + zv.z * tanhf(v[2]);
-                v[3] = (1.0f - zv.w) * hv.w + zv.w * tanhf(v[3]);
-                dst = a.out0 + (long)co * hw + pix;
-            } else {  // EFFI_EPI_HEAD
-                const float4 iv = *reinterpret_cast<const float4*>(a.aux0 + pix);
-                v[0] = iv.x + tanhf(v[0]);
-                v[1] = iv.y + tanhf(v[1]);
-                v[2] = iv.z + tanhf(v[2]);
-                v[3] = iv.w + tanhf(v[3]);
-                dst = a.out0 + pix;
-                *reinterpret_cast<float4*>(a.out1 + pix) = make_float4(effi_inv_to_depth(v[0], lo, hi), effi_inv_to_depth(v[1], lo, hi),
-                                                                       effi_inv_to_depth(v[2], lo, hi), effi_inv_to_depth(v[3], lo, hi));
+            for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const int next_tile = PERSIST ? tile + (int)gridDim.x : ntiles;
+        int nx0 = 0, ny0 = 0;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            bool have_next = true;
+            if (ch + 1 < nchunks) {
+                prefetch(ch + 1);
+            } else if (next_tile < ntiles) {
+                setup(next_tile, nx0, ny0);
+                prefetch(0);
+            } else {
+                have_next = false;
             }
-            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            // k-loop of the chunk: KG k-groups (rolled) x KS*KS taps (unrolled, fragments double-buffered)
+#pragma unroll 1
+            for (int kg = 0; kg < KG; ++kg) {
+                const float* abk = ab + kg * 4 * PLA;
+                const float* bbk = bb + kg * (KS * KS) * NT * 64;
+                float af[2][MR], bf[2][NT];
+                auto frag = [&](int tap, int s) {
+                    const int ky = tap / KS, kx = tap % KS;
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) bf[s][n] = bbk[(tap * NT + n) * 64];
+#pragma unroll
+                    for (int m = 0; m < MR; ++m) af[s][m] = abk[(m + ky) * AW + kx];
+                };
+                frag(0, 0);
+#pragma unroll
+                for (int tap = 0; tap < KS * KS; ++tap) {
+                    if (tap + 1 < KS * KS) frag(tap + 1, (tap + 1) & 1);
+#pragma unroll
+                    for (int m = 0; m < MR; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[tap & 1][m], bf[tap & 1][n], acc[m][n], 0, 0, 0);
+                }
+            }
+            if (have_next) {
+                __syncthreads();
+                stash();
+                __syncthreads();
+            }
         }
+
+        // ---- epilogue of tile (x0, y0): pixels x = x0 + 4*lk + r of row y, channel 16*n + li
+        const int x = x0 + 4 * lk;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const int y = y0 + wv * MR + m;
+            if (y >= h || x >= w) continue;
+            const long pix = (long)y * w + x;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int co = n * 16 + li;
+                if (co >= a.cout) continue;
+                const float b = a.bias[co];
+                float v[4] = {acc[m][n][0] + b, acc[m][n][1] + b, acc[m][n][2] + b, acc[m][n][3] + b};
+                float* dst;
+                if (EPI == EFFI_EPI_PLAIN) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], a.act);
+                    dst = a.out0 + (long)co * hw + pix;
+                } else if (EPI == EFFI_EPI_GRU_ZR) {
+                    if (co < a.hd) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = effi_sigmoid(v[r]);
+                        dst = a.out0 + (long)co * hw + pix;
+                    } else {
+                        const float4 hv = *reinterpret_cast<const float4*>(a.aux0 + (long)(co - a.hd) * hw + pix);
+                        v[0] = effi_sigmoid(v[0]) * hv.x;
+                        v[1] = effi_sigmoid(v[1]) * hv.y;
+                        v[2] = effi_sigmoid(v[2]) * hv.z;
+                        v[3] = effi_sigmoid(v[3]) * hv.w;
+                        dst = a.out1 + (long)(co - a.hd) * hw + pix;
+                    }
+                } else if (EPI == EFFI_EPI_GRU_Q) {
+                    const float4 hv = *reinterpret_cast<const float4*>(a.aux0 + (long)co * hw + pix);
+                    const float4 zv = *reinterpret_cast<const float4*>(a.aux1 + (long)co * hw + pix);
+                    v[0] = (1.0f - zv.x) * hv.x + zv.x * tanhf(v[0]);
+                    v[1] = (1.0f - zv.y) * hv.y + zv.y * tanhf(v[1]);
+                    v[2] = (1.0f - zv.z) * hv.z + zv.z * tanhf(v[2]);
+                    v[3] = (1.0f - zv.w) * hv.w + zv.w * tanhf(v[3]);
+                    dst = a.out0 + (long)co * hw + pix;
+                } else {  // EFFI_EPI_HEAD
+                    const float4 iv = *reinterpret_cast<const float4*>(a.aux0 + pix);
+                    v[0] = iv.x + tanhf(v[0]);
+                    v[1] = iv.y + tanhf(v[1]);
+                    v[2] = iv.z + tanhf(v[2]);
+                    v[3] = iv.w + tanhf(v[3]);
+                    dst = a.out0 + pix;
+                    *reinterpret_cast<float4*>(a.out1 + pix) =
+                        make_float4(effi_inv_to_depth(v[0], lo, hi), effi_inv_to_depth(v[1], lo, hi),
+                                    effi_inv_to_depth(v[2], lo, hi), effi_inv_to_depth(v[3], lo, hi));
+                }
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        if (next_tile >= ntiles) break;
+        tile = next_tile;
+        x0 = nx0;
+        y0 = ny0;
     }
 }
 
@@ -400,11 +447,150 @@ __global__ __launch_bounds__(256) void conv2d_c1k7_relu_kernel(const float* __re
     for (int c = 0; c < COUT; ++c) out[c * hw + pix] = fmaxf(acc[c], 0.0f);
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 convolution with ONE output channel (depth head conv2, models/update.py:15,21): an MFMA tile would
+// be 15/16 padding, so this runs on the vector ALUs.  64x16 pixel tile, 4 pixels per thread along x (each
+// LDS row segment of 6 values feeds 12 FMAs), 4 input channels per LDS chunk with register prefetch.
+// EPI_PLAIN: out0 = act(conv + bias); EPI_HEAD: out0 = aux0 + tanh(conv + bias), out1 = scaled depth.
+// ------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256) void conv2d_cout1_k3_kernel(const Conv2dArgs a, const float* __restrict__ wraw) {
+    constexpr int TXP = 64, TYP = 16, IW = TXP + 2, IH = TYP + 2, PSZ = IW * IH, CC = 4;
+    constexpr int NPL = (PSZ + 255) / 256;                         // 5
+    __shared__ float tile[CC * PSZ];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int x0 = blockIdx.x * TXP, y0 = blockIdx.y * TYP;
+    const int h = a.h, w = a.w;
+    const long hw = (long)h * w;
+    int poff[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int e = tid + k * 256;
+        const int ly = e / IW, lx = e - ly * IW;
+        const int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
+        poff[k] = ((e < PSZ) & (gy >= 0) & (gy < h) & (gx >= 0) & (gx < w)) ? gy * w + gx : -1;
+    }
+    float pf[CC][NPL];
+    auto prefetch = [&](int c0) {
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            int cg = c0 + c;
+            const bool cok = cg < a.cin;
+            const float* p = a.src[0];
+            if (cok && cg >= a.ch[0]) {
+                cg -= a.ch[0];
+                p = a.src[1];
+                if (cg >= a.ch[1]) { cg -= a.ch[1]; p = a.src[2]; }
+            }
+            p += cok ? (long)cg * hw : 0;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                const float t = p[max(poff[k], 0)];
+                pf[c][k] = (cok & (poff[k] >= 0)) ? t : 0.0f;
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int c = 0; c < CC; ++c)
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                const int e = tid + k * 256;
+                if (e < PSZ) tile[c * PSZ + e] = pf[c][k];
+            }
+    };
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    prefetch(0);
+    stash();
+    __syncthreads();
+    for (int c0 = 0; c0 < a.cin; c0 += CC) {
+        const bool more = (c0 + CC < a.cin);
+        if (more) prefetch(c0 + CC);
+        const int ccn = min(CC, a.cin - c0);
+        for (int c = 0; c < ccn; ++c) {
+            const float* __restrict__ wc = wraw + (long)(c0 + c) * 9;       // [cin][3][3] of the single output channel
+            const float* tc = tile + c * PSZ + ty * IW + 4 * tx;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                float r[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) r[i] = tc[ky * IW + i];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float wv = wc[ky * 3 + kx];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = fmaf(r[i + kx], wv, acc[i]);
+                }
+            }
+        }
+        if (more) {
+            __syncthreads();
+            stash();
+            __syncthreads();
+        }
+    }
+    const int y = y0 + ty, x = x0 + 4 * tx;
+    if (y >= h || x >= w) return;
+    const long pix = (long)y * w + x;
+    const float b = a.bias[0];
+    float lo = 0.0f, hi = 0.0f;
+    if (EPI == EFFI_EPI_HEAD) { lo = a.disp_range[0]; hi = a.disp_range[a.n_range - 1]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (x + i >= w) break;
+        float v = acc[i] + b;
+        if (EPI == EFFI_EPI_HEAD) {
+            v = a.aux0[pix + i] + tanhf(v);
+            a.out1[pix + i] = effi_inv_to_depth(v, lo, hi);
+        } else {
+            v = apply_act(v, a.act);
+        }
+        a.out0[pix + i] = v;
+    }
+}
+
+// Tuning knob for A/B measurements (tools/bench_conv2d.py): EFFI_CONV2D_VARIANT = 0 (one tile per
+// workgroup, 8-channel chunks), 1 (persistent, 8), 2 (persistent, 16-channel chunks where they fit).
+static int conv2d_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("EFFI_CONV2D_VARIANT");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
+template <int KS, int NT, int MR, int EPI, int CC, bool PERSIST>
+int launch2d_cfg(const Conv2dArgs& a, hipStream_t st) {
+    const int tiles_x = effi_cdiv(a.w, 16), ntiles = tiles_x * effi_cdiv(a.h, 4 * MR);
+    int grid = ntiles;
+    if (PERSIST) {
+        // persistent grid: as many workgroups as stay resident, each walks tiles b, b + grid, ...
+        const int acc = NT * MR;
+        const int per_cu = acc <= 4 ? 4 : (acc <= 8 ? 3 : 2);
+        grid = min(ntiles, 256 * per_cu);
+    }
+    hipLaunchKernelGGL((conv2d_mfma_v2_kernel<KS, NT, MR, EPI, CC, PERSIST>), dim3(grid), dim3(256), 0, st, a, tiles_x, ntiles);
+    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+}
+
 template <int KS, int NT, int MR, int EPI>
 int launch2d_v2(const Conv2dArgs& a, hipStream_t st) {
-    dim3 grid(effi_cdiv(a.w, 16), effi_cdiv(a.h, 4 * MR));
-    hipLaunchKernelGGL((conv2d_mfma_v2_kernel<KS, NT, MR, EPI>), grid, dim3(256), 0, st, a);
-    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+    switch (conv2d_variant()) {
+        case 1: return launch2d_cfg<KS, NT, MR, EPI, 8, true>(a, st);
+        case 2: return launch2d_cfg<KS, NT, MR, EPI, (NT * MR <= 4 ? 16 : 8), true>(a, st);
+        case 3: return launch2d_cfg<KS, NT, MR, EPI, (NT * MR <= 4 ? 16 : 8), false>(a, st);
+        default: return launch2d_cfg<KS, NT, MR, EPI, 8, false>(a, st);
+    }
+}
+
+static int conv2d_force_mr() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("EFFI_CONV2D_MR");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
 }
 
 template <int KS, int NT, int EPI>
@@ -412,8 +598,14 @@ int launch2d(const Conv2dArgs& a, hipStream_t st) {
     if ((a.w & 3) == 0) {
         // rows per wave: the largest of {4, 2, 1} that still yields >= 2 workgroups per CU (256 CUs)
         const long cols = effi_cdiv(a.w, 16);
-        if (cols * effi_cdiv(a.h, 16) >= 512 || KS == 1 && cols * effi_cdiv(a.h, 16) >= 256) return launch2d_v2<KS, NT, 4, EPI>(a, st);
-        if (cols * effi_cdiv(a.h, 8) >= 512 || KS == 1) return launch2d_v2<KS, NT, 2, EPI>(a, st);
+        int mr;
+        if (cols * effi_cdiv(a.h, 16) >= 512 || (KS == 1 && cols * effi_cdiv(a.h, 16) >= 256)) mr = 4;
+        else if (cols * effi_cdiv(a.h, 8) >= 512 || KS == 1) mr = 2;
+        else mr = 1;
+        if (conv2d_force_mr() > 0) mr = conv2d_force_mr();
+        if (KS == 1 && mr == 1) mr = 2;
+        if (mr == 4) return launch2d_v2<KS, NT, 4, EPI>(a, st);
+        if (mr == 2) return launch2d_v2<KS, NT, 2, EPI>(a, st);
         return launch2d_v2<KS, NT, (KS == 3 ? 1 : 2), EPI>(a, st);
     }
     dim3 grid(effi_cdiv(a.w, 16), effi_cdiv(a.h, 16));
@@ -465,6 +657,19 @@ extern "C" int effi_conv2d_f32(const float* const* srcs, const int* src_channels
     a.out1 = out1;
     const int nt = (cout + 15) / 16;
     hipStream_t st = effi_s(stream);
+    if (cout == 1 && ks == 3 && (long)h * w >= 262144 && (epilogue == EFFI_EPI_PLAIN || epilogue == EFFI_EPI_HEAD)) {
+        // single output channel on a large map: vector-ALU kernel (an MFMA tile would be 15/16 padding);
+        // it reads plain [cin][9] weights that the host appends behind the packed block (packing.py).
+        // Small maps keep the MFMA kernel, whose finer tiling still fills the chip.
+        if (epilogue == EFFI_EPI_HEAD && (!aux0 || !out1 || !disp_range || n_range < 2)) return EFFI_ERR_BADARG;
+        const float* wraw = wpack + (long)a.kgroups * 9 * 64;
+        dim3 grid(effi_cdiv(w, 64), effi_cdiv(h, 16));
+        if (epilogue == EFFI_EPI_HEAD)
+            hipLaunchKernelGGL(conv2d_cout1_k3_kernel<EFFI_EPI_HEAD>, grid, dim3(256), 0, st, a, wraw);
+        else
+            hipLaunchKernelGGL(conv2d_cout1_k3_kernel<EFFI_EPI_PLAIN>, grid, dim3(256), 0, st, a, wraw);
+        return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+    }
     switch (epilogue) {
         case EFFI_EPI_PLAIN:
             if (act < EFFI_ACT_NONE || act > EFFI_ACT_TANH) return EFFI_ERR_BADARG;

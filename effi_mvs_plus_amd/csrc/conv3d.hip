@@ -31,24 +31,29 @@ __device__ __forceinline__ const float* src_channel(const SrcSet& s, int c, long
 // ------------------------------------------------------------------------------------------------
 // forward convolution, stride (SZ, SXY, SXY)
 // ------------------------------------------------------------------------------------------------
-template <int COUT_T, int SZ, int SXY>
+template <int COUT_T, int SZ, int SXY, int ZPT>
 __global__ __launch_bounds__(256) void conv3d_k3_kernel(SrcSet src, int cin, const float* __restrict__ wgt,
                                                         const float* __restrict__ bias, int cout,
                                                         int D, int h, int w, int Do, int ho, int wo,
                                                         int relu, const float* __restrict__ skip,
                                                         float* __restrict__ out) {
-    constexpr int ZPT = (SXY == 1) ? 4 : ((SZ == 1) ? 4 : 2);
     constexpr int CC = (SXY == 1) ? 4 : ((SZ == 1) ? 1 : 2);
     constexpr int IZ = (ZPT - 1) * SZ + 3, IY = (TY - 1) * SXY + 3, IX = (TX - 1) * SXY + 3;
     constexpr int PLANE = IZ * IY * IX;
     constexpr int PSZ = IY * IX, NPL = (PSZ + 255) / 256;   // plane size, fill slots per thread and plane
     __shared__ float tile[CC * PLANE];
 
-    const int tiles_x = (wo + TX - 1) / TX;
-    const int by = blockIdx.x / tiles_x, bx = blockIdx.x - by * tiles_x;
+    // 1-D grid, XCD-aware: each XCD owns a contiguous run of (z-group, xy-tile) work items, so tiles that
+    // share halo planes / cache lines hit the same L2.  Order: xy-tile fastest, then z-group, then cout group.
+    const int tiles_x = (wo + TX - 1) / TX, tiles_xy = tiles_x * ((ho + TY - 1) / TY), nzg = (Do + ZPT - 1) / ZPT;
+    int lid = effi_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_xy = lid % tiles_xy;
+    lid /= tiles_xy;
+    const int zg = lid % nzg, cg = lid / nzg;
+    const int by = tile_xy / tiles_x, bx = tile_xy - by * tiles_x;
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-    const int ox = bx * TX + tx, oy = by * TY + ty, oz0 = blockIdx.y * ZPT;
-    const int co0 = blockIdx.z * COUT_T;
+    const int ox = bx * TX + tx, oy = by * TY + ty, oz0 = zg * ZPT;
+    const int co0 = cg * COUT_T;
     const int iz0 = oz0 * SZ - 1, iy0 = by * TY * SXY - 1, ix0 = bx * TX * SXY - 1;
     const long in_plane = (long)D * h * w;
 
@@ -67,34 +72,50 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(SrcSet src, int cin, con
 #pragma unroll
         for (int c = 0; c < COUT_T; ++c) acc[z][c] = 0.0f;
 
-    for (int c0 = 0; c0 < cin; c0 += CC) {
-        const int ccn = min(CC, cin - c0);
-        __syncthreads();
-        // tile fill: per channel, all IZ x NPL loads are issued before the first LDS write; the in-plane
-        // offsets were computed once per block, so a load costs a couple of VALU ops
-        for (int c = 0; c < ccn; ++c) {
-            const float* __restrict__ cp = src_channel(src, c0 + c, in_plane);
-            float v[IZ][NPL];
+    // Register prefetch: the loads of chunk k+1 are issued before the FMAs of chunk k and only waited
+    // for when they are written to LDS, so the tile-fill latency hides behind the multiply phase.
+    float pf[CC][IZ][NPL];
+    auto prefetch = [&](int c0) {
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            const bool cok = (c0 + c < cin);
+            const float* __restrict__ cp = src_channel(src, cok ? c0 + c : 0, in_plane);
 #pragma unroll
             for (int lz = 0; lz < IZ; ++lz) {
                 const int gz = iz0 + lz;
-                const bool zok = (gz >= 0) & (gz < D);
+                const bool zok = cok & (gz >= 0) & (gz < D);
                 const float* __restrict__ zp = cp + (zok ? (long)gz * h * w : 0);
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) {
                     const float t = zp[max(poff[k], 0)];
-                    v[lz][k] = (zok & (poff[k] >= 0)) ? t : 0.0f;
+                    pf[c][lz][k] = (zok & (poff[k] >= 0)) ? t : 0.0f;
                 }
             }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int c = 0; c < CC; ++c)
 #pragma unroll
             for (int lz = 0; lz < IZ; ++lz)
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) {
                     const int e = threadIdx.x + k * 256;
-                    if (e < PSZ) tile[c * PLANE + lz * PSZ + e] = v[lz][k];
+                    if (e < PSZ) tile[c * PLANE + lz * PSZ + e] = pf[c][lz][k];
                 }
-        }
-        __syncthreads();
+    };
+
+    // ZPT == 1 (low-resolution layers, few waves per SIMD): the next chunk is prefetched into registers
+    // behind the FMAs.  ZPT > 1: the extra registers would cost a wave per SIMD, and the other resident
+    // workgroups already cover the fill latency, so the chunk is loaded in place.
+    constexpr bool PF = (ZPT == 1);
+    prefetch(0);
+    stash();
+    __syncthreads();
+    for (int c0 = 0; c0 < cin; c0 += CC) {
+        const int ccn = min(CC, cin - c0);
+        const bool more = (c0 + CC < cin);
+        if (PF && more) prefetch(c0 + CC);
         for (int c = 0; c < ccn; ++c) {
             const float* __restrict__ wc = wgt + (long)(c0 + c) * 27 * cout + co0;
             const float* tc = tile + c * PLANE + (ty * SXY) * IX + tx * SXY;
@@ -115,6 +136,12 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(SrcSet src, int cin, con
                                 acc[z][co] = fmaf(col[z * SZ + kd], wk[co], acc[z][co]);
                     }
                 }
+        }
+        if (more) {
+            __syncthreads();
+            if (!PF) prefetch(c0 + CC);
+            stash();
+            __syncthreads();
         }
     }
 
@@ -158,11 +185,15 @@ __global__ __launch_bounds__(256) void deconv3d_k3_kernel(const float* __restric
     constexpr int PSZ = IY * IX, NPL = (PSZ + 255) / 256;
     __shared__ float tile[CC * PLANE];
 
-    const int tiles_x = (w + TX - 1) / TX;
-    const int by = blockIdx.x / tiles_x, bx = blockIdx.x - by * tiles_x;
+    const int tiles_x = (w + TX - 1) / TX, tiles_xy = tiles_x * ((h + TY - 1) / TY), nzg = (D + ZPT - 1) / ZPT;
+    int lid = effi_xcd_remap(blockIdx.x, gridDim.x);       // XCD-aware 1-D grid, as in conv3d_k3_kernel
+    const int tile_xy = lid % tiles_xy;
+    lid /= tiles_xy;
+    const int zg = lid % nzg, cg = lid / nzg;
+    const int by = tile_xy / tiles_x, bx = tile_xy - by * tiles_x;
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-    const int ix = bx * TX + tx, iy = by * TY + ty, z0 = blockIdx.y * ZPT;
-    const int co0 = blockIdx.z * COUT_T;
+    const int ix = bx * TX + tx, iy = by * TY + ty, z0 = zg * ZPT;
+    const int co0 = cg * COUT_T;
     const int iz0 = (SZ == 2) ? z0 : z0 - 1;
     const long in_plane = (long)D * h * w;
 
@@ -185,32 +216,44 @@ __global__ __launch_bounds__(256) void deconv3d_k3_kernel(const float* __restric
 #pragma unroll
                 for (int d = 0; d < COUT_T; ++d) acc[a][b][c][d] = 0.0f;
 
-    for (int c0 = 0; c0 < cin; c0 += CC) {
-        const int ccn = min(CC, cin - c0);
-        __syncthreads();
-        for (int c = 0; c < ccn; ++c) {
-            const float* __restrict__ cp = in + (long)(c0 + c) * in_plane;
-            float v[IZ][NPL];
+    float pf[CC][IZ][NPL];
+    auto prefetch = [&](int c0) {
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+            const bool cok = (c0 + c < cin);
+            const float* __restrict__ cp = in + (long)(cok ? c0 + c : 0) * in_plane;
 #pragma unroll
             for (int lz = 0; lz < IZ; ++lz) {
                 const int gz = iz0 + lz;
-                const bool zok = (gz >= 0) & (gz < D);
+                const bool zok = cok & (gz >= 0) & (gz < D);
                 const float* __restrict__ zp = cp + (zok ? (long)gz * h * w : 0);
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) {
                     const float t = zp[max(poff[k], 0)];
-                    v[lz][k] = (zok & (poff[k] >= 0)) ? t : 0.0f;
+                    pf[c][lz][k] = (zok & (poff[k] >= 0)) ? t : 0.0f;
                 }
             }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int c = 0; c < CC; ++c)
 #pragma unroll
             for (int lz = 0; lz < IZ; ++lz)
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) {
                     const int e = threadIdx.x + k * 256;
-                    if (e < PSZ) tile[c * PLANE + lz * PSZ + e] = v[lz][k];
+                    if (e < PSZ) tile[c * PLANE + lz * PSZ + e] = pf[c][lz][k];
                 }
-        }
-        __syncthreads();
+    };
+
+    prefetch(0);
+    stash();
+    __syncthreads();
+    for (int c0 = 0; c0 < cin; c0 += CC) {
+        const int ccn = min(CC, cin - c0);
+        const bool more = (c0 + CC < cin);
+        if (more) prefetch(c0 + CC);
         for (int c = 0; c < ccn; ++c) {
             const float* __restrict__ wc = wgt + (long)(c0 + c) * 27 * cout + co0;
             const float* tc = tile + c * PLANE + ty * IX + tx;
@@ -244,6 +287,11 @@ __global__ __launch_bounds__(256) void deconv3d_k3_kernel(const float* __restric
                         }
                     }
         }
+        if (more) {
+            __syncthreads();
+            stash();
+            __syncthreads();
+        }
     }
 
     if (ix >= w || iy >= h) return;
@@ -274,15 +322,26 @@ __global__ __launch_bounds__(256) void deconv3d_k3_kernel(const float* __restric
     }
 }
 
+template <int COUT_T, int SZ, int SXY, int ZPT>
+int launch_conv_z(const SrcSet& s, int cin, const float* wgt, const float* bias, int cout, int D, int h, int w,
+                  int relu, const float* skip, float* out, hipStream_t st) {
+    const int Do = (D - 1) / SZ + 1, ho = (h - 1) / SXY + 1, wo = (w - 1) / SXY + 1;
+    dim3 grid(effi_cdiv(wo, TX) * effi_cdiv(ho, TY) * effi_cdiv(Do, ZPT) * effi_cdiv(cout, COUT_T));
+    hipLaunchKernelGGL((conv3d_k3_kernel<COUT_T, SZ, SXY, ZPT>), grid, dim3(256), 0, st, s, cin, wgt, bias, cout, D, h, w,
+                       Do, ho, wo, relu, skip, out);
+    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+}
+
+// Output z-slices per thread: 4 (2 for stride 2) amortises the z halo of the LDS tile; low-resolution layers
+// fall back to 1 so that the grid still has >= 2 workgroups per CU.
 template <int COUT_T, int SZ, int SXY>
 int launch_conv(const SrcSet& s, int cin, const float* wgt, const float* bias, int cout, int D, int h, int w,
                 int relu, const float* skip, float* out, hipStream_t st) {
-    constexpr int ZPT = (SXY == 1) ? 4 : ((SZ == 1) ? 4 : 2);
+    constexpr int ZBIG = (SXY == 1) ? 4 : ((SZ == 1) ? 4 : 2);
     const int Do = (D - 1) / SZ + 1, ho = (h - 1) / SXY + 1, wo = (w - 1) / SXY + 1;
-    dim3 grid(effi_cdiv(wo, TX) * effi_cdiv(ho, TY), effi_cdiv(Do, ZPT), effi_cdiv(cout, COUT_T));
-    hipLaunchKernelGGL((conv3d_k3_kernel<COUT_T, SZ, SXY>), grid, dim3(256), 0, st, s, cin, wgt, bias, cout, D, h, w,
-                       Do, ho, wo, relu, skip, out);
-    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+    const long blocks = (long)effi_cdiv(wo, TX) * effi_cdiv(ho, TY) * effi_cdiv(Do, ZBIG) * effi_cdiv(cout, COUT_T);
+    if (blocks >= 384) return launch_conv_z<COUT_T, SZ, SXY, ZBIG>(s, cin, wgt, bias, cout, D, h, w, relu, skip, out, st);
+    return launch_conv_z<COUT_T, SZ, SXY, 1>(s, cin, wgt, bias, cout, D, h, w, relu, skip, out, st);
 }
 
 }  // namespace
@@ -319,10 +378,14 @@ extern "C" int effi_deconv3d_k3_f32(const float* in, int cin, const float* weigh
     hipStream_t st = effi_s(stream);
     const int tiles = effi_cdiv(w, TX) * effi_cdiv(h, TY);
     if (sz == 2 && cout % 8 == 0) {
-        hipLaunchKernelGGL((deconv3d_k3_kernel<8, 2>), dim3(tiles, D, cout / 8), dim3(256), 0, st, in, cin, weight, bias,
-                           cout, D, h, w, relu, skip, out);
+        if ((long)tiles * D * (cout / 8) >= 512)
+            hipLaunchKernelGGL((deconv3d_k3_kernel<8, 2>), dim3(tiles * D * (cout / 8)), dim3(256), 0, st, in, cin, weight, bias,
+                               cout, D, h, w, relu, skip, out);
+        else   // low-resolution level: split the output channels finer so the grid covers the chip
+            hipLaunchKernelGGL((deconv3d_k3_kernel<4, 2>), dim3(tiles * D * (cout / 4)), dim3(256), 0, st, in, cin, weight, bias,
+                               cout, D, h, w, relu, skip, out);
     } else if (sz == 1 && cout == 1) {
-        hipLaunchKernelGGL((deconv3d_k3_kernel<1, 1>), dim3(tiles, effi_cdiv(D, 4), 1), dim3(256), 0, st, in, cin, weight,
+        hipLaunchKernelGGL((deconv3d_k3_kernel<1, 1>), dim3(tiles * effi_cdiv(D, 4)), dim3(256), 0, st, in, cin, weight,
                            bias, cout, D, h, w, relu, skip, out);
     } else {
         return EFFI_ERR_UNSUPPORTED;

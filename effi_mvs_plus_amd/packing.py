@@ -76,7 +76,14 @@ def pack_conv2d_mfma(weight, bias, scale=1.0):
     b = torch.zeros(nt * 16, device=weight.device, dtype=torch.float32)
     if bias is not None:
         b[:cout] = bias.float() * scale
-    return w.view(kg, ks * ks, nt, 64), b
+    w = w.view(kg, ks * ks, nt, 64)
+    if cout == 1 and ks == 3:
+        # single-output-channel convs run on the vector ALUs and read plain [cin][9] weights, which ride
+        # behind the MFMA block in the same buffer (effi_conv2d_f32 finds them at offset kg*9*64)
+        raw = (weight.reshape(cin, 9).float() * scale).reshape(-1)
+        flat = torch.cat([w.reshape(-1), raw]).contiguous()
+        return flat, b
+    return w, b
 
 
 def pack_conv2d_c1k7(weight, bias):

@@ -118,12 +118,18 @@ def test_conv2d_weight_packing_layout(ks, cin, cout):
     wt, b = torch.randn(cout, cin, ks, ks, generator=g), torch.randn(cout, generator=g)
     x = torch.randn(cin, 6, 9, generator=g)
     wp, bp = packing.pack_conv2d_mfma(wt, b)
-    assert wp.shape == ((cin + 3) // 4, ks * ks, (cout + 15) // 16, 64) and bp.shape == (16 * ((cout + 15) // 16),)
+    shape4 = ((cin + 3) // 4, ks * ks, (cout + 15) // 16, 64)
+    if cout == 1 and ks == 3:          # depth head: plain [cin][9] weights ride behind the MFMA block
+        n = shape4[0] * shape4[1] * shape4[2] * 64
+        assert wp.dim() == 1 and wp.numel() == n + cin * 9
+        assert torch.equal(wp[n:].view(cin, 9), wt.reshape(cin, 9))
+        wp = wp[:n].view(shape4)
+    assert wp.shape == shape4 and bp.shape == (16 * ((cout + 15) // 16),)
     got = _emulate_mfma_conv(x.numpy(), wp.numpy(), bp.numpy(), cout, ks)
     want = F.conv2d(x.unsqueeze(0).double(), wt.double(), b.double(), padding=ks // 2)[0].numpy()
     assert np.allclose(got, want, rtol=1e-6, atol=1e-6)
     wq, bq = packing.pack_conv2d_mfma(wt, b, scale=0.25)              # mask head: exact power-of-two folding
-    assert torch.equal(wq, wp * 0.25) and torch.equal(bq, bp * 0.25)
+    assert torch.equal(wq.reshape(-1)[:wp.numel()], wp.reshape(-1) * 0.25) and torch.equal(bq, bp * 0.25)
 
 
 def test_bn_folding_and_3d_packing():
