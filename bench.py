@@ -63,7 +63,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
 
     from common import build_model
-    from effi_mvs_plus_amd import _lib, ops, synth
+    from effi_mvs_plus_amd import _lib, ops, shard, synth
 
     _lib.lib()                                   # fail loudly if the HIP library is missing
     H, W, N, nd = WORKLOADS[args.workload]
@@ -114,12 +114,9 @@ def main():
             finals.append(out["depth"][-1])
             confs.append(out["photometric_confidence"])
         if distributed:
-            depth_all = torch.cat(finals)                          # [K, H, W]
-            conf_all = torch.cat(confs)
-            gd = [torch.empty_like(depth_all) for _ in range(world)] if rank == 0 else None
-            gc = [torch.empty_like(conf_all) for _ in range(world)] if rank == 0 else None
-            dist.gather(depth_all, gd, dst=0)
-            dist.gather(conf_all, gc, dst=0)
+            # the path's only collective: ONE RCCL gather per tensor of this rank's finished maps to rank 0
+            shard.gather_maps(torch.cat(finals), args.steps * world, dst=0)
+            shard.gather_maps(torch.cat(confs), args.steps * world, dst=0)
         barrier()
         dt = time.perf_counter() - t0
         ops.set_profile(None)
@@ -142,7 +139,16 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": bytes_per_launch / (avg_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["traffic"] = None               # PMC bytes: see profiles/ (collected in separate rocprofv3 --pmc passes)
+        # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE), collected offline in separate
+        # rocprofv3 --pmc passes of this same command and summarised by tools/pmc_traffic.py (see profiles/)
+        roof["traffic"] = None
+        tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tr = json.load(f).get(key)
+            if tr:
+                roof["traffic"] = tr["fetch_bytes"] + tr["write_bytes"]
+                roof["traffic_detail"] = tr
         roof["kernel"] = key
         roof["avg_launch_ms"] = avg_ms
         roof["launches_timed"] = ksum["launches"]

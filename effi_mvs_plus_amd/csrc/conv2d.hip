@@ -12,8 +12,6 @@
 //   B operand  (lane l: k = l>>4, cout l&15): weights are host-packed in exactly that lane order, so each
 //              k-step's B tile is ONE coalesced 256-byte global load (L1/L2 resident, shared by all blocks).
 // Epilogues (bias, activation, GRU gating, depth-head update) are fused; see EFFI_EPI_* in the header.
-#include <cstdlib>
-
 #include "common.hpp"
 
 namespace {
@@ -549,48 +547,15 @@ __global__ __launch_bounds__(256) void conv2d_cout1_k3_kernel(const Conv2dArgs a
     }
 }
 
-// Tuning knob for A/B measurements (tools/bench_conv2d.py): EFFI_CONV2D_VARIANT = 0 (one tile per
-// workgroup, 8-channel chunks), 1 (persistent, 8), 2 (persistent, 16-channel chunks where they fit).
-static int conv2d_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("EFFI_CONV2D_VARIANT");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
-
-template <int KS, int NT, int MR, int EPI, int CC, bool PERSIST>
-int launch2d_cfg(const Conv2dArgs& a, hipStream_t st) {
-    const int tiles_x = effi_cdiv(a.w, 16), ntiles = tiles_x * effi_cdiv(a.h, 4 * MR);
-    int grid = ntiles;
-    if (PERSIST) {
-        // persistent grid: as many workgroups as stay resident, each walks tiles b, b + grid, ...
-        const int acc = NT * MR;
-        const int per_cu = acc <= 4 ? 4 : (acc <= 8 ? 3 : 2);
-        grid = min(ntiles, 256 * per_cu);
-    }
-    hipLaunchKernelGGL((conv2d_mfma_v2_kernel<KS, NT, MR, EPI, CC, PERSIST>), dim3(grid), dim3(256), 0, st, a, tiles_x, ntiles);
-    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
-}
-
+// Measured on MI355X (tools/bench_conv2d.py): 8-channel chunks with one tile per workgroup
+// beat 16-channel chunks, persistent workgroups and a same-accumulator ("run-ordered") MFMA schedule -- each of
+// those costs registers, i.e. waves per SIMD, and the kernel is bound by its LDS->MFMA phase, not by global
+// latency -- so only that configuration is instantiated; CC / PERSIST stay as parameters for future A/B runs.
 template <int KS, int NT, int MR, int EPI>
 int launch2d_v2(const Conv2dArgs& a, hipStream_t st) {
-    switch (conv2d_variant()) {
-        case 1: return launch2d_cfg<KS, NT, MR, EPI, 8, true>(a, st);
-        case 2: return launch2d_cfg<KS, NT, MR, EPI, (NT * MR <= 4 ? 16 : 8), true>(a, st);
-        case 3: return launch2d_cfg<KS, NT, MR, EPI, (NT * MR <= 4 ? 16 : 8), false>(a, st);
-        default: return launch2d_cfg<KS, NT, MR, EPI, 8, false>(a, st);
-    }
-}
-
-static int conv2d_force_mr() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("EFFI_CONV2D_MR");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
+    const int tiles_x = effi_cdiv(a.w, 16), ntiles = tiles_x * effi_cdiv(a.h, 4 * MR);
+    hipLaunchKernelGGL((conv2d_mfma_v2_kernel<KS, NT, MR, EPI, 8, false>), dim3(ntiles), dim3(256), 0, st, a, tiles_x, ntiles);
+    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
 
 template <int KS, int NT, int EPI>
@@ -602,7 +567,6 @@ int launch2d(const Conv2dArgs& a, hipStream_t st) {
         if (cols * effi_cdiv(a.h, 16) >= 512 || (KS == 1 && cols * effi_cdiv(a.h, 16) >= 256)) mr = 4;
         else if (cols * effi_cdiv(a.h, 8) >= 512 || KS == 1) mr = 2;
         else mr = 1;
-        if (conv2d_force_mr() > 0) mr = conv2d_force_mr();
         if (KS == 1 && mr == 1) mr = 2;
         if (mr == 4) return launch2d_v2<KS, NT, 4, EPI>(a, st);
         if (mr == 2) return launch2d_v2<KS, NT, 2, EPI>(a, st);

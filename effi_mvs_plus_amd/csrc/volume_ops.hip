@@ -118,7 +118,7 @@ __global__ void view_aggregate_kernel(const float* __restrict__ sim_views, const
 __global__ void softmax_regress_conf_kernel(const float* __restrict__ logits, const float* __restrict__ depth,
                                             long dds, long dps, int D, int hw,
                                             float* __restrict__ out_depth, float* __restrict__ out_conf) {
-    const int p = blockIdx.x * TPB + threadIdx.x;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;     // launched with 64-thread blocks
     if (p >= hw) return;
     float m = -INFINITY;
     for (int d = 0; d < D; ++d) m = fmaxf(m, logits[(long)d * hw + p]);
@@ -316,7 +316,7 @@ extern "C" int effi_view_aggregate_f32(const float* sim_views, const float* weig
 extern "C" int effi_softmax_regress_conf_f32(const float* logits, const float* depth, long dds, long dps, int D,
                                              int hw, float* out_depth, float* out_conf, effi_stream_t stream) {
     if (!logits || !depth || !out_depth || !out_conf || D < 1 || hw < 1) return EFFI_ERR_BADARG;
-    hipLaunchKernelGGL(softmax_regress_conf_kernel, dim3(effi_cdiv(hw, TPB)), dim3(TPB), 0, effi_s(stream), logits,
+    hipLaunchKernelGGL(softmax_regress_conf_kernel, dim3(effi_cdiv(hw, 64)), dim3(64), 0, effi_s(stream), logits,
                        depth, dds, dps, D, hw, out_depth, out_conf);
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;

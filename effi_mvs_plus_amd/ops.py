@@ -75,7 +75,9 @@ def _p(x):
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # raw hipStream_t of torch's current stream on the current device (fast path: ~1 us instead of the
+    # ~8 us of torch.cuda.current_stream().cuda_stream; this is called once per kernel launch)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def _ptr_array(tensors):

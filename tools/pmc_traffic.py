@@ -1,39 +1,81 @@
 #!/usr/bin/env python3
-"""Per-kernel effective clock (GRBM_GUI_ACTIVE / 8 / time) and HBM traffic (FETCH_SIZE / WRITE_SIZE, KB units;
-on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x -- MI355X_MICROARCH.md) from rocprofv3 --pmc CSVs."""
+"""Per-kernel HBM traffic from rocprofv3 --pmc passes -> profiles/pmc_traffic_<workload>.json (read by bench.py).
+
+usage: tools/pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv out.json
+
+FETCH_SIZE / WRITE_SIZE are reported in KB.  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE counts 128-B
+requests at 64 B, i.e. it reads exactly HALF of the bytes of a wide (16 B/lane) coalesced read stream; WRITE_SIZE is
+exact.  Kernels whose reads are float4 streams (conv2d staging, channel-last warp taps) are therefore corrected x2
+(`fetch_scale`); kernels with 4-B-per-lane reads (conv3d tile fill) are left uncorrected and marked uncalibrated.
+Also prints the effective clock (GRBM_GUI_ACTIVE / 8 / time) when that counter is present.
+"""
 import collections
 import csv
+import json
+import re
 import sys
 
 
-def short(n):
-    return n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:52]
+def key_of(name):
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    m = re.match(r"conv2d_mfma_v2_kernel<(\d+), (\d+), (\d+), (\d+)", n)
+    if m:
+        return f"conv2d_k{m.group(1)}_nt{m.group(2)}_epi{m.group(4)}", 2.0
+    m = re.match(r"conv2d_mfma_kernel<(\d+), (\d+), (\d+)", n)
+    if m:
+        return f"conv2d_k{m.group(1)}_nt{m.group(2)}_epi{m.group(3)}", 1.0
+    m = re.match(r"conv2d_cout1_k3_kernel<(\d+)", n)
+    if m:
+        return f"conv2d_k3_nt1_epi{m.group(1)}", 1.0
+    m = re.match(r"conv3d_k3_kernel<(\d+), (\d+), (\d+)", n)
+    if m:
+        return f"conv3d_c{m.group(1)}_s{m.group(2)}{m.group(3)}", 1.0
+    m = re.match(r"deconv3d_k3_kernel<(\d+), (\d+)", n)
+    if m:
+        return f"deconv3d_c{1 if m.group(1) == '1' else 8}_s{m.group(2)}", 1.0
+    m = re.match(r"warpcorr_(views|dyn)_kernel<(\d+)", n)
+    if m:
+        return f"warpcorr_{m.group(1)}_c{m.group(2)}", 2.0
+    return None, 1.0
 
 
-for f in sys.argv[1:]:
-    rows = list(csv.DictReader(open(f)))
+def collect(path):
     per = collections.defaultdict(lambda: collections.defaultdict(float))
-    cnt = collections.defaultdict(set)
+    disp = collections.defaultdict(set)
     dur = collections.defaultdict(float)
-    for r in rows:
-        k = short(r["Kernel_Name"])
-        if not any(s in k for s in ("conv2d", "conv3d", "warpcorr", "deconv", "getcost", "planar", "lookup", "softmax", "pixelwise", "split", "upsample", "aggregate")):
+    for r in csv.DictReader(open(path)):
+        k, scale = key_of(r["Kernel_Name"])
+        if k is None:
             continue
         per[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        if r["Dispatch_Id"] not in cnt[k]:
-            cnt[k].add(r["Dispatch_Id"])
+        per[k]["_scale"] = scale
+        if r["Dispatch_Id"] not in disp[k]:
+            disp[k].add(r["Dispatch_Id"])
             dur[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
-    print(f)
-    for k, v in sorted(per.items(), key=lambda kv: -dur[kv[0]])[:26]:
-        n = len(cnt[k])
-        us = dur[k] / n / 1e3
-        s = f"{k:54s} n={n:3d} {us:8.1f} us "
-        for c, val in v.items():
-            val /= n
-            if c == "GRBM_GUI_ACTIVE":
-                s += f" clk={val / 8 / us / 1e3:5.2f}GHz"
-            elif c in ("FETCH_SIZE", "WRITE_SIZE"):
-                s += f" {c}={val / 1024:8.1f}MB"
-            else:
-                s += f" {c}={val:10.3g}"
-        print(s)
+    return per, disp, dur
+
+
+def main(fetch_csv, write_csv, out_json):
+    pf, df, tf = collect(fetch_csv)
+    pw, dw, _ = collect(write_csv)
+    out = {}
+    for k in sorted(pf, key=lambda k: -tf[k]):
+        n = len(df[k])
+        raw = pf[k]["FETCH_SIZE"] * 1024.0 / n
+        scale = pf[k]["_scale"]
+        wr = pw[k]["WRITE_SIZE"] * 1024.0 / max(len(dw[k]), 1) if k in pw else 0.0
+        us = tf[k] / n / 1e3
+        clk = pf[k].get("GRBM_GUI_ACTIVE", 0.0) / n / 8 / us / 1e3 if us else 0.0
+        hit = pw[k].get("TCC_HIT_sum", 0.0)
+        miss = pw[k].get("TCC_MISS_sum", 0.0)
+        out[k] = {"launches_profiled": n, "avg_launch_us_profiled": us, "fetch_bytes_raw": raw, "fetch_scale": scale,
+                  "fetch_bytes": raw * scale, "write_bytes": wr, "calibrated": scale == 2.0,
+                  "l2_hit_rate": hit / (hit + miss) if hit + miss else None}
+        print(f"{k:24s} n={n:3d} {us:8.1f} us  fetch {raw * scale / 1e6:8.1f} MB (raw {raw / 1e6:7.1f}) write {wr / 1e6:7.1f} MB"
+              f"  L2 hit {100 * (hit / (hit + miss) if hit + miss else 0):5.1f}%  clk~{clk:4.2f} GHz")
+    with open(out_json, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
