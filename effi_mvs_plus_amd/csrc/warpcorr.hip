@@ -34,6 +34,26 @@ struct Taps {
     int off[4];   // element offsets of the 4 taps' pixel (already multiplied by C)
 };
 
+// Lanes of one pixel share the per-hypothesis set-up (projection, two divisions, bilinear weights): lane j of
+// every aligned group of G = min(lanes-per-pixel, 4) lanes computes hypothesis d0 + j, and the 8 results are
+// broadcast inside the quad with quad_perm DPP moves (full-rate VALU, no LDS).  For C = 32 the two quads of a
+// pixel do this redundantly (2x instead of 8x), for C = 8 a quad holds two pixels and G = 2.
+template <int G, int J>
+__device__ __forceinline__ int quad_bcast_i(int v) {
+    // source lane inside the quad for destination lanes 0..3
+    constexpr int s0 = J, s1 = J, s2 = (G == 4) ? J : 2 + J, s3 = (G == 4) ? J : 2 + J;
+    constexpr int ctrl = s0 | (s1 << 2) | (s2 << 4) | (s3 << 6);
+    return __builtin_amdgcn_update_dpp(0, v, ctrl, 0xF, 0xF, true);
+}
+template <int G, int J>
+__device__ __forceinline__ void taps_bcast(const Taps& mine, Taps& out) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        out.w[k] = __int_as_float(quad_bcast_i<G, J>(__float_as_int(mine.w[k])));
+        out.off[k] = quad_bcast_i<G, J>(mine.off[k]);
+    }
+}
+
 // (X, Y, Z) in the source camera -> 4 bilinear taps (weights zeroed when out of bounds).
 __device__ __forceinline__ void make_taps(float X, float Y, float Z, int W, int H, int C, Taps& t) {
     if (Z == 0.0f) Z = Z + 1e-8f;                                   // models/module.py:328-329
@@ -119,14 +139,32 @@ __global__ __launch_bounds__(256) void warpcorr_views_kernel(const float* __rest
     float* simv = sim_views + (long)view * D * hw + pix;
     const float* dp = depth + (long)pix * dps;
     float m = -INFINITY;
-#pragma unroll 2
-    for (int d = 0; d < D; ++d) {
-        const float dep = dp[d * dds];
+    constexpr int GS = (G::LPP >= 4) ? 4 : 2;                    // lanes sharing the set-up
+    const int gj = threadIdx.x % GS;
+    for (int d0 = 0; d0 < D; d0 += GS) {
+        // this lane's hypothesis (clamped: the tail group recomputes the last one and discards it)
+        const int dm = min(d0 + gj, D - 1);
+        const float dep = dp[dm * dds];
+        Taps mine;
+        make_taps(rx * dep + tx, ry * dep + ty, rz * dep + tz, w, h, C, mine);     // module.py:325-327
+        auto one = [&](const Taps& t, int d) {
+            const float s = effi_group_sum<G::LPP>(sample_dot(src, t, sub4, r4)) / (float)C;   // mean over C, :40
+            if (d < D) {
+                if ((d % G::LPP) == sub) simv[(long)d * hw] = s;
+                m = fmaxf(m, s);
+            }
+        };
         Taps t;
-        make_taps(rx * dep + tx, ry * dep + ty, rz * dep + tz, w, h, C, t);     // module.py:325-327
-        const float s = effi_group_sum<G::LPP>(sample_dot(src, t, sub4, r4)) / (float)C;   // mean over C, :40
-        if ((d % G::LPP) == sub) simv[(long)d * hw] = s;
-        m = fmaxf(m, s);
+        taps_bcast<GS, 0>(mine, t);
+        one(t, d0);
+        taps_bcast<GS, 1>(mine, t);
+        one(t, d0 + 1);
+        if (GS == 4) {
+            taps_bcast<GS, 2>(mine, t);
+            one(t, d0 + 2);
+            taps_bcast<GS, 3>(mine, t);
+            one(t, d0 + 3);
+        }
     }
     // softmax over D and entropy (models/Effi_MVS_plus.py:43-44); lane `sub` owns d = sub, sub+LPP, ...
     float z = 0.0f;
@@ -170,25 +208,44 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* __restri
     float wsum = 0.0f;
     for (int v = 0; v < S; ++v) wsum = wsum + view_w[(long)v * vh * vw + vpix];
     const float den = wsum + 1e-6f;
-    for (int d = 0; d < D; ++d) {
-        const float s_inv = fmaxf(smin + (float)d * step, 1e-5f);
-        const float dep = 1.0f / s_inv;
-        float acc = 0.0f;
+    constexpr int GS = (G::LPP >= 4) ? 4 : 2;
+    const int gj = threadIdx.x % GS;
+    for (int d0 = 0; d0 < D; d0 += GS) {
+        const int dm = min(d0 + gj, D - 1);
+        const float my_dep = 1.0f / fmaxf(smin + (float)dm * step, 1e-5f);
+        float acc[GS];
+#pragma unroll
+        for (int j = 0; j < GS; ++j) acc[j] = 0.0f;
         for (int v = 0; v < S; ++v) {
             const float* __restrict__ src = pick_view(srcs, v);
             const float* __restrict__ rt = rt_all + v * 12;
             const float rx = rt[0] * fx + rt[1] * fy + rt[2];
             const float ry = rt[3] * fx + rt[4] * fy + rt[5];
             const float rz = rt[6] * fx + rt[7] * fy + rt[8];
-            Taps t;
-            make_taps(rx * dep + rt[9], ry * dep + rt[10], rz * dep + rt[11], w, h, C, t);
+            Taps mine, t;
+            make_taps(rx * my_dep + rt[9], ry * my_dep + rt[10], rz * my_dep + rt[11], w, h, C, mine);
             const float wv = view_w[(long)v * vh * vw + vpix];
-            acc = fmaf(wv, sample_dot(src, t, sub4, r4), acc);
+            taps_bcast<GS, 0>(mine, t);
+            acc[0] = fmaf(wv, sample_dot(src, t, sub4, r4), acc[0]);
+            taps_bcast<GS, 1>(mine, t);
+            acc[1] = fmaf(wv, sample_dot(src, t, sub4, r4), acc[1]);
+            if (GS == 4) {
+                taps_bcast<GS, 2>(mine, t);
+                acc[2] = fmaf(wv, sample_dot(src, t, sub4, r4), acc[2]);
+                taps_bcast<GS, 3>(mine, t);
+                acc[3] = fmaf(wv, sample_dot(src, t, sub4, r4), acc[3]);
+            }
         }
-        const float total = (effi_group_sum<G::LPP>(acc) / (float)C) / den;
-        if ((d % G::LPP) == sub) {
-            sim[(long)d * hw + pix] = total;
-            samples[(long)d * hw + pix] = dep;
+#pragma unroll
+        for (int j = 0; j < GS; ++j) {
+            const int d = d0 + j;
+            const float total = (effi_group_sum<G::LPP>(acc[j]) / (float)C) / den;
+            // every lane recomputes the hypothesis value of d (two ops) so that the owner lane can store it
+            const float dep_d = 1.0f / fmaxf(smin + (float)min(d, D - 1) * step, 1e-5f);
+            if (d < D && (d % G::LPP) == sub) {
+                sim[(long)d * hw + pix] = total;
+                samples[(long)d * hw + pix] = dep_d;
+            }
         }
     }
 }
