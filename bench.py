@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--torch-baseline-views", type=int, default=3,
                     help="also time the reference-style composite PyTorch-ROCm path (the oracle's op sequence run on the GPU); 0 = skip")
     ap.add_argument("--profile-key", default=None, help="kernel key to bracket with events (default: auto = largest total time)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1: nccl (= RCCL over xGMI, the real path) or gloo (rehearsal of the "
+                         "multi-rank plumbing on a box with fewer GPUs than ranks; ranks then share devices)")
     args = ap.parse_args()
 
     import torch
@@ -56,11 +59,18 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     distributed = world > 1
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if distributed and args.backend == "nccl" and ndev < world:
+        raise SystemExit(f"{world} ranks need {world} GPUs for the RCCL path (found {ndev}); use --backend gloo to rehearse")
+    dev_index = local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend="gloo")
 
     from common import build_model
     from effi_mvs_plus_amd import _lib, ops, shard, synth
@@ -115,13 +125,14 @@ def main():
             confs.append(out["photometric_confidence"])
         if distributed:
             # the path's only collective: ONE RCCL gather per tensor of this rank's finished maps to rank 0
-            shard.gather_maps(torch.cat(finals), args.steps * world, dst=0)
-            shard.gather_maps(torch.cat(confs), args.steps * world, dst=0)
+            to = (lambda t_: t_) if args.backend == "nccl" else (lambda t_: t_.cpu())   # gloo gathers host tensors
+            shard.gather_maps(to(torch.cat(finals)), args.steps * world, dst=0)
+            shard.gather_maps(to(torch.cat(confs)), args.steps * world, dst=0)
         barrier()
         dt = time.perf_counter() - t0
         ops.set_profile(None)
     if distributed:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ksum = prof.summary()[key]
@@ -163,8 +174,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: DTU-shaped {W}x{H}, N={N} views (S={N - 1} sources), 3-stage cascade "
                                    f"ndepths={nd}, GRU iters 3,3,3, seeded-random weights, features of the stock FPN resident in HBM",
-                       "parallelism": f"view-sharded x{world}, RCCL gather of depth+confidence to rank 0 inside the timed region"
-                       if world > 1 else "single GPU"},
+                       "parallelism": f"view-sharded x{world}, {'RCCL' if args.backend == 'nccl' else 'gloo (rehearsal)'} gather of "
+                                      f"depth+confidence to rank 0 inside the timed region" if world > 1 else "single GPU"},
             "roofline": roof,
             "kernel_breakdown_ms": {k: round(v["ms"], 4) for k, v in sorted(disc.items(), key=lambda kv: -kv[1]["ms"])},
         }

@@ -32,6 +32,11 @@ struct Conv2dArgs {
     int n_range;
     float* out0;
     float* out1;
+    // z-batched use (3-D convolution as per-plane 2-D convolutions, effi_conv3d_k3s1_mfma_f32): blockIdx.y = z,
+    // source s is plane z + s - 1 of the SAME [cin][D][h][w] tensor (zero when outside), channel strides are D*h*w
+    long cstride;            // input channel stride in floats (h*w for plain 2-D)
+    long ostride;            // output channel stride
+    int zcount;              // D when z-batched, else 0
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(const Conv2dArgs a) {
 //   * the k-steps of a chunk are fully unrolled with double-buffered fragments.
 //   * MR = rows per wave (1, 2 or 4): small images use small MR so the grid still covers the 256 CUs.
 // ------------------------------------------------------------------------------------------------
-template <int KS, int NT, int MR, int EPI, int CC, bool PERSIST>
+template <int KS, int NT, int MR, int EPI, int CC, bool PERSIST, bool ALIGNED = true>
 __global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a, int tiles_x, int ntiles) {
     constexpr int R = KS / 2, TR = 4 * MR, AR = TR + 2 * R;
     constexpr int AW = (KS == 3) ? 24 : 16, AQ = AW / 4, XOFF = (KS == 3) ? 3 : 0, XLEFT = (KS == 3) ? 4 : 0;
@@ -223,6 +228,7 @@ __global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a,
     const int li = lane & 15, lk = lane >> 4;
     const int h = a.h, w = a.w;
     const long hw = (long)h * w;
+    const int zpl = a.zcount ? (int)blockIdx.y : 0;              // plane of a z-batched launch
     // XCD-aware tile order (non-persistent launches): workgroups are dealt round-robin to the 8 XCDs, so
     // logical tiles are assigned such that each XCD owns a contiguous run of tiles -- x/y-neighbouring tiles,
     // whose halo rows share cache lines, then hit the same L2 instead of re-fetching over the fabric.
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a,
     // this thread's float4 elements; the offset depends on the tile and is refreshed by setup().  Channel /
     // row / column are re-derived from the element index where needed (a few integer ops) rather than
     // kept in registers.
-    int a_lds[NA4], a_off[NA4];
+    int a_lds[NA4], a_off[NA4], a_gx[ALIGNED ? 1 : NA4];
 #pragma unroll
     for (int j = 0; j < NA4; ++j) {
         const int f = min(tid + j * 256, NA - 1);
@@ -252,7 +258,11 @@ __global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a,
             const int r = f % (AR * AQ);
             const int row = r / AQ;
             const int gy = y0 - R + row, gx = x0 - XLEFT + 4 * (r - row * AQ);
-            a_off[j] = ((tid + j * 256 < NA) & (gy >= 0) & (gy < h) & (gx >= 0) & (gx < w)) ? gy * w + gx : -1;
+            // ALIGNED (w % 4 == 0): a float4 is entirely inside or outside the row.  Otherwise the segment may
+            // straddle the row end; it is then fetched component-wise (prefetch) and a_off only says "row exists"
+            const bool xin = ALIGNED ? ((gx >= 0) & (gx < w)) : ((gx + 3 >= 0) & (gx < w));
+            a_off[j] = ((tid + j * 256 < NA) & (gy >= 0) & (gy < h) & xin) ? gy * w + gx : -1;
+            if (!ALIGNED) a_gx[j] = gx;
         }
     };
 
@@ -265,15 +275,33 @@ __global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a,
 #pragma unroll
         for (int j = 0; j < NA4; ++j) {
             int cg = ch * CC + min(tid + j * 256, NA - 1) / (AR * AQ);
-            const bool ok = (a_off[j] >= 0) & (cg < a.cin);
-            const float* p = a.src[0];
+            bool ok = (a_off[j] >= 0) & (cg < a.cin);
+            int srci = 0;
             if (cg >= a.ch[0]) {
                 cg -= a.ch[0];
-                p = a.src[1];
-                if (cg >= a.ch[1]) { cg -= a.ch[1]; p = a.src[2]; }
+                srci = 1;
+                if (cg >= a.ch[1]) { cg -= a.ch[1]; srci = 2; }
             }
-            const float4 t = *reinterpret_cast<const float4*>(ok ? p + (long)cg * hw + a_off[j] : a.wpack);
-            pa[j] = ok ? t : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const float* p = (srci == 0) ? a.src[0] : (srci == 1 ? a.src[1] : a.src[2]);
+            if (a.zcount) {                                   // source s = plane z + s - 1
+                const int zz = zpl + srci - 1;
+                ok &= (zz >= 0) & (zz < a.zcount);
+                p += (long)max(min(zz, a.zcount - 1), 0) * hw;
+            }
+            if (ALIGNED) {
+                const float4 t = *reinterpret_cast<const float4*>(ok ? p + (long)cg * a.cstride + a_off[j] : a.wpack);
+                pa[j] = ok ? t : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            } else {
+                const float* q = p + (long)cg * a.cstride + a_off[j];
+                float e[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool eok = ok & (a_gx[j] + i >= 0) & (a_gx[j] + i < w);
+                    const float t = *(eok ? q + i : a.wpack);
+                    e[i] = eok ? t : 0.0f;
+                }
+                pa[j] = make_float4(e[0], e[1], e[2], e[3]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < NB4; ++j) {
@@ -368,7 +396,13 @@ __global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a,
                 if (EPI == EFFI_EPI_PLAIN) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], a.act);
-                    dst = a.out0 + (long)co * hw + pix;
+                    dst = a.out0 + (long)co * a.ostride + (long)zpl * hw + pix;
+                    if (!ALIGNED) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (x + r < w) dst[r] = v[r];
+                        continue;
+                    }
                 } else if (EPI == EFFI_EPI_GRU_ZR) {
                     if (co < a.hd) {
 #pragma unroll
@@ -591,6 +625,53 @@ int dispatch_nt(const Conv2dArgs& a, int nt, hipStream_t st) {
 
 }  // namespace
 
+// ---- 3-D convolution (k3, stride 1, pad 1) as z-batched 2-D convolutions on the matrix cores -----------------
+template <int NT, int MR, bool ALIGNED>
+static int launch3d_planes(const Conv2dArgs& a, hipStream_t st) {
+    const int tiles_x = effi_cdiv(a.w, 16), ntiles = tiles_x * effi_cdiv(a.h, 4 * MR);
+    hipLaunchKernelGGL((conv2d_mfma_v2_kernel<3, NT, MR, EFFI_EPI_PLAIN, 8, false, ALIGNED>), dim3(ntiles, a.zcount), dim3(256), 0, st,
+                       a, tiles_x, ntiles);
+    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+}
+
+template <int NT>
+static int dispatch3d_planes(const Conv2dArgs& a, hipStream_t st) {
+    const long cols = effi_cdiv(a.w, 16);
+    const bool al = (a.w & 3) == 0;
+    // rows per wave: keep >= 2 workgroups per CU over all planes
+    if (cols * effi_cdiv(a.h, 16) * a.zcount >= 512) return al ? launch3d_planes<NT, 4, true>(a, st) : launch3d_planes<NT, 4, false>(a, st);
+    if (cols * effi_cdiv(a.h, 8) * a.zcount >= 512) return al ? launch3d_planes<NT, 2, true>(a, st) : launch3d_planes<NT, 2, false>(a, st);
+    return al ? launch3d_planes<NT, 1, true>(a, st) : launch3d_planes<NT, 1, false>(a, st);
+}
+
+extern "C" int effi_conv3d_k3s1_mfma_f32(const float* in, int cin, const float* wpack, const float* bias, int cout, int D,
+                                         int h, int w, int relu, float* out, effi_stream_t stream) {
+    if (!in || !wpack || !bias || !out || cin < 1 || D < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    if (cout != 16 && cout != 32) return EFFI_ERR_UNSUPPORTED;
+    Conv2dArgs a;
+    for (int i = 0; i < EFFI_MAX_SRC; ++i) {       // source s = plane z + s - 1 of the same tensor
+        a.src[i] = in;
+        a.ch[i] = cin;
+    }
+    a.cin = 3 * cin;
+    a.kgroups = (a.cin + 3) / 4;
+    a.wpack = wpack;
+    a.bias = bias;
+    a.cout = cout;
+    a.h = h;
+    a.w = w;
+    a.act = relu ? EFFI_ACT_RELU : EFFI_ACT_NONE;
+    a.hd = 0;
+    a.aux0 = a.aux1 = a.disp_range = nullptr;
+    a.n_range = 0;
+    a.out0 = out;
+    a.out1 = nullptr;
+    a.cstride = (long)D * h * w;
+    a.ostride = (long)D * h * w;
+    a.zcount = D;
+    return cout == 16 ? dispatch3d_planes<1>(a, effi_s(stream)) : dispatch3d_planes<2>(a, effi_s(stream));
+}
+
 extern "C" int effi_conv2d_f32(const float* const* srcs, const int* src_channels, int n_src, const float* wpack,
                                const float* bias, int cout, int ks, int h, int w, int epilogue, int act,
                                const float* aux0, const float* aux1, const float* disp_range, int n_range,
@@ -619,6 +700,9 @@ extern "C" int effi_conv2d_f32(const float* const* srcs, const int* src_channels
     a.n_range = n_range;
     a.out0 = out0;
     a.out1 = out1;
+    a.cstride = (long)h * w;
+    a.ostride = (long)h * w;
+    a.zcount = 0;
     const int nt = (cout + 15) / 16;
     hipStream_t st = effi_s(stream);
     if (cout == 1 && ks == 3 && (long)h * w >= 262144 && (epilogue == EFFI_EPI_PLAIN || epilogue == EFFI_EPI_HEAD)) {

@@ -51,6 +51,7 @@ class Conv3d(nn.Module):
         self.bn = nn.BatchNorm3d(out_channels, momentum=bn_momentum) if bn else None
         self.relu = relu
         self._cache = packing.PackCache()
+        self._cache_planes = packing.PackCache()
 
     def _packed(self):
         t = [self.conv.weight, self.conv.bias]
@@ -63,6 +64,14 @@ class Conv3d(nn.Module):
         _require_eval(self)
         if _triple(self.conv.kernel_size) != (3, 3, 3) or _triple(self.conv.padding) != (1, 1, 1):
             raise NotImplementedError("Conv3d: only kernel 3 / padding 1 is instantiated on the HIP path")
+        if (len(srcs) == 1 and skip is None and _triple(self.conv.stride) == (1, 1, 1) and self.out_channels in (16, 32)
+                and self.conv.in_channels >= 8):
+            # low-resolution U-Net levels: z-batched 2-D convolutions on the matrix cores
+            t = [self.conv.weight, self.conv.bias]
+            if self.bn is not None:
+                t += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
+            wp, bp = self._cache_planes.get(t, lambda: packing.pack_conv3d_planes(self.conv, self.bn))
+            return ops.conv3d_k3s1_mfma(srcs[0], wp, bp, self.out_channels, relu=self.relu)
         w, b = self._packed()
         return ops.conv3d_k3(srcs, w, b, self.out_channels, stride=_triple(self.conv.stride), relu=self.relu, skip=skip)
 

@@ -233,6 +233,17 @@ def conv3d_k3(srcs, weight, bias, cout, stride=(1, 1, 1), relu=True, skip=None):
     return out
 
 
+def conv3d_k3s1_mfma(x, wpack, bias, cout, relu=True):
+    """x planar [cin,D,h,w]; stride-1 3-D conv as z-batched 2-D MFMA convs -> [cout,D,h,w]."""
+    _t(x, "conv3d input")
+    cin, D, h, w = x.shape
+    out = torch.empty(cout, D, h, w, device=x.device, dtype=torch.float32)
+    work = lambda: {"flops": 2.0 * 27 * cin * cout * D * h * w, "bytes": 4.0 * (cin + cout) * D * h * w}
+    check(_call(f"conv3d_mfma_nt{cout // 16}", work, _lib.lib().effi_conv3d_k3s1_mfma_f32, _p(x), cin, _p(wpack), _p(bias), cout,
+                D, h, w, int(relu), _p(out), _stream()), "effi_conv3d_k3s1_mfma_f32")
+    return out
+
+
 def deconv3d_k3(x, weight, bias, cout, sz=2, relu=True, skip=None):
     _t(x, "deconv3d input")
     cin, D, h, w = x.shape

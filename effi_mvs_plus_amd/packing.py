@@ -50,6 +50,20 @@ def pack_conv3d(conv, bn):
     return wp, (None if bias is None else bias.contiguous().float())
 
 
+def pack_conv3d_planes(conv, bn):
+    """nn.Conv3d [cout,cin,3,3,3] (+BN) for the z-batched matrix-core path: the 3-D conv of output plane z is a 2-D
+    conv over cat(plane z-1, z, z+1), i.e. weight [cout][kd*cin+ci][ky][kx] in MFMA packing; bias [16*NT]."""
+    w = conv.weight
+    bias = conv.bias
+    if bn is not None:
+        scale, shift = bn_scale_shift(bn)
+        w = w * scale.view(-1, 1, 1, 1, 1)
+        bias = shift if bias is None else bias * scale + shift
+    cout, cin = w.shape[0], w.shape[1]
+    w2 = w.permute(0, 2, 1, 3, 4).reshape(cout, 3 * cin, 3, 3)
+    return pack_conv2d_mfma(w2, bias)
+
+
 def pack_deconv3d(conv, bn):
     """nn.ConvTranspose3d [cin,cout,3,3,3] (+BN) -> (weight [cin,27,cout], bias [cout] or None)."""
     w = conv.weight

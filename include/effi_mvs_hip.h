@@ -107,6 +107,12 @@ int effi_conv3d_k3_f32(const float* const* srcs, const int* src_channels, int n_
                        const float* weight, const float* bias, int cout,
                        int D, int h, int w, int sz, int sxy, int relu, const float* skip,
                        float* out, effi_stream_t stream);
+/* Same operator for the low-resolution levels of the regulariser (cout in {16,32}, stride 1): every output plane z is
+ * a 2-D convolution over the channel-concatenated planes z-1, z, z+1 and runs on the fp32 matrix cores
+ * (models/module.py:443,446).  in planar [cin][D][h][w]; wpack = MFMA packing (see effi_conv2d_f32) of the weight viewed
+ * as [cout][3*cin][3][3] with input channel index kd*cin + ci; bias [cout]; out planar [cout][D][h][w]. */
+int effi_conv3d_k3s1_mfma_f32(const float* in, int cin, const float* wpack, const float* bias, int cout,
+                              int D, int h, int w, int relu, float* out, effi_stream_t stream);
 /* Transposed 3-D convolution, kernel 3, padding 1, stride (sz,2,2), output_padding (sz-1,1,1):
  * out dims (sz*D, 2h, 2w).  models/module.py:448-450 (sz=2), :508 (sz=1).
  * in planar [cin][D][h][w]; weight [cin][kd][ky][kx][cout] (host-packed from torch's

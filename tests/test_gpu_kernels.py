@@ -173,7 +173,10 @@ def _rand_bn(bn, g):
 @pytest.mark.parametrize("cin,cout,stride,dims", [
     (1, 8, 1, (8, 16, 20)), (8, 8, 1, (12, 18, 44)), (16, 16, 1, (6, 9, 35)), (32, 32, 1, (3, 10, 13)),
     (8, 16, 2, (12, 20, 36)), (16, 32, 2, (6, 10, 18)), (8, 16, 2, (8, 14, 70)), (1, 8, (1, 2, 2), (8, 24, 40)),
-    (1, 8, (1, 2, 2), (5, 18, 66))])
+    (1, 8, (1, 2, 2), (5, 18, 66)),
+    # matrix-core path (cout 16/32, stride 1): aligned and unaligned rows, every rows-per-wave variant, real U-Net shapes
+    (16, 16, 1, (6, 12, 40)), (32, 32, 1, (4, 8, 52)), (16, 16, 1, (24, 74, 100)), (32, 32, 1, (12, 37, 50)),
+    (16, 16, 1, (48, 40, 64))])
 def test_conv3d_block(cin, cout, stride, dims):
     from effi_mvs_plus_amd.models.module import Conv3d
     g = torch.Generator().manual_seed(cin * 100 + cout)

@@ -98,6 +98,41 @@ def test_cascade_vs_oracle_large_tiles():
     assert (out["photometric_confidence"].cpu() - want["photometric_confidence"]).abs().mean() <= 1e-3
 
 
+def test_batch_of_two_and_48_32_8_cascade():
+    """B = 2 (the host loops over the batch) and BASELINE.json's 48/32/8 hypothesis counts."""
+    from oracle import effi_oracle as O
+    net, sd = build_model("48,32,8", seed=4, device=DEV)
+    a = synth.synth_sample(128, 192, 3, seed=21)
+    b = synth.synth_sample(128, 192, 3, seed=22)
+    imgs = torch.cat([a[0], b[0]])
+    pm = {k: torch.cat([a[1][k], a[1][k]]) for k in a[1]}
+    dv = torch.cat([a[2], a[2] * 1.1])                       # different depth ranges per sample
+    feats, ctx = _features_on_cpu(sd, imgs)
+    with torch.no_grad():
+        want = O.hot_path(sd, feats, ctx, pm, dv, ndepths=(48, 32, 8))
+        out = net.forward_hot([{k: t(v, DEV) for k, v in f.items()} for f in feats], {k: t(v, DEV) for k, v in ctx.items()},
+                              {k: t(v, DEV) for k, v in pm.items()}, t(dv, DEV))
+    assert out["depth"][-1].shape == (2, 128, 192) and out["photometric_confidence"].shape == (2, 64, 96)
+    for i, d in enumerate(out["depth"]):
+        mean, p99, _ = _norm_err(d, want["depth"][i])
+        assert mean <= 1e-3 and p99 <= 5e-3, (i, mean, p99)
+
+
+def test_tanks_and_temples_shaped_cascade():
+    """cfg4-like: 6 source views, 96 first-stage hypotheses (test_tank.sh:14-15), reduced resolution."""
+    from oracle import effi_oracle as O
+    net, sd = build_model("96,8,8", seed=6, device=DEV)
+    imgs, pm, dv = synth.synth_sample(160, 256, 7, seed=5)
+    feats, ctx = _features_on_cpu(sd, imgs)
+    with torch.no_grad():
+        want = O.hot_path(sd, feats, ctx, pm, dv, ndepths=(96, 8, 8))
+        out = net.forward_hot([{k: t(v, DEV) for k, v in f.items()} for f in feats], {k: t(v, DEV) for k, v in ctx.items()},
+                              {k: t(v, DEV) for k, v in pm.items()}, t(dv, DEV))
+    for i, d in enumerate(out["depth"]):
+        mean, p99, _ = _norm_err(d, want["depth"][i])
+        assert mean <= 1e-3 and p99 <= 5e-3, (i, mean, p99)
+
+
 def test_full_forward_including_fpn():
     """model(imgs, proj_matrices, depth_values) exactly as the reference's drivers call it
     (test_dtu_dypcd.py:439); FPN runs in stock PyTorch-ROCm, so features differ by MIOpen rounding."""
