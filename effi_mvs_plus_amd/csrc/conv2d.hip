@@ -34,9 +34,10 @@ struct Conv2dArgs {
     float* out1;
     // z-batched use (3-D convolution as per-plane 2-D convolutions, effi_conv3d_k3s1_mfma_f32): blockIdx.y = z,
     // source s is plane z + s - 1 of the SAME [cin][D][h][w] tensor (zero when outside), channel strides are D*h*w
-    long cstride;            // input channel stride in floats (h*w for plain 2-D)
+    long cstride;            // input channel stride in floats (hin*win for plain 2-D)
     long ostride;            // output channel stride
     int zcount;              // D when z-batched, else 0
+    int hin, win;            // input map size (= h, w for stride 1; stride-2 convs read a 2x larger map)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -210,10 +211,14 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(const Conv2dArgs a) {
 //   * the k-steps of a chunk are fully unrolled with double-buffered fragments.
 //   * MR = rows per wave (1, 2 or 4): small images use small MR so the grid still covers the 256 CUs.
 // ------------------------------------------------------------------------------------------------
-template <int KS, int NT, int MR, int EPI, int CC, bool PERSIST, bool ALIGNED = true>
+template <int KS, int NT, int MR, int EPI, int CC, bool PERSIST, bool ALIGNED = true, int S = 1>
 __global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a, int tiles_x, int ntiles) {
-    constexpr int R = KS / 2, TR = 4 * MR, AR = TR + 2 * R;
-    constexpr int AW = (KS == 3) ? 24 : 16, AQ = AW / 4, XOFF = (KS == 3) ? 3 : 0, XLEFT = (KS == 3) ? 4 : 0;
+    // S = stride (1, or 2 for the 5x5 down-sampling convs of the feature pyramid): output tile 16 x TR, input
+    // tile S*(TR-1)+KS rows x S*15+KS columns, fetched from column S*x0 - XLEFT in aligned float4 units.
+    // (For S = 2 the A reads have a 2-lane stride: 2-way bank conflicts, irrelevant at ~1 LDS read per MFMA.)
+    constexpr int R = KS / 2, TR = 4 * MR, AR = S * (TR - 1) + KS;
+    constexpr int XLEFT = (KS == 1) ? 0 : 4, XOFF = XLEFT - R;
+    constexpr int AW = (KS == 1) ? 16 : ((XOFF + S * 15 + KS + 3) / 4) * 4, AQ = AW / 4;
     constexpr int PL0 = AR * AW;
     constexpr int PLA = PL0 + ((16 - (PL0 % 32)) + 32) % 32;          // channel-plane stride == 16 (mod 32)
     constexpr int KG = CC / 4, T = KG * KS * KS;
@@ -226,8 +231,8 @@ __global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a,
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const int h = a.h, w = a.w;
-    const long hw = (long)h * w;
+    const int h = a.h, w = a.w, hin = a.hin, win = a.win;
+    const long hw = (long)h * w, hwin = (long)hin * win;
     const int zpl = a.zcount ? (int)blockIdx.y : 0;              // plane of a z-batched launch
     // XCD-aware tile order (non-persistent launches): workgroups are dealt round-robin to the 8 XCDs, so
     // logical tiles are assigned such that each XCD owns a contiguous run of tiles -- x/y-neighbouring tiles,
@@ -257,11 +262,11 @@ __global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a,
             const int f = min(tid + j * 256, NA - 1);
             const int r = f % (AR * AQ);
             const int row = r / AQ;
-            const int gy = y0 - R + row, gx = x0 - XLEFT + 4 * (r - row * AQ);
-            // ALIGNED (w % 4 == 0): a float4 is entirely inside or outside the row.  Otherwise the segment may
+            const int gy = S * y0 - R + row, gx = S * x0 - XLEFT + 4 * (r - row * AQ);
+            // ALIGNED (win % 4 == 0): a float4 is entirely inside or outside the row.  Otherwise the segment may
             // straddle the row end; it is then fetched component-wise (prefetch) and a_off only says "row exists"
-            const bool xin = ALIGNED ? ((gx >= 0) & (gx < w)) : ((gx + 3 >= 0) & (gx < w));
-            a_off[j] = ((tid + j * 256 < NA) & (gy >= 0) & (gy < h) & xin) ? gy * w + gx : -1;
+            const bool xin = ALIGNED ? ((gx >= 0) & (gx < win)) : ((gx + 3 >= 0) & (gx < win));
+            a_off[j] = ((tid + j * 256 < NA) & (gy >= 0) & (gy < hin) & xin) ? gy * win + gx : -1;
             if (!ALIGNED) a_gx[j] = gx;
         }
     };
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a,
             if (a.zcount) {                                   // source s = plane z + s - 1
                 const int zz = zpl + srci - 1;
                 ok &= (zz >= 0) & (zz < a.zcount);
-                p += (long)max(min(zz, a.zcount - 1), 0) * hw;
+                p += (long)max(min(zz, a.zcount - 1), 0) * hwin;
             }
             if (ALIGNED) {
                 const float4 t = *reinterpret_cast<const float4*>(ok ? p + (long)cg * a.cstride + a_off[j] : a.wpack);
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a,
                 float e[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const bool eok = ok & (a_gx[j] + i >= 0) & (a_gx[j] + i < w);
+                    const bool eok = ok & (a_gx[j] + i >= 0) & (a_gx[j] + i < win);
                     const float t = *(eok ? q + i : a.wpack);
                     e[i] = eok ? t : 0.0f;
                 }
@@ -325,7 +330,7 @@ __global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a,
     prefetch(0);
     stash();
     __syncthreads();
-    const float* ab = &lds_a[lk * PLA + (wv * MR) * AW + li + XOFF];
+    const float* ab = &lds_a[lk * PLA + (S * wv * MR) * AW + S * li + XOFF];
     const float* bb = &lds_b[lane];
     float lo = 0.0f, hi = 0.0f;
     if (EPI == EFFI_EPI_HEAD) { lo = a.disp_range[0]; hi = a.disp_range[a.n_range - 1]; }
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a,
 #pragma unroll
                     for (int n = 0; n < NT; ++n) bf[s][n] = bbk[(tap * NT + n) * 64];
 #pragma unroll
-                    for (int m = 0; m < MR; ++m) af[s][m] = abk[(m + ky) * AW + kx];
+                    for (int m = 0; m < MR; ++m) af[s][m] = abk[(S * m + ky) * AW + kx];
                 };
                 frag(0, 0);
 #pragma unroll
@@ -393,9 +398,17 @@ __global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a,
                 const float b = a.bias[co];
                 float v[4] = {acc[m][n][0] + b, acc[m][n][1] + b, acc[m][n][2] + b, acc[m][n][3] + b};
                 float* dst;
-                if (EPI == EFFI_EPI_PLAIN) {
+                if (EPI == EFFI_EPI_PLAIN || EPI == EFFI_EPI_ADD_UP2) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], a.act);
+                    if (EPI == EFFI_EPI_ADD_UP2) {      // + nearest-upsampled coarser map (two source pixels per float4)
+                        const float* up = a.aux0 + (long)co * ((long)(h >> 1) * (w >> 1)) + (long)(y >> 1) * (w >> 1) + (x >> 1);
+                        const float u0 = up[0], u1 = (x + 2 < w) ? up[1] : 0.0f;
+                        v[0] += u0;
+                        v[1] += u0;
+                        v[2] += u1;
+                        v[3] += u1;
+                    }
                     dst = a.out0 + (long)co * a.ostride + (long)zpl * hw + pix;
                     if (!ALIGNED) {
 #pragma unroll
@@ -669,6 +682,8 @@ extern "C" int effi_conv3d_k3s1_mfma_f32(const float* in, int cin, const float* 
     a.cstride = (long)D * h * w;
     a.ostride = (long)D * h * w;
     a.zcount = D;
+    a.hin = h;
+    a.win = w;
     return cout == 16 ? dispatch3d_planes<1>(a, effi_s(stream)) : dispatch3d_planes<2>(a, effi_s(stream));
 }
 
@@ -703,6 +718,8 @@ extern "C" int effi_conv2d_f32(const float* const* srcs, const int* src_channels
     a.cstride = (long)h * w;
     a.ostride = (long)h * w;
     a.zcount = 0;
+    a.hin = h;
+    a.win = w;
     const int nt = (cout + 15) / 16;
     hipStream_t st = effi_s(stream);
     if (cout == 1 && ks == 3 && (long)h * w >= 262144 && (epilogue == EFFI_EPI_PLAIN || epilogue == EFFI_EPI_HEAD)) {
@@ -722,6 +739,9 @@ extern "C" int effi_conv2d_f32(const float* const* srcs, const int* src_channels
         case EFFI_EPI_PLAIN:
             if (act < EFFI_ACT_NONE || act > EFFI_ACT_TANH) return EFFI_ERR_BADARG;
             return ks == 3 ? dispatch_nt<3, EFFI_EPI_PLAIN>(a, nt, st) : dispatch_nt<1, EFFI_EPI_PLAIN>(a, nt, st);
+        case EFFI_EPI_ADD_UP2:
+            if (ks != 1 || !aux0 || (h & 1) || (w & 3)) return EFFI_ERR_BADARG;
+            return dispatch_nt<1, EFFI_EPI_ADD_UP2>(a, nt, st);
         case EFFI_EPI_GRU_ZR:
             if (ks != 3 || !aux0 || !out1 || (cout % 32) != 0) return EFFI_ERR_BADARG;
             if (nt == 2) return launch2d<3, 2, EFFI_EPI_GRU_ZR>(a, st);
@@ -739,6 +759,59 @@ extern "C" int effi_conv2d_f32(const float* const* srcs, const int* src_channels
             return launch2d<3, 1, EFFI_EPI_HEAD>(a, st);
         default:
             return EFFI_ERR_BADARG;
+    }
+}
+
+// ---- 5x5 stride-2 convolution (feature pyramid down-sampling) ---------------------------------------------------
+template <int NT, int MR, bool ALIGNED>
+static int launch_k5s2(const Conv2dArgs& a, hipStream_t st) {
+    const int tiles_x = effi_cdiv(a.w, 16), ntiles = tiles_x * effi_cdiv(a.h, 4 * MR);
+    hipLaunchKernelGGL((conv2d_mfma_v2_kernel<5, NT, MR, EFFI_EPI_PLAIN, 4, false, ALIGNED, 2>), dim3(ntiles), dim3(256), 0, st, a,
+                       tiles_x, ntiles);
+    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+}
+
+template <int NT>
+static int dispatch_k5s2(const Conv2dArgs& a, hipStream_t st) {
+    const long cols = effi_cdiv(a.w, 16);
+    const bool al = (a.win & 3) == 0 && (a.w & 3) == 0;
+    if (cols * effi_cdiv(a.h, 8) >= 512) return al ? launch_k5s2<NT, 2, true>(a, st) : launch_k5s2<NT, 2, false>(a, st);
+    return al ? launch_k5s2<NT, 1, true>(a, st) : launch_k5s2<NT, 1, false>(a, st);
+}
+
+extern "C" int effi_conv2d_k5s2_f32(const float* in, int cin, const float* wpack, const float* bias, int cout, int hin,
+                                    int win, int act, float* out, effi_stream_t stream) {
+    if (!in || !wpack || !bias || !out || cin < 1 || cout < 1 || hin < 1 || win < 1) return EFFI_ERR_BADARG;
+    if (act < EFFI_ACT_NONE || act > EFFI_ACT_TANH) return EFFI_ERR_BADARG;
+    Conv2dArgs a;
+    for (int i = 0; i < EFFI_MAX_SRC; ++i) {
+        a.src[i] = (i == 0) ? in : nullptr;
+        a.ch[i] = (i == 0) ? cin : 0;
+    }
+    a.cin = cin;
+    a.kgroups = (cin + 3) / 4;
+    a.wpack = wpack;
+    a.bias = bias;
+    a.cout = cout;
+    a.hin = hin;
+    a.win = win;
+    a.h = (hin - 1) / 2 + 1;
+    a.w = (win - 1) / 2 + 1;
+    a.act = act;
+    a.hd = 0;
+    a.aux0 = a.aux1 = a.disp_range = nullptr;
+    a.n_range = 0;
+    a.out0 = out;
+    a.out1 = nullptr;
+    a.cstride = (long)hin * win;
+    a.ostride = (long)a.h * a.w;
+    a.zcount = 0;
+    hipStream_t st = effi_s(stream);
+    switch ((cout + 15) / 16) {
+        case 1: return dispatch_k5s2<1>(a, st);
+        case 2: return dispatch_k5s2<2>(a, st);
+        case 4: return dispatch_k5s2<4>(a, st);
+        default: return EFFI_ERR_UNSUPPORTED;
     }
 }
 

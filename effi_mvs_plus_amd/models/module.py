@@ -153,9 +153,11 @@ class Conv2d(nn.Module):
 
 
 class P_1to8_FeatureNet_Fast(nn.Module):
-    """Feature / context pyramid (reference: models/module.py:346-412).  OUT OF SCOPE for the HIP path
-    (SURVEY.md section 8(f) n1): stock PyTorch-ROCm convolutions, kept only so that the full model is callable
-    with the reference's checkpoints.  Outputs {stage1: 1/8, stage2: 1/4, stage3: 1/2 resolution}."""
+    """Feature / context pyramid (reference: models/module.py:346-412); outputs {stage1: 1/8, stage2: 1/4,
+    stage3: 1/2 resolution}.  First "next" row of the scope table: in eval mode on CUDA
+    tensors every layer runs on the fp32 matrix cores (BatchNorm folded; 3x3 / 5x5-stride-2 / 1x1 implicit-GEMM
+    kernels of csrc/conv2d.hip; the top-down ``upsample + lateral 1x1`` is one fused kernel).  ``forward_torch`` is
+    the stock PyTorch composite of the same layers (training, and the A/B baseline of tools/fpn_time.py)."""
 
     def __init__(self, base_channels=8, in_channel=[8, 16, 32, 64], out_channel=[32, 16, 8], stage_channel=True):
         super().__init__()
@@ -177,8 +179,60 @@ class P_1to8_FeatureNet_Fast(nn.Module):
         self.out2 = nn.Conv2d(c3, o2, 3, padding=1, bias=False)
         self.out3 = nn.Conv2d(c3, o3, 3, padding=1, bias=False)
         self.out_channels = [c3, c1, c0]
+        self._caches = {}
 
-    def forward(self, x):
+    # ---- packed weights (BN folded), cached per layer ------------------------------------------------
+    def _pk(self, name, conv, bn=None):
+        cache = self._caches.setdefault(name, packing.PackCache())
+        t = [conv.weight, conv.bias]
+        if bn is not None:
+            t += [bn.weight, bn.bias, bn.running_mean, bn.running_var]
+
+        def build():
+            w, b = conv.weight, conv.bias
+            if bn is not None:
+                scale, shift = packing.bn_scale_shift(bn)
+                w = w * scale.view(-1, 1, 1, 1)
+                b = shift if b is None else b * scale + shift
+            return packing.pack_conv2d_mfma(w, b)
+
+        return cache.get(t, build)
+
+    def _block(self, name, blk, x):
+        """Conv2d wrapper (conv + BN + ReLU) on the HIP path; 3x3 stride 1 or 5x5 stride 2."""
+        w, b = self._pk(name, blk.conv, blk.bn)
+        act = ops.ACT_RELU if blk.relu else ops.ACT_NONE
+        if blk.conv.kernel_size == (5, 5) and blk.conv.stride == (2, 2) and blk.conv.padding == (2, 2):
+            return ops.conv2d_k5s2(x, w, b, blk.conv.out_channels, act=act)
+        if blk.conv.kernel_size == (3, 3) and blk.conv.stride == (1, 1) and blk.conv.padding == (1, 1):
+            return ops.conv2d([x], w, b, blk.conv.out_channels, 3, act=act)
+        raise NotImplementedError("feature pyramid: only 3x3/s1/p1 and 5x5/s2/p2 blocks are instantiated on the HIP path")
+
+    def run(self, img):
+        """img planar [3,H,W] (H, W multiples of 8, W/2 multiple of 4) -> {stageK: [C,h,w]}."""
+        _require_eval(self)
+        x = img
+        for i, blk in enumerate(self.conv0):
+            x = self._block(f"conv0.{i}", blk, x)
+        levels = []
+        for lname in ("conv1", "conv2", "conv3"):
+            for i, blk in enumerate(getattr(self, lname)):
+                x = self._block(f"{lname}.{i}", blk, x)
+            levels.append(x)
+        l1, l2, top = levels
+        w, b = self._pk("out1", self.out1)
+        out = {"stage1": ops.conv2d([top], w, b, self.out1.out_channels, 1)}
+        w, b = self._pk("inner1", self.inner1)       # lateral 1x1 + nearest-upsampled coarser map, one kernel
+        top = ops.conv2d([l2], w, b, self.inner1.out_channels, 1, epilogue=ops.EPI_ADD_UP2, aux0=top)
+        w, b = self._pk("out2", self.out2)
+        out["stage2"] = ops.conv2d([top], w, b, self.out2.out_channels, 3)
+        w, b = self._pk("inner2", self.inner2)
+        top = ops.conv2d([l1], w, b, self.inner2.out_channels, 1, epilogue=ops.EPI_ADD_UP2, aux0=top)
+        w, b = self._pk("out3", self.out3)
+        out["stage3"] = ops.conv2d([top], w, b, self.out3.out_channels, 3)
+        return out
+
+    def forward_torch(self, x):
         l1 = self.conv1(self.conv0(x))
         l2 = self.conv2(l1)
         top = self.conv3(l2)
@@ -188,6 +242,12 @@ class P_1to8_FeatureNet_Fast(nn.Module):
         top = F.interpolate(top, scale_factor=2, mode="nearest") + self.inner2(l1)
         outputs["stage3"] = self.out3(top)
         return outputs
+
+    def forward(self, x):
+        if self.training:
+            return self.forward_torch(x)
+        outs = [self.run(x[i].contiguous()) for i in range(x.shape[0])]
+        return {k: _stack([o[k] for o in outs]) for k in outs[0]}
 
 
 # =============================================================================================

@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import EffiLibraryError, check
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
-EPI_PLAIN, EPI_GRU_ZR, EPI_GRU_Q, EPI_HEAD = 0, 1, 2, 3
+EPI_PLAIN, EPI_GRU_ZR, EPI_GRU_Q, EPI_HEAD, EPI_ADD_UP2 = 0, 1, 2, 3, 4
 MAX_VIEWS = 12
 
 
@@ -354,6 +354,18 @@ def conv2d(srcs, wpack, bias, cout, ks, epilogue=EPI_PLAIN, act=ACT_NONE, aux0=N
                 _int_array([s.shape[0] for s in srcs]), len(srcs), _p(wpack), _p(bias), cout, ks, h, w, epilogue, act,
                 _p(aux0), _p(aux1), _p(disp_range), n_range, _p(out0), _p(out1), _stream()), "effi_conv2d_f32")
     return (out0, out1) if out1 is not None else out0
+
+
+def conv2d_k5s2(x, wpack, bias, cout, act=ACT_RELU):
+    """5x5 stride-2 pad-2 convolution (+bias, activation): x planar [cin,hin,win] -> [cout,ceil(hin/2),ceil(win/2)]."""
+    _t(x, "conv input")
+    cin, hin, win = x.shape
+    ho, wo = (hin - 1) // 2 + 1, (win - 1) // 2 + 1
+    out = torch.empty(cout, ho, wo, device=x.device, dtype=torch.float32)
+    work = lambda: {"flops": 2.0 * ho * wo * cin * cout * 25, "bytes": 4.0 * (hin * win * cin + ho * wo * cout)}
+    check(_call(f"conv2d_k5s2_nt{(cout + 15) // 16}", work, _lib.lib().effi_conv2d_k5s2_f32, _p(x), cin, _p(wpack), _p(bias), cout,
+                hin, win, act, _p(out), _stream()), "effi_conv2d_k5s2_f32")
+    return out
 
 
 def conv2d_c1k7_relu(x, weight, bias, cout, out=None):

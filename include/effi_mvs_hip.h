@@ -40,6 +40,8 @@ typedef void* effi_stream_t;
 #define EFFI_EPI_GRU_ZR  1   /* channels [0,hd): out0 = sigmoid(.) (= z);  [hd,2hd): out1 = sigmoid(.) * aux0 (= r*h) */
 #define EFFI_EPI_GRU_Q   2   /* q = tanh(.);  out0 = (1 - aux1) * aux0 + aux1 * q   (aux0 = h, aux1 = z) */
 #define EFFI_EPI_HEAD    3   /* 1 channel: out0 = aux0 + tanh(.) (inverse depth);  out1 = 1/clamp(lo+(hi-lo)*out0, 1e-4) */
+#define EFFI_EPI_ADD_UP2 4   /* out0 = act(conv + bias) + nearest_upsample_x2(aux0), aux0 planar [cout][h/2][w/2]
+                              * (feature pyramid top-down path, models/module.py:403,407) */
 
 int effi_version(void);
 const char* effi_error_string(int code);
@@ -167,6 +169,11 @@ int effi_conv2d_f32(const float* const* srcs, const int* src_channels, int n_src
                     int epilogue, int act, const float* aux0, const float* aux1,
                     const float* disp_range, int n_range,
                     float* out0, float* out1, effi_stream_t stream);
+/* 5x5, stride 2, padding 2 convolution (+ folded BN + activation) of the feature pyramid's down-sampling layers,
+ * models/module.py:359,365,370.  in planar [cin][hin][win]; wpack: MFMA packing [ceil(cin/4)][25][ceil(cout/16)][64];
+ * bias [16*ceil(cout/16)]; out planar [cout][(hin-1)/2+1][(win-1)/2+1] = act(conv + bias).  cout <= 64. */
+int effi_conv2d_k5s2_f32(const float* in, int cin, const float* wpack, const float* bias, int cout,
+                         int hin, int win, int act, float* out, effi_stream_t stream);
 /* 7x7, one input channel (convd1, models/update.py:76,90): in [h][w]; weight [49][cout]
  * (host-packed), bias [cout]; out planar [cout][h][w] = relu(conv + bias).  cout in {16,32,48}. */
 int effi_conv2d_c1k7_relu_f32(const float* in, const float* weight, const float* bias, int cout,

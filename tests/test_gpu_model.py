@@ -133,6 +133,24 @@ def test_tanks_and_temples_shaped_cascade():
         assert mean <= 1e-3 and p99 <= 5e-3, (i, mean, p99)
 
 
+@pytest.mark.parametrize("H,W", [(64, 96), (256, 320), (1184, 1600)])
+def test_feature_pyramid_on_hip(H, W):
+    """Scope row n1: P_1to8_FeatureNet_Fast (feature net and context net) on the MFMA conv kernels vs the oracle."""
+    from oracle import effi_oracle as O
+    net, sd = build_model("8,8,8", seed=8, device=DEV)
+    g = torch.Generator().manual_seed(H)
+    img = torch.rand(1, 3, H, W, generator=g)
+    with torch.no_grad():
+        for name, mod in (("feature", net.feature), ("cnet_depth", net.cnet_depth)):
+            want = O.feature_net(sd, name, img)
+            got = mod(img.to(DEV))
+            ref_torch = mod.forward_torch(img.to(DEV))
+            for k in ("stage1", "stage2", "stage3"):
+                assert tuple(got[k].shape) == tuple(want[k].shape)
+                check_close(f"FPN {name}.{k} {H}x{W}", got[k], want[k], rtol=1e-4, atol=2e-5)
+                check_close(f"FPN {name}.{k} {H}x{W} (stock torch on GPU)", ref_torch[k], want[k], rtol=1e-3, atol=1e-4)
+
+
 def test_full_forward_including_fpn():
     """model(imgs, proj_matrices, depth_values) exactly as the reference's drivers call it
     (test_dtu_dypcd.py:439); FPN runs in stock PyTorch-ROCm, so features differ by MIOpen rounding."""
