@@ -180,6 +180,37 @@ def main():
             "kernel_breakdown_ms": {k: round(v["ms"], 4) for k, v in sorted(disc.items(), key=lambda kv: -kv[1]["ms"])},
         }
 
+    # ---- secondary (rank 0, N = 1, outside the timed region): the whole forward as the reference's drivers time it
+    # (test_dtu_dypcd.py:437-442: images -> 13 depth maps), with the feature pyramid on the HIP kernels (scope row n1)
+    # and, for comparison, with the stock PyTorch-ROCm pyramid in front of the same hot path
+    if rank == 0 and world == 1:
+        imgs, pm_c, dv_c = synth.synth_sample(H, W, N, seed=0)
+        imgs = imgs.to(dev)
+        pm_d = {k: v.to(dev) for k, v in pm_c.items()}
+        dv_d = dv_c.to(dev)
+
+        def timed(fn, n=5):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n * 1e3
+
+        def fwd_torch_fpn():
+            f = [net.feature.forward_torch(imgs[:, v]) for v in range(N)]
+            return net.forward_hot(f, net.cnet_depth.forward_torch(imgs[:, 0]), pm_d, dv_d)
+
+        with torch.no_grad():
+            full_ms = timed(lambda: net(imgs, pm_d, dv_d))
+            fpn_ms = timed(lambda: ([net.feature(imgs[:, v]) for v in range(N)], net.cnet_depth(imgs[:, 0])))
+            full_torch_fpn_ms = timed(fwd_torch_fpn)
+        result["whole_forward"] = {"ms_per_view": full_ms, "views_per_s": 1e3 / full_ms, "feature_pyramids_ms": fpn_ms,
+                                   "ms_per_view_with_stock_pytorch_pyramid": full_torch_fpn_ms,
+                                   "note": "images resident in HBM -> 13 depth maps + confidence; N feature nets + 1 context net + hot path"}
+        del imgs
+
     # ---- baselines (rank 0, N = 1 only): bounded samples of the same workload ------------------------
     if rank == 0 and world == 1:
         from oracle import effi_oracle as O

@@ -398,6 +398,12 @@ __global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a,
                 const float b = a.bias[co];
                 float v[4] = {acc[m][n][0] + b, acc[m][n][1] + b, acc[m][n][2] + b, acc[m][n][3] + b};
                 float* dst;
+                if (EPI == EFFI_EPI_NHWC) {              // channel-last output: 16 lanes (channels) write one 64-B run per pixel
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (x + r < w) a.out0[(pix + r) * a.cout + co] = apply_act(v[r], a.act);
+                    continue;
+                }
                 if (EPI == EFFI_EPI_PLAIN || EPI == EFFI_EPI_ADD_UP2) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], a.act);
@@ -742,6 +748,9 @@ extern "C" int effi_conv2d_f32(const float* const* srcs, const int* src_channels
         case EFFI_EPI_ADD_UP2:
             if (ks != 1 || !aux0 || (h & 1) || (w & 3)) return EFFI_ERR_BADARG;
             return dispatch_nt<1, EFFI_EPI_ADD_UP2>(a, nt, st);
+        case EFFI_EPI_NHWC:
+            if (act < EFFI_ACT_NONE || act > EFFI_ACT_TANH || (w & 3)) return EFFI_ERR_BADARG;
+            return ks == 3 ? dispatch_nt<3, EFFI_EPI_NHWC>(a, nt, st) : dispatch_nt<1, EFFI_EPI_NHWC>(a, nt, st);
         case EFFI_EPI_GRU_ZR:
             if (ks != 3 || !aux0 || !out1 || (cout % 32) != 0) return EFFI_ERR_BADARG;
             if (nt == 2) return launch2d<3, 2, EFFI_EPI_GRU_ZR>(a, st);

@@ -2,8 +2,8 @@
 
 Public classes / functions keep the reference's names, signatures, return structures and state-dict
 keys (``models/Effi_MVS_plus.py`` in bdwsq1996/Effi-MVS-plus); the work is done by the gfx950 kernels.
-``Effi_MVS_plus.forward`` runs the stock FPN (out of scope) and then
-``forward_hot`` -- the path this repository accelerates and ``bench.py`` times.  Inference only.
+``Effi_MVS_plus.forward`` runs the feature / context pyramids (scope row n1, also on the HIP conv kernels) and then
+``forward_hot`` -- the cost-volume path this repository accelerates and ``bench.py`` times.  Inference only.
 """
 from __future__ import annotations
 
@@ -227,6 +227,7 @@ class Effi_MVS_plus(nn.Module):
         self.PixelwiseNet = PixelwiseNet2d()
         self.feature = P_1to8_FeatureNet_Fast(base_channels=4, in_channel=self.feature_in_channel,
                                               out_channel=self.cost_dim_stage, stage_channel=self.stage_channel)
+        self.feature.channels_last_outputs = True     # the cost-volume kernels read channel-last features
         self.cnet_depth = P_1to8_FeatureNet_Fast(base_channels=4, in_channel=self.context_in_channel,
                                                  out_channel=self.context_feature, stage_channel=self.stage_channel)
         blocks = [BasicUpdateBlock(hidden_dim=self.hdim_stage[s], cost_dim=self.G * self.CostNum,

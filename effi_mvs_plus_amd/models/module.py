@@ -162,6 +162,9 @@ class P_1to8_FeatureNet_Fast(nn.Module):
     def __init__(self, base_channels=8, in_channel=[8, 16, 32, 64], out_channel=[32, 16, 8], stage_channel=True):
         super().__init__()
         self.base_channels = base_channels
+        # eval/HIP path only: emit the stage maps channel-last in memory (same [B,C,h,w] shape, torch.channels_last
+        # strides) so the warp kernels take them without a transpose; set by Effi_MVS_plus for its feature net
+        self.channels_last_outputs = False
         c0, c1, c2, c3 = in_channel
 
         def level(cin, cout):
@@ -220,16 +223,21 @@ class P_1to8_FeatureNet_Fast(nn.Module):
                 x = self._block(f"{lname}.{i}", blk, x)
             levels.append(x)
         l1, l2, top = levels
-        w, b = self._pk("out1", self.out1)
-        out = {"stage1": ops.conv2d([top], w, b, self.out1.out_channels, 1)}
+        cl = self.channels_last_outputs and img.shape[-1] % 32 == 0
+
+        def head(name, conv, x, ks):
+            w, b = self._pk(name, conv)
+            if cl:      # [h,w,C] in memory, presented as [C,h,w]
+                return ops.conv2d([x], w, b, conv.out_channels, ks, epilogue=ops.EPI_NHWC).permute(2, 0, 1)
+            return ops.conv2d([x], w, b, conv.out_channels, ks)
+
+        out = {"stage1": head("out1", self.out1, top, 1)}
         w, b = self._pk("inner1", self.inner1)       # lateral 1x1 + nearest-upsampled coarser map, one kernel
         top = ops.conv2d([l2], w, b, self.inner1.out_channels, 1, epilogue=ops.EPI_ADD_UP2, aux0=top)
-        w, b = self._pk("out2", self.out2)
-        out["stage2"] = ops.conv2d([top], w, b, self.out2.out_channels, 3)
+        out["stage2"] = head("out2", self.out2, top, 3)
         w, b = self._pk("inner2", self.inner2)
         top = ops.conv2d([l1], w, b, self.inner2.out_channels, 1, epilogue=ops.EPI_ADD_UP2, aux0=top)
-        w, b = self._pk("out3", self.out3)
-        out["stage3"] = ops.conv2d([top], w, b, self.out3.out_channels, 3)
+        out["stage3"] = head("out3", self.out3, top, 3)
         return out
 
     def forward_torch(self, x):

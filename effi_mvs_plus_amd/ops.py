@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import EffiLibraryError, check
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
-EPI_PLAIN, EPI_GRU_ZR, EPI_GRU_Q, EPI_HEAD, EPI_ADD_UP2 = 0, 1, 2, 3, 4
+EPI_PLAIN, EPI_GRU_ZR, EPI_GRU_Q, EPI_HEAD, EPI_ADD_UP2, EPI_NHWC = 0, 1, 2, 3, 4, 5
 MAX_VIEWS = 12
 
 
@@ -341,6 +341,8 @@ def conv2d(srcs, wpack, bias, cout, ks, epilogue=EPI_PLAIN, act=ACT_NONE, aux0=N
             out0 = torch.empty(cout // 2, h, w, device=dev, dtype=torch.float32)
         elif epilogue == EPI_HEAD:
             out0 = torch.empty(1, h, w, device=dev, dtype=torch.float32)
+        elif epilogue == EPI_NHWC:
+            out0 = torch.empty(h, w, cout, device=dev, dtype=torch.float32)
         else:
             out0 = torch.empty(cout, h, w, device=dev, dtype=torch.float32)
     if out1 is None and epilogue == EPI_GRU_ZR:

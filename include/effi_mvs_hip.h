@@ -40,6 +40,7 @@ typedef void* effi_stream_t;
 #define EFFI_EPI_GRU_ZR  1   /* channels [0,hd): out0 = sigmoid(.) (= z);  [hd,2hd): out1 = sigmoid(.) * aux0 (= r*h) */
 #define EFFI_EPI_GRU_Q   2   /* q = tanh(.);  out0 = (1 - aux1) * aux0 + aux1 * q   (aux0 = h, aux1 = z) */
 #define EFFI_EPI_HEAD    3   /* 1 channel: out0 = aux0 + tanh(.) (inverse depth);  out1 = 1/clamp(lo+(hi-lo)*out0, 1e-4) */
+#define EFFI_EPI_NHWC    5   /* out0 = act(conv + bias) written channel-last [h][w][cout] (what the warp kernels read) */
 #define EFFI_EPI_ADD_UP2 4   /* out0 = act(conv + bias) + nearest_upsample_x2(aux0), aux0 planar [cout][h/2][w/2]
                               * (feature pyramid top-down path, models/module.py:403,407) */
 
