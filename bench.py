@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--torch-baseline-views", type=int, default=3,
                     help="also time the reference-style composite PyTorch-ROCm path (the oracle's op sequence run on the GPU); 0 = skip")
     ap.add_argument("--profile-key", default=None, help="kernel key to bracket with events (default: auto = largest total time)")
+    ap.add_argument("--no-whole-forward", action="store_true", help="skip the secondary whole-forward timings (profiling runs)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1: nccl (= RCCL over xGMI, the real path) or gloo (rehearsal of the "
                          "multi-rank plumbing on a box with fewer GPUs than ranks; ranks then share devices)")
@@ -183,7 +184,7 @@ def main():
     # ---- secondary (rank 0, N = 1, outside the timed region): the whole forward as the reference's drivers time it
     # (test_dtu_dypcd.py:437-442: images -> 13 depth maps), with the feature pyramid on the HIP kernels (scope row n1)
     # and, for comparison, with the stock PyTorch-ROCm pyramid in front of the same hot path
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_whole_forward:
         imgs, pm_c, dv_c = synth.synth_sample(H, W, N, seed=0)
         imgs = imgs.to(dev)
         pm_d = {k: v.to(dev) for k, v in pm_c.items()}

@@ -163,7 +163,7 @@ int effi_getcost_f32(const float* inv_depth, const float* disp_range, int n_rang
  * [ceil(cin/4)][ks*ks][ceil(cout/16)][64] (lane order of the MFMA B operand); bias [16*ceil(cout/16)].
  * cout == 1 && ks == 3 (depth head) runs on the vector ALUs and reads plain [cin][9] weights appended
  * to wpack at float offset ceil(cin/4)*9*64.
- * epilogue: EFFI_EPI_*; act used by EFFI_EPI_PLAIN; aux0/aux1/out1 per the EFFI_EPI_* comments;
+ * epilogue: EFFI_EPI_*; act used by EFFI_EPI_PLAIN / _ADD_UP2 / _NHWC; aux0/aux1/out1 per the EFFI_EPI_* comments;
  * disp_range (EPI_HEAD only): device pointer to depth_values, n_range entries. */
 int effi_conv2d_f32(const float* const* srcs, const int* src_channels, int n_src,
                     const float* wpack, const float* bias, int cout, int ks, int h, int w,
