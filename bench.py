@@ -31,7 +31,10 @@ WORKLOADS = {
     "cfg4": (1056, 1920, 7, "96,8,8"),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3                 # MI355X_MICROARCH.md, dense fp32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0                # dense bf16 matrix peak; a split-precision product costs three bf16 MFMAs
 PEAK_HBM_GBPS = 8000.0
+DTYPE = {"split": "f32 (3x3 MFMA convs: products as 3 bf16 partial products hi*hi+hi*lo+lo*hi, f32 accumulate; all else f32)",
+         "fp32": "f32"}
 
 
 def main():
@@ -46,6 +49,8 @@ def main():
                     help="also time the reference-style composite PyTorch-ROCm path (the oracle's op sequence run on the GPU); 0 = skip")
     ap.add_argument("--profile-key", default=None, help="kernel key to bracket with events (default: auto = largest total time)")
     ap.add_argument("--no-whole-forward", action="store_true", help="skip the secondary whole-forward timings (profiling runs)")
+    ap.add_argument("--precision", default=None, choices=["split", "fp32"],
+                    help="arithmetic of the 3x3 MFMA convolutions (default: the library default, EFFI_MVS_PRECISION or 'split')")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1: nccl (= RCCL over xGMI, the real path) or gloo (rehearsal of the "
                          "multi-rank plumbing on a box with fewer GPUs than ranks; ranks then share devices)")
@@ -77,6 +82,9 @@ def main():
     from effi_mvs_plus_amd import _lib, ops, shard, synth
 
     _lib.lib()                                   # fail loudly if the HIP library is missing
+    if args.precision:
+        ops.set_precision(args.precision)
+    precision = ops.get_precision()
     H, W, N, nd = WORKLOADS[args.workload]
     net, sd = build_model(nd, seed=1, device=dev)
 
@@ -145,8 +153,10 @@ def main():
         flops_per_launch = ksum["flops"] / ksum["launches"]
         bytes_per_launch = ksum["bytes"] / ksum["launches"]
         intensity = flops_per_launch / max(bytes_per_launch, 1.0)
-        if key.startswith("conv") and intensity > PEAK_FP32_MFMA_TFLOPS * 1e12 / (PEAK_HBM_GBPS * 1e9):
-            roof = {"bound": "mfma", "achieved": flops_per_launch / (avg_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
+        # split-precision kernels: three bf16 MFMAs per fp32-equivalent product
+        mfma_peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if key.startswith("conv2d_k3x3") else PEAK_FP32_MFMA_TFLOPS
+        if key.startswith("conv") and intensity > mfma_peak * 1e12 / (PEAK_HBM_GBPS * 1e9):
+            roof = {"bound": "mfma", "achieved": flops_per_launch / (avg_ms * 1e-3) / 1e12, "peak": mfma_peak,
                     "unit": "TFLOP/s"}
         else:
             roof = {"bound": "hbm", "achieved": bytes_per_launch / (avg_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s"}
@@ -172,7 +182,7 @@ def main():
             "metric": "ref-views/sec (cost-volume hot path: warp + cost volume + 3-D regularisation + cascaded GRU refinement)",
             "value": views / dt, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": DTYPE[precision], "data": "synthetic",
             "config": {"workload": f"{args.workload}: DTU-shaped {W}x{H}, N={N} views (S={N - 1} sources), 3-stage cascade "
                                    f"ndepths={nd}, GRU iters 3,3,3, seeded-random weights, features of the stock FPN resident in HBM",
                        "parallelism": f"view-sharded x{world}, {'RCCL' if args.backend == 'nccl' else 'gloo (rehearsal)'} gather of "
@@ -180,6 +190,29 @@ def main():
             "roofline": roof,
             "kernel_breakdown_ms": {k: round(v["ms"], 4) for k, v in sorted(disc.items(), key=lambda kv: -kv[1]["ms"])},
         }
+
+    # ---- secondary (rank 0, N = 1, outside the timed region): the same K steps with the other conv arithmetic, and the
+    # distance between the two modes' final depth maps (normalised by the depth range, as the parity tests do)
+    if rank == 0 and world == 1:
+        other = "fp32" if precision == "split" else "split"
+        with torch.no_grad():
+            ref_out = step(0)["depth"][-1].clone()
+            ops.set_precision(other)
+            alt_out = step(0)["depth"][-1].clone()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                step(i)
+            torch.cuda.synchronize()
+            dt_other = time.perf_counter() - t0
+            ops.set_precision(precision)
+        rng = synth.DEPTH_MAX_MM - synth.DEPTH_MIN_MM
+        diff = (ref_out - alt_out).abs() / rng
+        result["other_precision"] = {"mode": other, "dtype": DTYPE[other], "value": args.steps / dt_other, "unit": "views/s",
+                                     "ms_per_step": dt_other / args.steps * 1e3,
+                                     "final_depth_diff_between_modes": {"mean_norm": float(diff.mean()),
+                                                                        "p99_norm": float(diff.flatten().kthvalue(int(0.99 * diff.numel())).values),
+                                                                        "max_norm": float(diff.max())}}
 
     # ---- secondary (rank 0, N = 1, outside the timed region): the whole forward as the reference's drivers time it
     # (test_dtu_dypcd.py:437-442: images -> 13 depth maps), with the feature pyramid on the HIP kernels (scope row n1)

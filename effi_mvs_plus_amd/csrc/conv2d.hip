@@ -198,6 +198,72 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(const Conv2dArgs a) {
     }
 }
 
+// Epilogue of one lane's result: v[0..3] = conv + bias for pixels x..x+3 of row y, output channel co.
+// Shared by the fp32-MFMA kernel and the split-bf16 kernel (same C/D fragment layout).
+template <int EPI, bool ALIGNED>
+__device__ __forceinline__ void conv_epilogue_store(const Conv2dArgs& a, float (&v)[4], int co, int x, int y, long pix, long hw,
+                                                    int zpl, float lo, float hi) {
+    const int h = a.h, w = a.w;
+    float* dst;
+    if (EPI == EFFI_EPI_NHWC) {              // channel-last output: 16 lanes (channels) write one 64-B run per pixel
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (x + r < w) a.out0[(pix + r) * a.cout + co] = apply_act(v[r], a.act);
+        return;
+    }
+    if (EPI == EFFI_EPI_PLAIN || EPI == EFFI_EPI_ADD_UP2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], a.act);
+        if (EPI == EFFI_EPI_ADD_UP2) {      // + nearest-upsampled coarser map (two source pixels per float4)
+            const float* up = a.aux0 + (long)co * ((long)(h >> 1) * (w >> 1)) + (long)(y >> 1) * (w >> 1) + (x >> 1);
+            const float u0 = up[0], u1 = (x + 2 < w) ? up[1] : 0.0f;
+            v[0] += u0;
+            v[1] += u0;
+            v[2] += u1;
+            v[3] += u1;
+        }
+        dst = a.out0 + (long)co * a.ostride + (long)zpl * hw + pix;
+        if (!ALIGNED) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (x + r < w) dst[r] = v[r];
+            return;
+        }
+    } else if (EPI == EFFI_EPI_GRU_ZR) {
+        if (co < a.hd) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = effi_sigmoid(v[r]);
+            dst = a.out0 + (long)co * hw + pix;
+        } else {
+            const float4 hv = *reinterpret_cast<const float4*>(a.aux0 + (long)(co - a.hd) * hw + pix);
+            v[0] = effi_sigmoid(v[0]) * hv.x;
+            v[1] = effi_sigmoid(v[1]) * hv.y;
+            v[2] = effi_sigmoid(v[2]) * hv.z;
+            v[3] = effi_sigmoid(v[3]) * hv.w;
+            dst = a.out1 + (long)(co - a.hd) * hw + pix;
+        }
+    } else if (EPI == EFFI_EPI_GRU_Q) {
+        const float4 hv = *reinterpret_cast<const float4*>(a.aux0 + (long)co * hw + pix);
+        const float4 zv = *reinterpret_cast<const float4*>(a.aux1 + (long)co * hw + pix);
+        v[0] = (1.0f - zv.x) * hv.x + zv.x * tanhf(v[0]);
+        v[1] = (1.0f - zv.y) * hv.y + zv.y * tanhf(v[1]);
+        v[2] = (1.0f - zv.z) * hv.z + zv.z * tanhf(v[2]);
+        v[3] = (1.0f - zv.w) * hv.w + zv.w * tanhf(v[3]);
+        dst = a.out0 + (long)co * hw + pix;
+    } else {  // EFFI_EPI_HEAD
+        const float4 iv = *reinterpret_cast<const float4*>(a.aux0 + pix);
+        v[0] = iv.x + tanhf(v[0]);
+        v[1] = iv.y + tanhf(v[1]);
+        v[2] = iv.z + tanhf(v[2]);
+        v[3] = iv.w + tanhf(v[3]);
+        dst = a.out0 + pix;
+        *reinterpret_cast<float4*>(a.out1 + pix) =
+            make_float4(effi_inv_to_depth(v[0], lo, hi), effi_inv_to_depth(v[1], lo, hi),
+                        effi_inv_to_depth(v[2], lo, hi), effi_inv_to_depth(v[3], lo, hi));
+    }
+    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // v3 (used whenever w % 4 == 0): both operands come from LDS inside the k-loop, workgroups are persistent.
 //   * chunk = CC input channels (CC/4 k-groups; 16 when the accumulators leave room, else 8):
@@ -397,70 +463,182 @@ __global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a,
                 if (co >= a.cout) continue;
                 const float b = a.bias[co];
                 float v[4] = {acc[m][n][0] + b, acc[m][n][1] + b, acc[m][n][2] + b, acc[m][n][3] + b};
-                float* dst;
-                if (EPI == EFFI_EPI_NHWC) {              // channel-last output: 16 lanes (channels) write one 64-B run per pixel
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (x + r < w) a.out0[(pix + r) * a.cout + co] = apply_act(v[r], a.act);
-                    continue;
-                }
-                if (EPI == EFFI_EPI_PLAIN || EPI == EFFI_EPI_ADD_UP2) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], a.act);
-                    if (EPI == EFFI_EPI_ADD_UP2) {      // + nearest-upsampled coarser map (two source pixels per float4)
-                        const float* up = a.aux0 + (long)co * ((long)(h >> 1) * (w >> 1)) + (long)(y >> 1) * (w >> 1) + (x >> 1);
-                        const float u0 = up[0], u1 = (x + 2 < w) ? up[1] : 0.0f;
-                        v[0] += u0;
-                        v[1] += u0;
-                        v[2] += u1;
-                        v[3] += u1;
-                    }
-                    dst = a.out0 + (long)co * a.ostride + (long)zpl * hw + pix;
-                    if (!ALIGNED) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (x + r < w) dst[r] = v[r];
-                        continue;
-                    }
-                } else if (EPI == EFFI_EPI_GRU_ZR) {
-                    if (co < a.hd) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = effi_sigmoid(v[r]);
-                        dst = a.out0 + (long)co * hw + pix;
-                    } else {
-                        const float4 hv = *reinterpret_cast<const float4*>(a.aux0 + (long)(co - a.hd) * hw + pix);
-                        v[0] = effi_sigmoid(v[0]) * hv.x;
-                        v[1] = effi_sigmoid(v[1]) * hv.y;
-                        v[2] = effi_sigmoid(v[2]) * hv.z;
-                        v[3] = effi_sigmoid(v[3]) * hv.w;
-                        dst = a.out1 + (long)(co - a.hd) * hw + pix;
-                    }
-                } else if (EPI == EFFI_EPI_GRU_Q) {
-                    const float4 hv = *reinterpret_cast<const float4*>(a.aux0 + (long)co * hw + pix);
-                    const float4 zv = *reinterpret_cast<const float4*>(a.aux1 + (long)co * hw + pix);
-                    v[0] = (1.0f - zv.x) * hv.x + zv.x * tanhf(v[0]);
-                    v[1] = (1.0f - zv.y) * hv.y + zv.y * tanhf(v[1]);
-                    v[2] = (1.0f - zv.z) * hv.z + zv.z * tanhf(v[2]);
-                    v[3] = (1.0f - zv.w) * hv.w + zv.w * tanhf(v[3]);
-                    dst = a.out0 + (long)co * hw + pix;
-                } else {  // EFFI_EPI_HEAD
-                    const float4 iv = *reinterpret_cast<const float4*>(a.aux0 + pix);
-                    v[0] = iv.x + tanhf(v[0]);
-                    v[1] = iv.y + tanhf(v[1]);
-                    v[2] = iv.z + tanhf(v[2]);
-                    v[3] = iv.w + tanhf(v[3]);
-                    dst = a.out0 + pix;
-                    *reinterpret_cast<float4*>(a.out1 + pix) =
-                        make_float4(effi_inv_to_depth(v[0], lo, hi), effi_inv_to_depth(v[1], lo, hi),
-                                    effi_inv_to_depth(v[2], lo, hi), effi_inv_to_depth(v[3], lo, hi));
-                }
-                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                conv_epilogue_store<EPI, ALIGNED>(a, v, co, x, y, pix, hw, zpl, lo, hi);
             }
         }
         if (next_tile >= ntiles) break;
         tile = next_tile;
         x0 = nx0;
         y0 = ny0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split-precision 3x3 convolution ("bf16x3"): every fp32 operand is written as hi + lo with hi = bf16(x),
+// lo = bf16(x - hi), and a product is evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with fp32
+// accumulation (the dropped lo*lo term and the bf16 rounding of lo are ~2^-17 relative, i.e. ~1e-5 vs 6e-8 for the
+// exact fp32 MFMA).  One bf16 MFMA covers K = 32 in 16 cycles where the fp32 MFMA covers K = 4 in 32-40, so the three
+// MFMAs per product are still ~6x cheaper; the three run back to back on the same accumulator.
+//   * chunk = 16 input channels.  K index inside a chunk = (tap, octet of 8 channels); a K-step of 32 = 4 such items
+//     (lane quarter q = lane>>4 owns item 4s+q), 9 taps x 2 octets = 18 items -> 5 K-steps (the last two items are zero).
+//   * A tile in LDS is bf16 [octet][pixel][8 ch] for hi and for lo, so a lane's fragment (8 consecutive channels of one
+//     pixel at one tap) is ONE ds_read_b128 and the 16 pixels of a lane group sit in 16 consecutive 16-byte slots = all 64
+//     banks (conflict-free whatever the tap shift).  Staging does the transposition in registers: a thread owns (4 pixels,
+//     8 channels) = 8 coalesced float4 loads from the planar fp32 map, splits them and writes 2 x 4 ds_write_b128; pixel
+//     slot p is stored at p ^ ((p >> 3) & 1), which keeps the reads conflict-free and makes the stores 2-way (13 vs 16
+//     LDS cycles) instead of 4-way.
+//   * B fragments are pre-split and pre-ordered by the host ([chunk][K-step][N-tile][hi|lo][lane][8] bf16) and copied to LDS.
+// Same tiling (16 x 4*MR pixels per workgroup), prefetch-into-registers structure and epilogues as the fp32 kernel.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <int NT, int MR, int EPI>
+__global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs a, int tiles_x, int ntiles) {
+    constexpr int TR = 4 * MR, AR = TR + 2, AW = 24, AQ = 6, XOFF = 3, XLEFT = 4, CCH = 16, NKS = 5;
+    constexpr int APIX = AR * AW, NITEMS = (APIX / 4) * 2;             // staging work items: (pixel quad, octet)
+    constexpr int NBF = NKS * NT * 2 * 64;                             // 16-byte units of B per chunk
+    constexpr int NB4 = (NBF + 255) / 256;
+    static_assert(NITEMS <= 256, "one staging item per thread");
+    __shared__ __attribute__((aligned(16))) unsigned short lds_ah[APIX * CCH];
+    __shared__ __attribute__((aligned(16))) unsigned short lds_al[APIX * CCH];
+    __shared__ __attribute__((aligned(16))) unsigned short lds_b[NBF * 8];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int h = a.h, w = a.w;
+    const long hw = (long)h * w;
+    const int tile = effi_xcd_remap(blockIdx.x, gridDim.x);
+    if (tile >= ntiles) return;
+    const int ty_ = tile / tiles_x;
+    const int x0 = (tile - ty_ * tiles_x) * 16, y0 = ty_ * TR;
+
+    // staging item of this thread
+    const bool stager = tid < NITEMS;
+    const int pq = stager ? tid % (APIX / 4) : 0, soct = stager ? tid / (APIX / 4) : 0;
+    const int srow = pq / AQ, sqx = pq - srow * AQ;
+    const int sgy = y0 - 1 + srow, sgx = x0 - XLEFT + 4 * sqx;
+    const int s_off = (stager & (sgy >= 0) & (sgy < h) & (sgx >= 0) & (sgx < w)) ? sgy * w + sgx : -1;
+    const int s_p0 = srow * AW + 4 * sqx;                              // pixel slot of the quad (multiple of 4)
+    const int s_sw = (s_p0 >> 3) & 1;
+    const int s_lds = (soct * APIX + s_p0) * 8;                        // bf16 index of the quad in its octet plane
+
+    float pa[8][4];                                   // [channel of the octet][pixel of the quad]
+    const int nchunks = (a.cin + CCH - 1) / CCH;
+    const unsigned short* wbf = reinterpret_cast<const unsigned short*>(a.wpack);
+    auto prefetch = [&](int ch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int cg = ch * CCH + soct * 8 + e;
+            const bool ok = (s_off >= 0) & (cg < a.cin);
+            const float* p = a.src[0];
+            if (cg >= a.ch[0]) {
+                cg -= a.ch[0];
+                p = a.src[1];
+                if (cg >= a.ch[1]) { cg -= a.ch[1]; p = a.src[2]; }
+            }
+            const float4 t = *reinterpret_cast<const float4*>(ok ? p + (long)cg * hw + s_off : a.bias);
+            pa[e][0] = ok ? t.x : 0.0f;
+            pa[e][1] = ok ? t.y : 0.0f;
+            pa[e][2] = ok ? t.z : 0.0f;
+            pa[e][3] = ok ? t.w : 0.0f;
+        }
+    };
+    // A: split + transpose out of the prefetch registers.  B (pre-split by the host, L2-resident, identical for every
+    // workgroup) is copied global -> LDS here rather than held in registers across the multiply phase.
+    auto stash = [&](int ch) {
+        float4 tb[NB4];
+#pragma unroll
+        for (int j = 0; j < NB4; ++j) {
+            const int u = min(tid + j * 256, NBF - 1);
+            tb[j] = *reinterpret_cast<const float4*>(wbf + ((long)ch * NBF + u) * 8);
+        }
+        if (stager) {
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                bf16x8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    hi[e] = (__bf16)pa[e][px];
+                    lo[e] = (__bf16)(pa[e][px] - (float)hi[e]);
+                }
+                *reinterpret_cast<bf16x8*>(&lds_ah[s_lds + (px ^ s_sw) * 8]) = hi;
+                *reinterpret_cast<bf16x8*>(&lds_al[s_lds + (px ^ s_sw) * 8]) = lo;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB4; ++j) {
+            const int u = tid + j * 256;
+            if (u < NBF) *reinterpret_cast<float4*>(&lds_b[u * 8]) = tb[j];
+        }
+    };
+
+    // fragment addressing: lane (pixel li, quarter lk) owns item 4s + lk = (tap, octet) of K-step s
+    int aoff[MR][NKS];
+#pragma unroll
+    for (int s_ = 0; s_ < NKS; ++s_) {
+        const int item = 4 * s_ + lk;
+        const int tap = min(item >> 1, 8), oct = item & 1;               // items 18, 19 are padding (B is zero there)
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const int p = (wv * MR + m + tap / 3) * AW + li + XOFF + tap % 3;
+            aoff[m][s_] = (oct * APIX + (p ^ ((p >> 3) & 1))) * 8;
+        }
+    }
+
+    f32x4 acc[MR][NT];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    prefetch(0);
+    stash(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if (ch + 1 < nchunks) prefetch(ch + 1);
+#pragma unroll
+        for (int s_ = 0; s_ < NKS; ++s_) {
+            bf16x8 ah[MR], al[MR];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                ah[m] = *reinterpret_cast<const bf16x8*>(&lds_ah[aoff[m][s_]]);
+                al[m] = *reinterpret_cast<const bf16x8*>(&lds_al[aoff[m][s_]]);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&lds_b[(((s_ * NT + n) * 2 + 0) * 64 + lane) * 8]);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&lds_b[(((s_ * NT + n) * 2 + 1) * 64 + lane) * 8]);
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh, acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl, acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh, acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+        if (ch + 1 < nchunks) {
+            __syncthreads();
+            stash(ch + 1);
+            __syncthreads();
+        }
+    }
+
+    const int x = x0 + 4 * lk;
+    float lo = 0.0f, hi = 0.0f;
+    if (EPI == EFFI_EPI_HEAD) { lo = a.disp_range[0]; hi = a.disp_range[a.n_range - 1]; }
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        const int y = y0 + wv * MR + m;
+        if (y >= h || x >= w) continue;
+        const long pix = (long)y * w + x;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int co = n * 16 + li;
+            if (co >= a.cout) continue;
+            const float b = a.bias[co];
+            float v[4] = {acc[m][n][0] + b, acc[m][n][1] + b, acc[m][n][2] + b, acc[m][n][3] + b};
+            conv_epilogue_store<EPI, true>(a, v, co, x, y, pix, hw, 0, lo, hi);
+        }
     }
 }
 
@@ -821,6 +999,90 @@ extern "C" int effi_conv2d_k5s2_f32(const float* in, int cin, const float* wpack
         case 2: return dispatch_k5s2<2>(a, st);
         case 4: return dispatch_k5s2<4>(a, st);
         default: return EFFI_ERR_UNSUPPORTED;
+    }
+}
+
+// ---- split-bf16 3x3 convolution entry --------------------------------------------------------------------------
+template <int NT, int EPI>
+static int launch_bf16x3(const Conv2dArgs& a, hipStream_t st) {
+    const long cols = effi_cdiv(a.w, 16);
+    int mr;
+    if (cols * effi_cdiv(a.h, 16) >= 512) mr = 4;
+    else if (cols * effi_cdiv(a.h, 8) >= 512) mr = 2;
+    else mr = 1;
+    const int tiles_x = (int)cols, ntiles = tiles_x * effi_cdiv(a.h, 4 * mr);
+    if (mr == 4) hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 4, EPI>), dim3(ntiles), dim3(256), 0, st, a, tiles_x, ntiles);
+    else if (mr == 2) hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 2, EPI>), dim3(ntiles), dim3(256), 0, st, a, tiles_x, ntiles);
+    else hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 1, EPI>), dim3(ntiles), dim3(256), 0, st, a, tiles_x, ntiles);
+    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+}
+
+template <int EPI>
+static int dispatch_bf16x3(const Conv2dArgs& a, int nt, hipStream_t st) {
+    switch (nt) {
+        case 1: return launch_bf16x3<1, EPI>(a, st);
+        case 2: return launch_bf16x3<2, EPI>(a, st);
+        case 3: return launch_bf16x3<3, EPI>(a, st);
+        case 4: return launch_bf16x3<4, EPI>(a, st);
+        case 6: return launch_bf16x3<6, EPI>(a, st);
+        default: return EFFI_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int effi_conv2d_k3_bf16x3_f32(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
+                                         const float* bias, int cout, int h, int w, int epilogue, int act, const float* aux0,
+                                         const float* aux1, const float* disp_range, int n_range, float* out0, float* out1,
+                                         effi_stream_t stream) {
+    if (!srcs || !src_channels || n_src < 1 || n_src > EFFI_MAX_SRC || !wpack_bf16 || !bias || !out0) return EFFI_ERR_BADARG;
+    if (cout < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    if (w & 3) return EFFI_ERR_UNSUPPORTED;                 // rows must be float4-aligned (callers fall back to the fp32 kernel)
+    Conv2dArgs a;
+    a.cin = 0;
+    for (int i = 0; i < EFFI_MAX_SRC; ++i) {
+        a.src[i] = (i < n_src) ? srcs[i] : nullptr;
+        a.ch[i] = (i < n_src) ? src_channels[i] : 0;
+        if (i < n_src && (!srcs[i] || src_channels[i] < 1)) return EFFI_ERR_BADARG;
+        a.cin += a.ch[i];
+    }
+    a.kgroups = (a.cin + 3) / 4;
+    a.wpack = reinterpret_cast<const float*>(wpack_bf16);
+    a.bias = bias;
+    a.cout = cout;
+    a.h = a.hin = h;
+    a.w = a.win = w;
+    a.act = act;
+    a.hd = cout / 2;
+    a.aux0 = aux0;
+    a.aux1 = aux1;
+    a.disp_range = disp_range;
+    a.n_range = n_range;
+    a.out0 = out0;
+    a.out1 = out1;
+    a.cstride = a.ostride = (long)h * w;
+    a.zcount = 0;
+    const int nt = (cout + 15) / 16;
+    hipStream_t st = effi_s(stream);
+    switch (epilogue) {
+        case EFFI_EPI_PLAIN:
+            if (act < EFFI_ACT_NONE || act > EFFI_ACT_TANH) return EFFI_ERR_BADARG;
+            return dispatch_bf16x3<EFFI_EPI_PLAIN>(a, nt, st);
+        case EFFI_EPI_NHWC:
+            if (act < EFFI_ACT_NONE || act > EFFI_ACT_TANH) return EFFI_ERR_BADARG;
+            return dispatch_bf16x3<EFFI_EPI_NHWC>(a, nt, st);
+        case EFFI_EPI_GRU_ZR:
+            if (!aux0 || !out1 || (cout % 32) != 0) return EFFI_ERR_BADARG;
+            if (nt == 2) return launch_bf16x3<2, EFFI_EPI_GRU_ZR>(a, st);
+            if (nt == 4) return launch_bf16x3<4, EFFI_EPI_GRU_ZR>(a, st);
+            if (nt == 6) return launch_bf16x3<6, EFFI_EPI_GRU_ZR>(a, st);
+            return EFFI_ERR_UNSUPPORTED;
+        case EFFI_EPI_GRU_Q:
+            if (!aux0 || !aux1 || (cout % 16) != 0) return EFFI_ERR_BADARG;
+            if (nt == 1) return launch_bf16x3<1, EFFI_EPI_GRU_Q>(a, st);
+            if (nt == 2) return launch_bf16x3<2, EFFI_EPI_GRU_Q>(a, st);
+            if (nt == 3) return launch_bf16x3<3, EFFI_EPI_GRU_Q>(a, st);
+            return EFFI_ERR_UNSUPPORTED;
+        default:
+            return EFFI_ERR_UNSUPPORTED;
     }
 }
 

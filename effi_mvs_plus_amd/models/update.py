@@ -18,7 +18,7 @@ from .module import _require_eval
 
 
 def _pack(cache, conv, scale=1.0):
-    return cache.get([conv.weight, conv.bias], lambda: packing.pack_conv2d_mfma(conv.weight, conv.bias, scale))
+    return cache.get([conv.weight, conv.bias], lambda: packing.pack_conv2d(conv.weight, conv.bias, scale))
 
 
 def _unbatched(t):
@@ -79,7 +79,7 @@ class ConvGRU(nn.Module):
 
     def _packed_zr(self):
         t = [self.convz.weight, self.convz.bias, self.convr.weight, self.convr.bias]
-        return self._czr.get(t, lambda: packing.pack_conv2d_mfma(
+        return self._czr.get(t, lambda: packing.pack_conv2d(
             torch.cat([self.convz.weight, self.convr.weight], 0), torch.cat([self.convz.bias, self.convr.bias], 0)))
 
     def run(self, h, xs, z_buf=None, rh_buf=None, out=None):

@@ -6,6 +6,7 @@ stream.  CPU tensors raise: there is no fallback path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -39,6 +40,25 @@ class KernelProfile:
 
 
 _PROF = None
+
+# Arithmetic of the 3x3 MFMA convolutions: "split" = every fp32 product as hi*hi + hi*lo + lo*hi on the bf16 MFMA with
+# fp32 accumulation (~5e-6 of the output scale), "fp32" = v_mfma_f32_16x16x4_f32 (exact products).  Everything else on the
+# path (warps, 3-D regularisation, soft-argmin, lookups, epilogues) is plain fp32 in both modes.
+PRECISIONS = ("split", "fp32")
+_PRECISION = os.environ.get("EFFI_MVS_PRECISION", "split")
+if _PRECISION not in PRECISIONS:
+    raise ValueError(f"EFFI_MVS_PRECISION must be one of {PRECISIONS}, got {_PRECISION!r}")
+
+
+def set_precision(mode):
+    global _PRECISION
+    if mode not in PRECISIONS:
+        raise ValueError(f"precision must be one of {PRECISIONS}, got {mode!r}")
+    _PRECISION = mode
+
+
+def get_precision():
+    return _PRECISION
 
 
 def set_profile(p):
@@ -351,10 +371,40 @@ def conv2d(srcs, wpack, bias, cout, ks, epilogue=EPI_PLAIN, act=ACT_NONE, aux0=N
         out1 = torch.empty(1, h, w, device=dev, dtype=torch.float32)
     n_range = 0 if disp_range is None else disp_range.numel()
     cin = sum(s.shape[0] for s in srcs)
+    if hasattr(wpack, "w32"):                 # packing.Conv2dWeights: both operand orders, pick the arithmetic here
+        if (_PRECISION == "split" and wpack.wx is not None and ks == 3 and w % 4 == 0
+                and epilogue in (EPI_PLAIN, EPI_NHWC, EPI_GRU_ZR, EPI_GRU_Q)):
+            return conv2d_k3_bf16x3(srcs, wpack.wx, bias, cout, epilogue=epilogue, act=act, aux0=aux0, aux1=aux1,
+                                    out0=out0, out1=out1)
+        wpack = wpack.w32
     work = lambda: {"flops": 2.0 * h * w * cin * cout * ks * ks, "bytes": 4.0 * h * w * (cin + cout)}
     check(_call(f"conv2d_k{ks}_nt{(cout + 15) // 16}_epi{epilogue}", work, _lib.lib().effi_conv2d_f32, _ptr_array(srcs),
                 _int_array([s.shape[0] for s in srcs]), len(srcs), _p(wpack), _p(bias), cout, ks, h, w, epilogue, act,
                 _p(aux0), _p(aux1), _p(disp_range), n_range, _p(out0), _p(out1), _stream()), "effi_conv2d_f32")
+    return (out0, out1) if out1 is not None else out0
+
+
+def conv2d_k3_bf16x3(srcs, wpack, bias, cout, epilogue=EPI_PLAIN, act=ACT_NONE, aux0=None, aux1=None, out0=None, out1=None):
+    """3x3 convolution in split precision (hi*hi + hi*lo + lo*hi on the bf16 MFMA, fp32 accumulate); ``wpack`` from
+    ``packing.pack_conv2d_bf16x3``.  Same sources / epilogues as ``conv2d`` (PLAIN, NHWC, GRU_ZR, GRU_Q); w % 4 == 0."""
+    for s in srcs:
+        _t(s, "conv2d input")
+    h, w = srcs[0].shape[-2:]
+    dev = srcs[0].device
+    if out0 is None:
+        if epilogue == EPI_GRU_ZR:
+            out0 = torch.empty(cout // 2, h, w, device=dev, dtype=torch.float32)
+        elif epilogue == EPI_NHWC:
+            out0 = torch.empty(h, w, cout, device=dev, dtype=torch.float32)
+        else:
+            out0 = torch.empty(cout, h, w, device=dev, dtype=torch.float32)
+    if out1 is None and epilogue == EPI_GRU_ZR:
+        out1 = torch.empty(cout // 2, h, w, device=dev, dtype=torch.float32)
+    cin = sum(s.shape[0] for s in srcs)
+    work = lambda: {"flops": 2.0 * h * w * cin * cout * 9, "bytes": 4.0 * h * w * (cin + cout)}
+    check(_call(f"conv2d_k3x3_nt{(cout + 15) // 16}_epi{epilogue}", work, _lib.lib().effi_conv2d_k3_bf16x3_f32, _ptr_array(srcs),
+                _int_array([s.shape[0] for s in srcs]), len(srcs), _p(wpack), _p(bias), cout, h, w, epilogue, act,
+                _p(aux0), _p(aux1), None, 0, _p(out0), _p(out1), _stream()), "effi_conv2d_k3_bf16x3_f32")
     return (out0, out1) if out1 is not None else out0
 
 

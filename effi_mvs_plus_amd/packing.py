@@ -100,6 +100,48 @@ def pack_conv2d_mfma(weight, bias, scale=1.0):
     return w, b
 
 
+def pack_conv2d_bf16x3(weight, bias, scale=1.0):
+    """[cout,cin,3,3] (+bias) -> (wpack bf16 [ceil(cin/16), 5, NT, 2(hi|lo), 64, 8], bias fp32 [16*NT]).
+
+    Operand order of effi_conv2d_k3_bf16x3_f32: inside a 16-channel chunk the K index is (tap, octet); K-step s of
+    v_mfma_f32_16x16x32_bf16 takes items 4s..4s+3, lane = q*16 + j holds W[cout=16n+j][chunk*16 + oct*8 + e][tap] for
+    item 4s+q = 2*tap + oct (items 18, 19 are zero).  hi = bf16(W), lo = bf16(W - hi).
+    """
+    cout, cin, ks, _ = weight.shape
+    assert ks == 3
+    nt, nch = (cout + 15) // 16, (cin + 15) // 16
+    w = torch.zeros(nt * 16, nch * 16, 10, device=weight.device, dtype=torch.float32)
+    w[:cout, :cin, :9] = weight.reshape(cout, cin, 9).float() * scale
+    # [n, j, chunk, oct, e, tap] -> [chunk, tap, oct, n, j, e]; (tap, oct) flattens to item = 2*tap + oct = 4*s + q
+    w = w.view(nt, 16, nch, 2, 8, 10).permute(2, 5, 3, 0, 1, 4).contiguous()
+    w = w.view(nch, 5, 4, nt, 16, 8).permute(0, 1, 3, 2, 4, 5).contiguous()      # [chunk, s, n, q, j, e]
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    wp = torch.stack([hi, lo], dim=3).contiguous().view(nch, 5, nt, 2, 64, 8)    # [chunk, s, n, hl, lane, e]
+    b = torch.zeros(nt * 16, device=weight.device, dtype=torch.float32)
+    if bias is not None:
+        b[:cout] = bias.float() * scale
+    return wp, b
+
+
+class Conv2dWeights:
+    """Both operand orders of one 2-D convolution: ``w32`` for the exact-fp32 MFMA kernel and, for 3x3 kernels with more
+    than one output channel, ``wx`` for the split-bf16 kernel.  ``ops.conv2d`` picks per call (precision mode, shape)."""
+    __slots__ = ("w32", "wx")
+
+    def __init__(self, w32, wx):
+        self.w32, self.wx = w32, wx
+
+
+def pack_conv2d(weight, bias, scale=1.0):
+    """-> (Conv2dWeights, bias [16*NT]) for ``ops.conv2d``."""
+    w32, b = pack_conv2d_mfma(weight, bias, scale)
+    wx = None
+    if weight.shape[2] == 3 and weight.shape[0] > 1:
+        wx, _ = pack_conv2d_bf16x3(weight, bias, scale)
+    return Conv2dWeights(w32, wx), b
+
+
 def pack_conv2d_c1k7(weight, bias):
     """[cout,1,7,7] -> ([49,cout], [cout])."""
     cout = weight.shape[0]

@@ -170,6 +170,15 @@ int effi_conv2d_f32(const float* const* srcs, const int* src_channels, int n_src
                     int epilogue, int act, const float* aux0, const float* aux1,
                     const float* disp_range, int n_range,
                     float* out0, float* out1, effi_stream_t stream);
+/* Split-precision variant of the 3x3 convolution (ks = 3, w % 4 == 0): operands are split x = hi + lo into two bf16
+ * values and each product is evaluated as hi*hi + hi*lo + lo*hi on the bf16 matrix cores with fp32 accumulation
+ * (~1e-5 relative error instead of 6e-8; ~3x the throughput of effi_conv2d_f32 on these layers).  Same arguments as
+ * effi_conv2d_f32 except wpack_bf16: host-packed [ceil(cin/16)][5][ceil(cout/16)][hi|lo][64][8] bf16 (packing.py).
+ * Epilogues: PLAIN, NHWC, GRU_ZR, GRU_Q. */
+int effi_conv2d_k3_bf16x3_f32(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
+                              const float* bias, int cout, int h, int w, int epilogue, int act,
+                              const float* aux0, const float* aux1, const float* disp_range, int n_range,
+                              float* out0, float* out1, effi_stream_t stream);
 /* 5x5, stride 2, padding 2 convolution (+ folded BN + activation) of the feature pyramid's down-sampling layers,
  * models/module.py:359,365,370.  in planar [cin][hin][win]; wpack: MFMA packing [ceil(cin/4)][25][ceil(cout/16)][64];
  * bias [16*ceil(cout/16)]; out planar [cout][(hin-1)/2+1][(win-1)/2+1] = act(conv + bias).  cout <= 64. */

@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from common import build_model, check_close, load_golden, t
+from common import build_model, check_close, conv_tol, load_golden, t
 from effi_mvs_plus_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -290,7 +290,7 @@ def test_getcost_initvolume(model, O):
 # GRU update block
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("stage", [1, 2, 3])
-def test_update_block_parts(model, O, stage):
+def test_update_block_parts(model, O, stage, precision):
     import sys
     import effi_mvs_plus_amd.models  # noqa: F401
     M = sys.modules["effi_mvs_plus_amd.models.Effi_MVS_plus"]     # the package attribute of that name is the class
@@ -314,25 +314,26 @@ def test_update_block_parts(model, O, stage):
     cost = costf(depth0, iter=0)
     check_close(f"GetCost st{stage} (golden)", cost, g["cost"], rtol=1e-4, atol=2e-5, frac_ok=0.999)
     enc = blk.encoder(inv0, t(g["cost"], DEV), ctx)
-    check_close(f"ProjectionInput st{stage} (golden)", enc, g["enc"], rtol=1e-4, atol=2e-5)
+    ct = lambda want, layers=1: conv_tol(precision, want, 1e-4, 2e-5, layers)  # noqa: E731
+    check_close(f"ProjectionInput st{stage} (golden)", enc, g["enc"], **ct(g["enc"], 3))
     hnew = blk.depth_gru(h0, t(g["enc"], DEV))
-    check_close(f"ConvGRU st{stage} (golden)", hnew, g["hnew"], rtol=1e-4, atol=2e-5)
+    check_close(f"ConvGRU st{stage} (golden)", hnew, g["hnew"], **ct(g["hnew"], 2))
     delta = blk.depth_head(t(g["hnew"], DEV))
-    check_close(f"DepthHead st{stage} (golden)", delta, g["delta"], rtol=1e-4, atol=2e-5)
+    check_close(f"DepthHead st{stage} (golden)", delta, g["delta"], **ct(g["delta"], 2))
     mask = blk.run_mask(t(g["hnew"][0], DEV)).unsqueeze(0)
-    check_close(f"mask head st{stage} (golden)", mask, g["mask"], rtol=1e-4, atol=2e-5)
+    check_close(f"mask head st{stage} (golden)", mask, g["mask"], **ct(g["mask"], 2))
     up = M.upsample_depth(inv0, t(g["mask"], DEV), ratio=2)
     check_close(f"upsample_depth st{stage} (golden)", up, g["up"], rtol=1e-4, atol=1e-6)
     # full 3-iteration rollout through the public forward (fused path, reference-style partials)
     n_out, masks, invs = blk(h0, costf, inv0, ctx, seq_len=3, scale_inv_depth=scale)
     check_close(f"BasicUpdateBlock.net st{stage} (golden)", n_out, g["blk_net"], rtol=1e-3, atol=2e-4)
     check_close(f"BasicUpdateBlock.mask st{stage} (golden)", masks[-1], g["blk_mask"], rtol=1e-3, atol=2e-4)
-    check_close(f"BasicUpdateBlock.inv st{stage} (golden)", torch.stack(invs), g["blk_inv"], rtol=1e-4, atol=2e-5)
+    check_close(f"BasicUpdateBlock.inv st{stage} (golden)", torch.stack(invs), g["blk_inv"], **ct(g["blk_inv"], 8))
     assert masks[0] is invs[0] or torch.equal(masks[0], invs[0])            # non-final mask slots hold inv_depth
     # generic path (callables that are not ours): same kernels through GetCost.forward
     gen_scale = lambda d: M.disp_to_depth(d, 1.0 / disp_max, 1.0 / disp_min)  # noqa: E731
     n2, m2, i2 = blk(h0, lambda d, iter=0: costf(d, iter=iter), inv0, ctx, seq_len=3, scale_inv_depth=gen_scale)
-    check_close(f"BasicUpdateBlock generic path st{stage}", torch.stack(i2), g["blk_inv"], rtol=1e-4, atol=2e-5)
+    check_close(f"BasicUpdateBlock generic path st{stage}", torch.stack(i2), g["blk_inv"], **ct(g["blk_inv"], 8))
     # oracle pinned to the reference on the same fixture
     o_min, o_max = 1.0 / dv[:, -1, None, None, None], 1.0 / dv[:, 0, None, None, None]
     opro = [g["reg"].permute(0, 2, 3, 1).reshape(h * w, 1, 1, D), g["cur"].permute(0, 2, 3, 1).reshape(h * w, 1, 1, D)]
@@ -365,9 +366,46 @@ def test_conv2d_generic(ks, cins, cout, act):
     check_close(f"conv2d k{ks} {cins}->{cout} act{act} (w=28)", got2, want2, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("h,w", [(21, 28), (130, 256), (256, 512)])      # rows-per-wave 1, 2 and 4
+@pytest.mark.parametrize("cins,cout,epi", [((5,), 7, 0), ((16,), 16, 0), ((16, 16), 12, 0), ((17, 3, 9), 20, 0), ((48,), 48, 5),
+                                           ((16, 16), 32, 1), ((48, 48), 96, 1), ((32, 32), 32, 2), ((64,), 64, 0)])
+def test_conv2d_split_bf16(h, w, cins, cout, epi):
+    """Split-precision (bf16x3) 3x3 conv against an fp64 F.conv2d: every product carries ~2^-16 relative error, so the
+    result must sit within 3e-5 of the fp64 value relative to the output scale (fp32 MFMA path: ~1e-6), all epilogues."""
+    from effi_mvs_plus_amd import ops, packing
+    g = torch.Generator().manual_seed(cout * 100 + h)
+    xs = [torch.randn(c, h, w, generator=g) for c in cins]
+    cin = sum(cins)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = 0.1 * torch.randn(cout, generator=g)
+    y = F.conv2d(torch.cat(xs).unsqueeze(0).double(), wt.double(), b.double(), padding=1)[0]
+    wp, bp = packing.pack_conv2d_bf16x3(wt.to(DEV), b.to(DEV))
+    dx = [t(x, DEV) for x in xs]
+    tol = dict(rtol=0.0, atol=3e-5 * float(y.abs().max()))
+    if epi == 0:
+        got = ops.conv2d_k3_bf16x3(dx, wp, bp, cout, act=1)
+        check_close("bf16x3 plain", got, F.relu(y).float(), **tol)
+    elif epi == 5:
+        got = ops.conv2d_k3_bf16x3(dx, wp, bp, cout, epilogue=ops.EPI_NHWC, act=0)
+        check_close("bf16x3 nhwc", got, y.permute(1, 2, 0).float(), **tol)
+    elif epi == 1:
+        hd = cout // 2
+        hprev = torch.randn(hd, h, w, generator=g)
+        z, rh = ops.conv2d_k3_bf16x3(dx, wp, bp, cout, epilogue=ops.EPI_GRU_ZR, aux0=t(hprev, DEV))
+        check_close("bf16x3 z", z, torch.sigmoid(y[:hd]).float(), **tol)
+        check_close("bf16x3 r*h", rh, (torch.sigmoid(y[hd:]) * hprev.double()).float(), rtol=0.0,
+                    atol=tol["atol"] * float(hprev.abs().max()))
+    else:
+        hprev = torch.randn(cout, h, w, generator=g)
+        z = torch.rand(cout, h, w, generator=g)
+        got = ops.conv2d_k3_bf16x3(dx, wp, bp, cout, epilogue=ops.EPI_GRU_Q, aux0=t(hprev, DEV), aux1=t(z, DEV))
+        want = (1 - z.double()) * hprev.double() + z.double() * torch.tanh(y)
+        check_close("bf16x3 gru q", got, want.float(), **tol)
+
+
 @pytest.mark.parametrize("h,w", [(36, 60), (256, 256), (256, 512)])      # rows-per-wave 1, 2 and 4 of the v2 kernel
 @pytest.mark.parametrize("hd,cd", [(16, 4), (48, 12)])
-def test_update_convs_at_tile_configs(O, h, w, hd, cd):
+def test_update_convs_at_tile_configs(O, h, w, hd, cd, precision):
     """ConvGRU / encoder / heads against the oracle at image sizes that select every tiling of the
     MFMA kernel (the golden fixtures are small and only reach the 1-row-per-wave variant)."""
     import contextlib
@@ -385,20 +423,21 @@ def test_update_convs_at_tile_configs(O, h, w, hd, cd):
     inv = torch.rand(1, 1, h, w, generator=g)
     cost = torch.randn(1, 6, h, w, generator=g)
     ctx = torch.relu(torch.randn(1, cd, h, w, generator=g))
-    check_close(f"ConvGRU hd={hd} {h}x{w}", blk.depth_gru(t(net_h, DEV), t(x, DEV)), O.conv_gru(sd, "b.depth_gru", net_h, x),
-                rtol=1e-4, atol=2e-5)
-    check_close(f"ProjectionInput hd={hd} {h}x{w}", blk.encoder(t(inv, DEV), t(cost, DEV), t(ctx, DEV)),
-                O.projection_input(sd, "b.encoder", inv, cost, ctx), rtol=1e-4, atol=2e-5)
-    check_close(f"DepthHead hd={hd} {h}x{w}", blk.depth_head(t(net_h, DEV)), O.depth_head(sd, "b.depth_head", net_h),
-                rtol=1e-4, atol=2e-5)
-    check_close(f"mask head hd={hd} {h}x{w}", blk.run_mask(t(net_h[0], DEV)), O.mask_head(sd, "b.mask", net_h)[0],
-                rtol=1e-4, atol=2e-5)
+    ct = lambda want, layers: conv_tol(precision, want, 1e-4, 2e-5, layers)  # noqa: E731
+    want = O.conv_gru(sd, "b.depth_gru", net_h, x)
+    check_close(f"ConvGRU hd={hd} {h}x{w}", blk.depth_gru(t(net_h, DEV), t(x, DEV)), want, **ct(want, 2))
+    want = O.projection_input(sd, "b.encoder", inv, cost, ctx)
+    check_close(f"ProjectionInput hd={hd} {h}x{w}", blk.encoder(t(inv, DEV), t(cost, DEV), t(ctx, DEV)), want, **ct(want, 3))
+    want = O.depth_head(sd, "b.depth_head", net_h)
+    check_close(f"DepthHead hd={hd} {h}x{w}", blk.depth_head(t(net_h, DEV)), want, **ct(want, 2))
+    want = O.mask_head(sd, "b.mask", net_h)[0]
+    check_close(f"mask head hd={hd} {h}x{w}", blk.run_mask(t(net_h[0], DEV)), want, **ct(want, 2))
     # fused depth-head tail: inv + tanh(conv2(relu(conv1(net)))) and the depth it scales to
     dv = torch.linspace(1 / 935.0, 1 / 425.0, 384)
     hid = blk.depth_head.run_hidden(t(net_h[0], DEV))
     inv_new, depth = blk.depth_head.run_update(hid, t(inv[0], DEV), t(dv, DEV))
     want_inv = inv + O.depth_head(sd, "b.depth_head", net_h)
-    check_close(f"head update hd={hd} {h}x{w}", inv_new, want_inv[0], rtol=1e-4, atol=2e-5)
+    check_close(f"head update hd={hd} {h}x{w}", inv_new, want_inv[0], **ct(want_inv, 2))
     want_depth = O.disp_to_depth(want_inv, torch.tensor(425.0), torch.tensor(935.0))[1]
     check_close(f"head depth hd={hd} {h}x{w}", depth, want_depth[0], rtol=1e-4, atol=2e-2)
 

@@ -39,4 +39,20 @@ for name, h, w, cins, cout, ks, epi in shapes:
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / n * 1e3
     fl = 2.0 * h * w * cin * cout * ks * ks
-    print(f"{name:16s} {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s")
+    line = f"{name:16s} {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s"
+    if ks == 3 and w % 4 == 0:
+        wx, bx = packing.pack_conv2d_bf16x3(wt, b)
+        for _ in range(3):
+            outx = ops.conv2d_k3_bf16x3(xs, wx, bx, cout, **kw)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            ops.conv2d_k3_bf16x3(xs, wx, bx, cout, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        usx = e0.elapsed_time(e1) / n * 1e3
+        o0 = out[0] if isinstance(out, tuple) else out
+        x0 = outx[0] if isinstance(outx, tuple) else outx
+        err = (o0 - x0).abs().max().item() / max(o0.abs().max().item(), 1e-30)
+        line += f"   | bf16x3 {usx:8.1f} us  {fl / usx / 1e6:7.1f} TFLOP/s  x{us / usx:4.2f}  max rel-to-peak diff {err:.2e}"
+    print(line)
