@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--no-whole-forward", action="store_true", help="skip the secondary whole-forward timings (profiling runs)")
     ap.add_argument("--precision", default=None, choices=["split", "fp32"],
                     help="arithmetic of the 3x3 MFMA convolutions (default: the library default, EFFI_MVS_PRECISION or 'split')")
+    ap.add_argument("--no-other-precision", action="store_true", help="skip the secondary run in the other conv arithmetic (profiling runs)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1: nccl (= RCCL over xGMI, the real path) or gloo (rehearsal of the "
                          "multi-rank plumbing on a box with fewer GPUs than ranks; ranks then share devices)")
@@ -193,7 +194,7 @@ def main():
 
     # ---- secondary (rank 0, N = 1, outside the timed region): the same K steps with the other conv arithmetic, and the
     # distance between the two modes' final depth maps (normalised by the depth range, as the parity tests do)
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_other_precision:
         other = "fp32" if precision == "split" else "split"
         with torch.no_grad():
             ref_out = step(0)["depth"][-1].clone()

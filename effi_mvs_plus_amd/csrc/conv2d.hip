@@ -492,7 +492,9 @@ __global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a,
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int NT, int MR, int EPI>
+// ZB = z-batched (3-D convolution, effi_conv3d_k3s1_bf16x3_f32): blockIdx.y = output plane z, the effective input channels
+// are (dz, c) = cat over dz of the sources' channels at plane z + dz - 1 (zero outside), channel strides D*h*w.
+template <int NT, int MR, int EPI, bool ZB = false>
 __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs a, int tiles_x, int ntiles) {
     constexpr int TR = 4 * MR, AR = TR + 2, AW = 24, AQ = 6, XOFF = 3, XLEFT = 4, CCH = 16, NKS = 5;
     constexpr int APIX = AR * AW, NITEMS = (APIX / 4) * 2;             // staging work items: (pixel quad, octet)
@@ -523,20 +525,30 @@ __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs 
     const int s_lds = (soct * APIX + s_p0) * 8;                        // bf16 index of the quad in its octet plane
 
     float pa[8][4];                                   // [channel of the octet][pixel of the quad]
-    const int nchunks = (a.cin + CCH - 1) / CCH;
+    const int zpl = ZB ? (int)blockIdx.y : 0;
+    const int cin_eff = ZB ? 3 * a.cin : a.cin;
+    const int nchunks = (cin_eff + CCH - 1) / CCH;
     const unsigned short* wbf = reinterpret_cast<const unsigned short*>(a.wpack);
     auto prefetch = [&](int ch) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             int cg = ch * CCH + soct * 8 + e;
-            const bool ok = (s_off >= 0) & (cg < a.cin);
+            bool ok = (s_off >= 0) & (cg < cin_eff);
+            long zoff = 0;
+            if (ZB) {
+                const int dz = (cg >= a.cin) + (cg >= 2 * a.cin);
+                cg -= dz * a.cin;
+                const int zz = zpl + dz - 1;
+                ok &= (zz >= 0) & (zz < a.zcount);
+                zoff = (long)zz * hw;
+            }
             const float* p = a.src[0];
             if (cg >= a.ch[0]) {
                 cg -= a.ch[0];
                 p = a.src[1];
                 if (cg >= a.ch[1]) { cg -= a.ch[1]; p = a.src[2]; }
             }
-            const float4 t = *reinterpret_cast<const float4*>(ok ? p + (long)cg * hw + s_off : a.bias);
+            const float4 t = *reinterpret_cast<const float4*>(ok ? p + (long)cg * a.cstride + zoff + s_off : a.bias);
             pa[e][0] = ok ? t.x : 0.0f;
             pa[e][1] = ok ? t.y : 0.0f;
             pa[e][2] = ok ? t.z : 0.0f;
@@ -637,7 +649,7 @@ __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs 
             if (co >= a.cout) continue;
             const float b = a.bias[co];
             float v[4] = {acc[m][n][0] + b, acc[m][n][1] + b, acc[m][n][2] + b, acc[m][n][3] + b};
-            conv_epilogue_store<EPI, true>(a, v, co, x, y, pix, hw, 0, lo, hi);
+            conv_epilogue_store<EPI, true>(a, v, co, x, y, pix, hw, zpl, lo, hi);
         }
     }
 }
@@ -1003,17 +1015,25 @@ extern "C" int effi_conv2d_k5s2_f32(const float* in, int cin, const float* wpack
 }
 
 // ---- split-bf16 3x3 convolution entry --------------------------------------------------------------------------
-template <int NT, int EPI>
+// Rows per wave (MR): 4 rows amortise the B fragments best, but the grid must still cover the 256 CUs (>= ~400 workgroups),
+// and with two N-tiles the 4-row variant drops to 2 workgroups per CU (188 registers) where the 2-row one keeps 4:
+// on large maps the latter wins (measured, MI355X: 32->32 at 592x800 69 -> 57 us).
+template <int NT, int EPI, bool ZB = false>
 static int launch_bf16x3(const Conv2dArgs& a, hipStream_t st) {
     const long cols = effi_cdiv(a.w, 16);
+    const long planes = ZB ? a.zcount : 1;
+    const long t4 = cols * effi_cdiv(a.h, 16) * planes, t2 = cols * effi_cdiv(a.h, 8) * planes;
     int mr;
-    if (cols * effi_cdiv(a.h, 16) >= 512) mr = 4;
-    else if (cols * effi_cdiv(a.h, 8) >= 512) mr = 2;
+    if (t4 >= 400 && !(NT == 2 && t4 >= 1024)) mr = 4;
+    else if (t2 >= 400) mr = 2;
     else mr = 1;
+    static const char* force = getenv("EFFI_FORCE_MR");
+    if (force) mr = atoi(force);
     const int tiles_x = (int)cols, ntiles = tiles_x * effi_cdiv(a.h, 4 * mr);
-    if (mr == 4) hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 4, EPI>), dim3(ntiles), dim3(256), 0, st, a, tiles_x, ntiles);
-    else if (mr == 2) hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 2, EPI>), dim3(ntiles), dim3(256), 0, st, a, tiles_x, ntiles);
-    else hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 1, EPI>), dim3(ntiles), dim3(256), 0, st, a, tiles_x, ntiles);
+    const dim3 grid(ntiles, (unsigned)planes);
+    if (mr == 4) hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 4, EPI, ZB>), grid, dim3(256), 0, st, a, tiles_x, ntiles);
+    else if (mr == 2) hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 2, EPI, ZB>), grid, dim3(256), 0, st, a, tiles_x, ntiles);
+    else hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 1, EPI, ZB>), grid, dim3(256), 0, st, a, tiles_x, ntiles);
     return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
 
@@ -1083,6 +1103,42 @@ extern "C" int effi_conv2d_k3_bf16x3_f32(const float* const* srcs, const int* sr
             return EFFI_ERR_UNSUPPORTED;
         default:
             return EFFI_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int effi_conv3d_k3s1_bf16x3_f32(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
+                                           const float* bias, int cout, int D, int h, int w, int relu, float* out,
+                                           effi_stream_t stream) {
+    if (!srcs || !src_channels || n_src < 1 || n_src > EFFI_MAX_SRC || !wpack_bf16 || !bias || !out) return EFFI_ERR_BADARG;
+    if (cout < 1 || D < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    if (w & 3) return EFFI_ERR_UNSUPPORTED;
+    Conv2dArgs a;
+    a.cin = 0;
+    for (int i = 0; i < EFFI_MAX_SRC; ++i) {
+        a.src[i] = (i < n_src) ? srcs[i] : nullptr;
+        a.ch[i] = (i < n_src) ? src_channels[i] : 0;
+        if (i < n_src && (!srcs[i] || src_channels[i] < 1)) return EFFI_ERR_BADARG;
+        a.cin += a.ch[i];
+    }
+    a.kgroups = 0;
+    a.wpack = reinterpret_cast<const float*>(wpack_bf16);
+    a.bias = bias;
+    a.cout = cout;
+    a.h = a.hin = h;
+    a.w = a.win = w;
+    a.act = relu ? EFFI_ACT_RELU : EFFI_ACT_NONE;
+    a.hd = 0;
+    a.aux0 = a.aux1 = a.disp_range = nullptr;
+    a.n_range = 0;
+    a.out0 = out;
+    a.out1 = nullptr;
+    a.cstride = a.ostride = (long)D * h * w;
+    a.zcount = D;
+    hipStream_t st = effi_s(stream);
+    switch ((cout + 15) / 16) {
+        case 1: return launch_bf16x3<1, EFFI_EPI_PLAIN, true>(a, st);
+        case 2: return launch_bf16x3<2, EFFI_EPI_PLAIN, true>(a, st);
+        default: return EFFI_ERR_UNSUPPORTED;
     }
 }
 

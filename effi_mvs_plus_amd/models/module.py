@@ -52,6 +52,7 @@ class Conv3d(nn.Module):
         self.relu = relu
         self._cache = packing.PackCache()
         self._cache_planes = packing.PackCache()
+        self._cache_planes_x3 = packing.PackCache()
 
     def _packed(self):
         t = [self.conv.weight, self.conv.bias]
@@ -64,6 +65,16 @@ class Conv3d(nn.Module):
         _require_eval(self)
         if _triple(self.conv.kernel_size) != (3, 3, 3) or _triple(self.conv.padding) != (1, 1, 1):
             raise NotImplementedError("Conv3d: only kernel 3 / padding 1 is instantiated on the HIP path")
+        t = None
+        if (skip is None and _triple(self.conv.stride) == (1, 1, 1) and 1 < self.out_channels <= 32
+                and self.conv.in_channels >= 8 and srcs[0].shape[-1] % 4 == 0 and ops.get_precision() == "split"):
+            # stride-1 layers with >= 8 input channels: z-batched 2-D convolutions on the bf16 matrix cores in split
+            # precision (single-channel inputs stay on the vector kernel: 3 of 16 K-slots used, measured slower)
+            t = [self.conv.weight, self.conv.bias]
+            if self.bn is not None:
+                t += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
+            wp, bp = self._cache_planes_x3.get(t, lambda: packing.pack_conv3d_planes_bf16x3(self.conv, self.bn))
+            return ops.conv3d_k3s1_bf16x3(srcs, wp, bp, self.out_channels, relu=self.relu)
         if (len(srcs) == 1 and skip is None and _triple(self.conv.stride) == (1, 1, 1) and self.out_channels in (16, 32)
                 and self.conv.in_channels >= 8):
             # low-resolution U-Net levels: z-batched 2-D convolutions on the matrix cores

@@ -264,6 +264,21 @@ def conv3d_k3s1_mfma(x, wpack, bias, cout, relu=True):
     return out
 
 
+def conv3d_k3s1_bf16x3(srcs, wpack, bias, cout, relu=True):
+    """srcs: planar [Ci,D,h,w] tensors (channel concatenation); stride-1 3-D conv as z-batched 2-D convs in split precision
+    (``packing.pack_conv3d_planes_bf16x3``) -> [cout,D,h,w].  w % 4 == 0, cout <= 32."""
+    for s in srcs:
+        _t(s, "conv3d input")
+    _, D, h, w = srcs[0].shape
+    cin = sum(s.shape[0] for s in srcs)
+    out = torch.empty(cout, D, h, w, device=srcs[0].device, dtype=torch.float32)
+    work = lambda: {"flops": 2.0 * 27 * cin * cout * D * h * w, "bytes": 4.0 * (cin + cout) * D * h * w}
+    check(_call(f"conv3d_x3_c{cin}_{cout}", work, _lib.lib().effi_conv3d_k3s1_bf16x3_f32, _ptr_array(srcs),
+                _int_array([s.shape[0] for s in srcs]), len(srcs), _p(wpack), _p(bias), cout, D, h, w, int(relu), _p(out),
+                _stream()), "effi_conv3d_k3s1_bf16x3_f32")
+    return out
+
+
 def deconv3d_k3(x, weight, bias, cout, sz=2, relu=True, skip=None):
     _t(x, "deconv3d input")
     cin, D, h, w = x.shape

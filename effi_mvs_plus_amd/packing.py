@@ -64,6 +64,19 @@ def pack_conv3d_planes(conv, bn):
     return pack_conv2d_mfma(w2, bias)
 
 
+def pack_conv3d_planes_bf16x3(conv, bn):
+    """Same view of the weight as ``pack_conv3d_planes`` in the split-bf16 operand order (``pack_conv2d_bf16x3``)."""
+    w = conv.weight
+    bias = conv.bias
+    if bn is not None:
+        scale, shift = bn_scale_shift(bn)
+        w = w * scale.view(-1, 1, 1, 1, 1)
+        bias = shift if bias is None else bias * scale + shift
+    cout, cin = w.shape[0], w.shape[1]
+    w2 = w.permute(0, 2, 1, 3, 4).reshape(cout, 3 * cin, 3, 3)
+    return pack_conv2d_bf16x3(w2, bias)
+
+
 def pack_deconv3d(conv, bn):
     """nn.ConvTranspose3d [cin,cout,3,3,3] (+BN) -> (weight [cin,27,cout], bias [cout] or None)."""
     w = conv.weight

@@ -116,6 +116,13 @@ int effi_conv3d_k3_f32(const float* const* srcs, const int* src_channels, int n_
  * as [cout][3*cin][3][3] with input channel index kd*cin + ci; bias [cout]; out planar [cout][D][h][w]. */
 int effi_conv3d_k3s1_mfma_f32(const float* in, int cin, const float* wpack, const float* bias, int cout,
                               int D, int h, int w, int relu, float* out, effi_stream_t stream);
+/* Same operator (stride 1, cout <= 32, w % 4 == 0) in split precision: products as hi*hi + hi*lo + lo*hi on the bf16
+ * matrix cores with fp32 accumulation (see effi_conv2d_k3_bf16x3_f32).  Input = channel concatenation of n_src planar
+ * tensors [Ci][D][h][w] (models/module.py:513); wpack_bf16 = split-bf16 packing of the weight viewed as
+ * [cout][3*cin][3][3] with input channel index kd*cin + ci; bias [16*ceil(cout/16)]; out planar [cout][D][h][w]. */
+int effi_conv3d_k3s1_bf16x3_f32(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
+                                const float* bias, int cout, int D, int h, int w, int relu, float* out,
+                                effi_stream_t stream);
 /* Transposed 3-D convolution, kernel 3, padding 1, stride (sz,2,2), output_padding (sz-1,1,1):
  * out dims (sz*D, 2h, 2w).  models/module.py:448-450 (sz=2), :508 (sz=1).
  * in planar [cin][D][h][w]; weight [cin][kd][ky][kx][cout] (host-packed from torch's

@@ -176,8 +176,8 @@ def _rand_bn(bn, g):
     (1, 8, (1, 2, 2), (5, 18, 66)),
     # matrix-core path (cout 16/32, stride 1): aligned and unaligned rows, every rows-per-wave variant, real U-Net shapes
     (16, 16, 1, (6, 12, 40)), (32, 32, 1, (4, 8, 52)), (16, 16, 1, (24, 74, 100)), (32, 32, 1, (12, 37, 50)),
-    (16, 16, 1, (48, 40, 64))])
-def test_conv3d_block(cin, cout, stride, dims):
+    (16, 16, 1, (48, 40, 64)), (8, 8, 1, (8, 37, 48)), (1, 8, 1, (8, 148, 200))])
+def test_conv3d_block(cin, cout, stride, dims, precision):
     from effi_mvs_plus_amd.models.module import Conv3d
     g = torch.Generator().manual_seed(cin * 100 + cout)
     m = Conv3d(cin, cout, stride=stride, padding=1).eval()
@@ -186,7 +186,21 @@ def test_conv3d_block(cin, cout, stride, dims):
     x = torch.randn(1, cin, *dims, generator=g)
     want = F.relu(m.bn(m.conv(x)))
     got = m.to(DEV)(t(x, DEV))
-    check_close(f"Conv3d {cin}->{cout} s={stride} {dims}", got, want, rtol=1e-4, atol=1e-5)
+    check_close(f"Conv3d {cin}->{cout} s={stride} {dims}", got, want, **conv_tol(precision, want, 1e-4, 1e-5))
+
+
+@pytest.mark.parametrize("dims", [(8, 20, 24), (8, 74, 100), (5, 148, 200)])
+def test_conv3d_two_sources(dims, precision):
+    """cost_up_small.conv1 (models/module.py:513-514): the channel concatenation is read in place from two tensors."""
+    from effi_mvs_plus_amd.models.module import Conv3d
+    g = torch.Generator().manual_seed(dims[1])
+    m = Conv3d(16, 8, padding=1).eval()
+    m.conv.weight.data = torch.randn(m.conv.weight.shape, generator=g) * (2.0 / (27 * 16)) ** 0.5
+    _rand_bn(m.bn, g)
+    a, b = torch.randn(8, *dims, generator=g), torch.randn(8, *dims, generator=g)
+    want = F.relu(m.bn(m.conv(torch.cat([a, b]).unsqueeze(0))))[0]
+    got = m.to(DEV).run([t(a, DEV), t(b, DEV)])
+    check_close(f"Conv3d [8+8]->8 {dims}", got, want, **conv_tol(precision, want, 1e-4, 1e-5))
 
 
 @pytest.mark.parametrize("cin,cout,stride,dims,skip", [
