@@ -31,6 +31,8 @@ SIGNATURES = {
     "effi_deconv3d_k3_f32": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "effi_softmax_regress_conf_f32": [_vp, _vp, _l, _l, _i, _i, _vp, _vp, _vp],
     "effi_vol_lookup1d_f32": [_vp, _l, _l, _i, _vp, _l, _l, _l, _i, _vp, _vp, _l, _i, _i, _vp, _vp],
+    "effi_getcost_conv1x1_f32": [_vp, _vp, _i, _i, _vp, _vp, _l, _l, _i, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _i,
+                                 _i, _vp, _vp],
     "effi_getcost_f32": [_vp, _vp, _i, _i, _vp, _vp, _l, _l, _i, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _vp, _vp],
     "effi_conv2d_f32": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "effi_conv3d_k3s1_bf16x3_f32": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],

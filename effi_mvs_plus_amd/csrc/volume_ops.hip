@@ -205,6 +205,49 @@ __global__ void getcost_kernel(const float* __restrict__ inv_depth, const float*
     }
 }
 
+// GetCost followed by the encoder's 1x1 convolution + ReLU (convc1, models/update.py:73,86): the 2*NQ looked-up costs of
+// a pixel stay in registers and go straight through the [2*NQ] -> [cout] matrix (weights through the scalar cache), so the
+// cost map is neither written nor read back.
+template <int NQ>
+__global__ void getcost_conv1x1_kernel(const float* __restrict__ inv_depth, const float* __restrict__ disp_range,
+                                       int n_range, int input_is_depth, const float* __restrict__ interval,
+                                       const float* __restrict__ cur_vol, long cds, long cps, int Dcur,
+                                       const float* __restrict__ reg_vol, long rds, long rps_, int Dreg,
+                                       const float* __restrict__ dmin, const float* __restrict__ dmax, long range_ps,
+                                       int hw, const float* __restrict__ weight, const float* __restrict__ bias, int cout,
+                                       int relu, float* __restrict__ out) {
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= hw) return;
+    const float itv = interval[0];
+    float depth = inv_depth[p];
+    if (!input_is_depth) depth = effi_inv_to_depth(depth, disp_range[0], disp_range[n_range - 1]);
+    const float dv = 1.0f / depth;
+    const float half = (float)(NQ / 2) * itv;
+    const float smin = fmaxf(dv - half, 1e-4f);
+    const float smax = fminf(fmaxf(dv + half, 1e-4f), 1e4f);
+    const float step = (smax - smin) / (float)(NQ - 1);
+    const float rlo = dmin[p * range_ps], rhi = dmax[p * range_ps];
+    float cost[2 * NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        const float s = fmaxf(smin + (float)k * step, 1e-5f);
+        const float qd = 1.0f / s;
+        cost[k] = lookup1d(cur_vol + p * cps, cds, Dcur, qd, rlo, rhi);
+        cost[NQ + k] = lookup1d(reg_vol + p * rps_, rds, Dreg, qd, rlo, rhi);
+    }
+    for (int c0 = 0; c0 < cout; c0 += 8) {                 // cout % 8 == 0 (checked by the caller)
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = bias[c0 + j];
+#pragma unroll
+        for (int k = 0; k < 2 * NQ; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaf(cost[k], weight[k * cout + c0 + j], acc[j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[(long)(c0 + j) * hw + p] = relu ? fmaxf(acc[j], 0.0f) : acc[j];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K10: convex upsampling x2 (models/Effi_MVS_plus.py:167-178) + scale_inv_depth
 // ------------------------------------------------------------------------------------------------
@@ -343,6 +386,32 @@ extern "C" int effi_getcost_f32(const float* inv_depth, const float* disp_range,
     hipLaunchKernelGGL(getcost_kernel, dim3(effi_cdiv((long)h * w, TPB)), dim3(TPB), 0, effi_s(stream), inv_depth,
                        disp_range, n_range, input_is_depth, interval, cur_vol, cds, cps, Dcur, reg_vol, rds, rps, Dreg, dmin, dmax,
                        range_ps, nq, h * w, cost);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_getcost_conv1x1_f32(const float* inv_depth, const float* disp_range, int n_range, int input_is_depth,
+                                        const float* interval, const float* cur_vol, long cds, long cps, int Dcur,
+                                        const float* reg_vol, long rds, long rps, int Dreg, const float* dmin,
+                                        const float* dmax, long range_ps, int nq, int h, int w, const float* weight,
+                                        const float* bias, int cout, int relu, float* out, effi_stream_t stream) {
+    if (!inv_depth || !interval || !cur_vol || !reg_vol || !dmin || !dmax || !weight || !bias || !out) return EFFI_ERR_BADARG;
+    if (!input_is_depth && (!disp_range || n_range < 2)) return EFFI_ERR_BADARG;
+    if (Dcur < 2 || Dreg < 2 || h < 1 || w < 1 || cout < 8) return EFFI_ERR_BADARG;
+    if (cout % 8) return EFFI_ERR_UNSUPPORTED;
+    const dim3 grid(effi_cdiv((long)h * w, TPB));
+    hipStream_t st = effi_s(stream);
+#define EFFI_GC(NQ)                                                                                                        \
+    hipLaunchKernelGGL(getcost_conv1x1_kernel<NQ>, grid, dim3(TPB), 0, st, inv_depth, disp_range, n_range, input_is_depth, \
+                       interval, cur_vol, cds, cps, Dcur, reg_vol, rds, rps, Dreg, dmin, dmax, range_ps, h * w, weight,    \
+                       bias, cout, relu, out)
+    switch (nq) {
+        case 2: EFFI_GC(2); break;
+        case 3: EFFI_GC(3); break;
+        case 4: EFFI_GC(4); break;
+        default: return EFFI_ERR_UNSUPPORTED;
+    }
+#undef EFFI_GC
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
 }

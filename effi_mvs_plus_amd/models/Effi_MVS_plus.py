@@ -168,6 +168,14 @@ class GetCost(nn.Module):
             return ops.getcost(inv_depth, disp_range[b], interval, cur[b * n:(b + 1) * n], reg[b * n:(b + 1) * n],
                                lo, hi, CostNum, h, w, input_is_depth=False, out=out)
 
+        def lookup_conv1x1(inv_depth, weight, bias, cout, out=None):
+            """Same lookup with the encoder's convc1 (+ReLU) applied in the kernel: -> [cout,h,w]."""
+            h, w = inv_depth.shape[-2:]
+            n = h * w
+            return ops.getcost_conv1x1(inv_depth, disp_range[b], interval, cur[b * n:(b + 1) * n], reg[b * n:(b + 1) * n],
+                                       lo, hi, CostNum, h, w, weight, bias, cout, relu=True, out=out)
+
+        lookup.conv1x1 = lookup_conv1x1 if CostNum in (2, 3, 4) else None
         return lookup
 
     def forward(self, depth_values, pro, features, proj_matrices, depth_interval, depth_max, depth_min, view_weights,
@@ -291,6 +299,12 @@ class Effi_MVS_plus(nn.Module):
             def lookup(inv_depth, out=None, cur_c=cur_c, reg_c=reg_c, lo_c=lo_c, hi_c=hi_c, itv=itv, h=h, w=w):
                 return ops.getcost(inv_depth, disp_range, itv, cur_c, reg_c, lo_c, hi_c, self.CostNum, h, w, out=out)
 
+            def lookup_conv1x1(inv_depth, weight, bias, cout, out=None, cur_c=cur_c, reg_c=reg_c, lo_c=lo_c, hi_c=hi_c,
+                               itv=itv, h=h, w=w):
+                return ops.getcost_conv1x1(inv_depth, disp_range, itv, cur_c, reg_c, lo_c, hi_c, self.CostNum, h, w,
+                                           weight, bias, cout, relu=True, out=out)
+
+            lookup.conv1x1 = lookup_conv1x1 if self.CostNum in (2, 3, 4) else None
             _, masks, invs, depths = self.update_block[s].run_fused(hidden, lookup, inv_cur, inp, self.seq_len[s],
                                                                      disp_range)
             preds.extend(d[0] for d in depths)

@@ -112,17 +112,27 @@ class ProjectionInput(nn.Module):
         self.convc = nn.Conv2d(hidden_dim, hidden_dim, 1, padding=0)
         self.out_chs = hidden_dim
         self.dropout = nn.Dropout2d(p=0.1)
-        self._caches = {k: packing.PackCache() for k in ("c1", "c2", "d1", "d2", "d", "c")}
+        self._caches = {k: packing.PackCache() for k in ("c1", "c1raw", "c2", "d1", "d2", "d", "c")}
 
-    def run(self, disp, cost, context, bufs=None):
+    def convc1_raw(self):
+        """convc1 as ([cost_dim, hidden] weight, [hidden] bias) for the lookup kernel that applies it in place."""
+        return self._caches["c1raw"].get(
+            [self.convc1.weight, self.convc1.bias],
+            lambda: (self.convc1.weight.reshape(self.convc1.out_channels, -1).t().contiguous().float(),
+                     self.convc1.bias.contiguous().float()))
+
+    def run(self, disp, cost, context, bufs=None, cor1=None):
         """disp [1,h,w], cost [2*nq,h,w], context [cd,h,w] -> [hidden,h,w].  ``bufs``: optional dict of
-        scratch tensors reused across GRU iterations."""
+        scratch tensors reused across GRU iterations; ``cor1``: relu(convc1(cost)) when the lookup kernel already
+        produced it (then ``cost`` is not needed)."""
         hd = self.convc1.out_channels
         if self.convd1.in_channels != 1:
             raise NotImplementedError("ProjectionInput: depth_num must be 1 on the HIP path")
         g = (lambda k: bufs.get(k)) if bufs is not None else (lambda k: None)
-        w, b = _pack(self._caches["c1"], self.convc1)
-        cor = ops.conv2d([cost], w, b, hd, 1, act=ops.ACT_RELU, out0=g("cor1"))
+        if cor1 is None:
+            w, b = _pack(self._caches["c1"], self.convc1)
+            cor1 = ops.conv2d([cost], w, b, hd, 1, act=ops.ACT_RELU, out0=g("cor1"))
+        cor = cor1
         w, b = _pack(self._caches["c2"], self.convc2)
         cor = ops.conv2d([cor], w, b, hd, 3, act=ops.ACT_RELU, out0=g("cor2"))
         w7, b7 = self._caches["d1"].get([self.convd1.weight, self.convd1.bias],
@@ -178,9 +188,14 @@ class BasicUpdateBlock(nn.Module):
                 "mix": mk(self.encoder.convd.out_channels), "enc": mk(hd)}
         z_buf, rh_buf, head_buf, cost_buf = mk(hd), mk(hd), mk(hd), None
         inv_list, mask_list, depth_list = [], [], []
+        fuse_c1 = getattr(lookup, "conv1x1", None) is not None and hd % 8 == 0
         for i in range(seq_len):
-            cost_buf = lookup(inv_depth, cost_buf)
-            x = self.encoder.run(inv_depth, cost_buf, context, bufs)
+            if fuse_c1:      # lookup + convc1 + ReLU in one kernel: the cost map never reaches HBM
+                wc1, bc1 = self.encoder.convc1_raw()
+                x = self.encoder.run(inv_depth, None, context, bufs, cor1=lookup.conv1x1(inv_depth, wc1, bc1, hd, bufs["cor1"]))
+            else:
+                cost_buf = lookup(inv_depth, cost_buf)
+                x = self.encoder.run(inv_depth, cost_buf, context, bufs)
             net = self.depth_gru.run(net, [x], z_buf, rh_buf)          # fresh tensor: callers keep every state
             hid = self.depth_head.run_hidden(net, head_buf)
             inv_depth, depth = self.depth_head.run_update(hid, inv_depth, disp_range)

@@ -365,6 +365,26 @@ def getcost(x, disp_range, interval, cur_vol, reg_vol, dmin, dmax, nq, h, w, inp
     return out
 
 
+def getcost_conv1x1(x, disp_range, interval, cur_vol, reg_vol, dmin, dmax, nq, h, w, weight, bias, cout, relu=True,
+                    input_is_depth=False, out=None):
+    """``getcost`` + 1x1 convolution (weight [2*nq, cout], bias [cout]) + ReLU in one kernel -> [cout,h,w]."""
+    _t(x, "inv_depth"), _t(interval, "interval"), _t(weight, "weight"), _t(bias, "bias")
+    cur_vol, cds, cps, Dc = _vol_strides(cur_vol, h, w)
+    reg_vol, rds, rps, Dr = _vol_strides(reg_vol, h, w)
+    dmin_t, gps = _range_ptr(dmin, h, w)
+    dmax_t, gps2 = _range_ptr(dmax, h, w)
+    if gps != gps2:
+        raise ValueError("depth_min / depth_max must both be global or both per-pixel")
+    if out is None:
+        out = torch.empty(cout, h, w, device=x.device, dtype=torch.float32)
+    n_range = 0 if disp_range is None else disp_range.numel()
+    work = lambda: {"flops": 2.0 * h * w * 2 * nq * cout, "bytes": 4.0 * h * w * (cout + 1 + Dc + Dr)}
+    check(_call("getcost_conv1x1", work, _lib.lib().effi_getcost_conv1x1_f32, _p(x), _p(disp_range), n_range,
+                int(input_is_depth), _p(interval), _p(cur_vol), cds, cps, Dc, _p(reg_vol), rds, rps, Dr, _p(dmin_t), _p(dmax_t),
+                gps, nq, h, w, _p(weight), _p(bias), cout, int(relu), _p(out), _stream()), "effi_getcost_conv1x1_f32")
+    return out
+
+
 def conv2d(srcs, wpack, bias, cout, ks, epilogue=EPI_PLAIN, act=ACT_NONE, aux0=None, aux1=None, disp_range=None,
            out0=None, out1=None):
     for s in srcs:

@@ -164,6 +164,17 @@ int effi_getcost_f32(const float* inv_depth, const float* disp_range, int n_rang
                      const float* dmin, const float* dmax, long range_pstride, int nq,
                      int h, int w, float* cost, effi_stream_t stream);
 
+/* Same lookup fused with the encoder's 1x1 convolution that consumes it (convc1 + ReLU, models/update.py:73,86):
+ * out [cout][h][w] = relu?(bias + W . cost), weight [2*nq][cout] (transposed from torch's [cout][2*nq][1][1]),
+ * nq in {2,3,4}, cout % 8 == 0.  The cost map itself is not materialised. */
+int effi_getcost_conv1x1_f32(const float* inv_depth, const float* disp_range, int n_range, int input_is_depth,
+                             const float* interval,
+                             const float* cur_vol, long cur_dstride, long cur_pstride, int Dcur,
+                             const float* reg_vol, long reg_dstride, long reg_pstride, int Dreg,
+                             const float* dmin, const float* dmax, long range_pstride, int nq,
+                             int h, int w, const float* weight, const float* bias, int cout, int relu,
+                             float* out, effi_stream_t stream);
+
 /* ---- K9: 2-D convolutions of the update block on the fp32 MFMA path (v_mfma_f32_16x16x4_f32).
  * models/update.py:14-15,36-38,73-81,109-112.  ks in {1,3}, padding ks/2, stride 1.
  * Input = concatenation of n_src planar tensors.  wpack: host-packed

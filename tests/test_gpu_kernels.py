@@ -327,6 +327,13 @@ def test_update_block_parts(model, O, stage, precision):
     depth0 = scale(inv0)[1]
     cost = costf(depth0, iter=0)
     check_close(f"GetCost st{stage} (golden)", cost, g["cost"], rtol=1e-4, atol=2e-5, frac_ok=0.999)
+    # lookup + convc1 + ReLU in one kernel (the fused GRU path) against conv1x1 of the golden cost
+    lookup = net.GetCost.make_lookup(0, disp_range=dvd, **costf.keywords)
+    wc1, bc1 = blk.encoder.convc1_raw()
+    cor1 = lookup.conv1x1(inv0[0], wc1, bc1, blk.encoder.convc1.out_channels)
+    want_cor1 = F.relu(F.conv2d(g["cost"], sd[f"update_block.{stage - 1}.encoder.convc1.weight"],
+                                sd[f"update_block.{stage - 1}.encoder.convc1.bias"]))[0]
+    check_close(f"GetCost+convc1 st{stage} (golden)", cor1, want_cor1, rtol=1e-4, atol=2e-5, frac_ok=0.999)
     enc = blk.encoder(inv0, t(g["cost"], DEV), ctx)
     ct = lambda want, layers=1: conv_tol(precision, want, 1e-4, 2e-5, layers)  # noqa: E731
     check_close(f"ProjectionInput st{stage} (golden)", enc, g["enc"], **ct(g["enc"], 3))
