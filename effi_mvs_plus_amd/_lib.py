@@ -35,6 +35,7 @@ SIGNATURES = {
                                  _i, _vp, _vp],
     "effi_getcost_f32": [_vp, _vp, _i, _i, _vp, _vp, _l, _l, _i, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _vp, _vp],
     "effi_conv2d_f32": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp],
+    "effi_conv3d_k3s1_roll_bf16x3_f32": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "effi_conv3d_k3s1_bf16x3_f32": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "effi_conv2d_k3_bf16x3_f32": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "effi_conv2d_k5s2_f32": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp],

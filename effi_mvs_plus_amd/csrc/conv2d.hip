@@ -38,7 +38,19 @@ struct Conv2dArgs {
     long ostride;            // output channel stride
     int zcount;              // D when z-batched, else 0
     int hin, win;            // input map size (= h, w for stride 1; stride-2 convs read a 2x larger map)
+    const float* zeros;      // >= 64 B of zeros in device memory: where padding is read from (split-precision kernels)
 };
+
+// One zero page per process (never freed): padding loads of the split-precision kernels read it instead of masking.
+static const float* effi_zero_page() {
+    static const float* page = [] {
+        void* p = nullptr;
+        if (hipMalloc(&p, 256) != hipSuccess) return (const float*)nullptr;
+        if (hipMemset(p, 0, 256) != hipSuccess) return (const float*)nullptr;
+        return (const float*)p;
+    }();
+    return page;
+}
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
@@ -262,6 +274,67 @@ __device__ __forceinline__ void conv_epilogue_store(const Conv2dArgs& a, float (
                         effi_inv_to_depth(v[2], lo, hi), effi_inv_to_depth(v[3], lo, hi));
     }
     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// Epilogue for the TRANSPOSED fragment layout (MFMA called as weights x pixels, D[cout][pixel]): a lane holds output
+// channels co0..co0+3 of ONE pixel, and the 16 lanes of a lane group hold 16 consecutive pixels of a row, so every store /
+// auxiliary load of a wave instruction is 4 runs of 64 contiguous bytes written by ADJACENT lanes (they coalesce), instead of
+// 16 scattered 16-byte pieces per run as in the pixel-major layout above -- the store phase of the planar epilogues was the
+// largest single cost of the memory-bound layers.  Channel-last output becomes one float4 per lane, 1 KB contiguous per wave.
+template <int EPI>
+__device__ __forceinline__ void conv_epilogue_store_t(const Conv2dArgs& a, const f32x4& acc, int co0, long pix, long hw,
+                                                      int zpl) {
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = acc[r] + a.bias[co0 + r];       // bias is padded to 16*NT entries
+    if (EPI == EFFI_EPI_NHWC || EPI == EFFI_EPI_PLAIN) {               // activation: one uniform branch for the 4 values
+        if (a.act == EFFI_ACT_RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+        } else if (a.act != EFFI_ACT_NONE) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], a.act);
+        }
+    }
+    if (EPI == EFFI_EPI_NHWC) {
+        if (co0 + 3 < a.cout) {
+            *reinterpret_cast<float4*>(a.out0 + pix * a.cout + co0) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (co0 + r < a.cout) a.out0[pix * a.cout + co0 + r] = v[r];
+        }
+        return;
+    }
+    // channel guard: one test per group of 4 when cout is a multiple of 4 (every layer of the model), else per channel
+    const int nvalid = ((a.cout & 3) == 0) ? (co0 < a.cout ? 4 : 0) : a.cout - co0;
+    if (EPI == EFFI_EPI_PLAIN) {
+        float* dst = a.out0 + (long)co0 * a.ostride + (long)zpl * hw + pix;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (r < nvalid) dst[(long)r * a.ostride] = v[r];
+    } else if (EPI == EFFI_EPI_GRU_ZR) {         // co0 is a multiple of 4 and hd of 16: the 4 channels are all z or all r
+        if (nvalid <= 0) return;                 // cout % 16 == 0 for the GRU epilogues (checked by the host): all or nothing
+        const bool is_z = co0 < a.hd;
+        const long o = (long)(is_z ? co0 : co0 - a.hd) * hw + pix;
+        float* dst = (is_z ? a.out0 : a.out1) + o;
+        float hv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hv[r] = a.aux0[o + (long)r * hw];              // r*h needs h; harmless extra read for z
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(long)r * hw] = effi_sigmoid(v[r]) * (is_z ? 1.0f : hv[r]);
+    } else if (EPI == EFFI_EPI_GRU_Q) {
+        if (nvalid <= 0) return;
+        const long o = (long)co0 * hw + pix;
+        float hv[4], zv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            hv[r] = a.aux0[o + (long)r * hw];
+            zv[r] = a.aux1[o + (long)r * hw];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.out0[o + (long)r * hw] = (1.0f - zv[r]) * hv[r] + zv[r] * tanhf(v[r]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -494,6 +567,34 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // ZB = z-batched (3-D convolution, effi_conv3d_k3s1_bf16x3_f32): blockIdx.y = output plane z, the effective input channels
 // are (dz, c) = cat over dz of the sources' channels at plane z + dz - 1 (zero outside), channel strides D*h*w.
+//
+// These layers are bound by the vector-ALU instruction count around the MFMAs (measured: 751 VALU instructions per wave and
+// tile for 60 MFMAs before this form), so the staging is written for few instructions:
+//   * every source but the last has a multiple of 8 channels (checked by the host), so a thread's octet of 8 channels lies in
+//     one source: ONE source/plane selection per chunk, then 8 loads at p + e*cstride;
+//   * padding outside the map / the volume is read from a zero page (base and channel step are selected once per chunk)
+//     instead of being masked; channels beyond cin re-read the last real channel (their weights are zero);
+//   * fp32 -> (hi, lo) uses the packed conversion (v_cvt_pk_bf16_f32) on channel pairs;
+//   * A fragments sit at lane_base + koff[s] + m*row with the row term as an immediate (no address swizzle: the stores are then
+//     4-way instead of 2-way conflicted, ~0.5k LDS cycles per tile, against ~150 address instructions per wave).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// 8 fp32 channels of 4 pixels (pa[e] = 4 pixels of channel e) -> hi/lo bf16x8 of pixel px
+__device__ __forceinline__ void split_octet(const f32x4 (&pa)[8], int px, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const f32x2 x = {pa[e][px], pa[e + 1][px]};
+        const bf16x2 h2 = __builtin_convertvector(x, bf16x2);
+        const f32x2 hf = __builtin_convertvector(h2, f32x2);
+        const bf16x2 l2 = __builtin_convertvector(x - hf, bf16x2);
+        hi[e] = h2[0];
+        hi[e + 1] = h2[1];
+        lo[e] = l2[0];
+        lo[e + 1] = l2[1];
+    }
+}
+
 template <int NT, int MR, int EPI, bool ZB = false>
 __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs a, int tiles_x, int ntiles) {
     constexpr int TR = 4 * MR, AR = TR + 2, AW = 24, AQ = 6, XOFF = 3, XLEFT = 4, CCH = 16, NKS = 5;
@@ -501,9 +602,10 @@ __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs 
     constexpr int NBF = NKS * NT * 2 * 64;                             // 16-byte units of B per chunk
     constexpr int NB4 = (NBF + 255) / 256;
     static_assert(NITEMS <= 256, "one staging item per thread");
+    static_assert(EPI != EFFI_EPI_HEAD && EPI != EFFI_EPI_ADD_UP2, "epilogue not instantiated for the split-precision kernel");
     __shared__ __attribute__((aligned(16))) unsigned short lds_ah[APIX * CCH];
     __shared__ __attribute__((aligned(16))) unsigned short lds_al[APIX * CCH];
-    __shared__ __attribute__((aligned(16))) unsigned short lds_b[NBF * 8];
+    __shared__ __attribute__((aligned(16))) unsigned short lds_b[NB4 * 256 * 8];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -513,88 +615,75 @@ __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs 
     if (tile >= ntiles) return;
     const int ty_ = tile / tiles_x;
     const int x0 = (tile - ty_ * tiles_x) * 16, y0 = ty_ * TR;
+    const int zpl = ZB ? (int)blockIdx.y : 0;
 
     // staging item of this thread
     const bool stager = tid < NITEMS;
     const int pq = stager ? tid % (APIX / 4) : 0, soct = stager ? tid / (APIX / 4) : 0;
     const int srow = pq / AQ, sqx = pq - srow * AQ;
     const int sgy = y0 - 1 + srow, sgx = x0 - XLEFT + 4 * sqx;
-    const int s_off = (stager & (sgy >= 0) & (sgy < h) & (sgx >= 0) & (sgx < w)) ? sgy * w + sgx : -1;
-    const int s_p0 = srow * AW + 4 * sqx;                              // pixel slot of the quad (multiple of 4)
-    const int s_sw = (s_p0 >> 3) & 1;
-    const int s_lds = (soct * APIX + s_p0) * 8;                        // bf16 index of the quad in its octet plane
+    const bool s_in = stager & (sgy >= 0) & (sgy < h) & (sgx >= 0) & (sgx < w);
+    const int s_off = sgy * w + sgx;
+    const int s_lds = (soct * APIX + srow * AW + 4 * sqx) * 8;         // bf16 index of the quad in its octet plane
 
-    float pa[8][4];                                   // [channel of the octet][pixel of the quad]
-    const int zpl = ZB ? (int)blockIdx.y : 0;
+    f32x4 pa[8];                                      // raw loads: pa[e] = 4 pixels of channel e of the octet
     const int cin_eff = ZB ? 3 * a.cin : a.cin;
     const int nchunks = (cin_eff + CCH - 1) / CCH;
     const unsigned short* wbf = reinterpret_cast<const unsigned short*>(a.wpack);
     auto prefetch = [&](int ch) {
+        int cb = ch * CCH + soct * 8;                                  // first channel of this thread's octet
+        const int emax = min(cin_eff - cb, 8) - 1;                     // last real channel of the octet (< 0: none)
+        bool in = s_in & (emax >= 0);
+        long zoff = 0;
+        if (ZB) {
+            const int dz = (cb >= a.cin) + (cb >= 2 * a.cin);          // a.cin % 8 == 0: the octet lies in one plane
+            cb -= dz * a.cin;
+            const int zz = zpl + dz - 1;
+            in &= (zz >= 0) & (zz < a.zcount);
+            zoff = (long)zz * hw;
+        }
+        const int c1 = cb - a.ch[0], c2 = c1 - a.ch[1];
+        const float* src = (c1 < 0) ? a.src[0] : (c2 < 0 ? a.src[1] : a.src[2]);
+        const int cl = (c1 < 0) ? cb : (c2 < 0 ? c1 : c2);
+        const float* base = in ? src + ((long)cl * a.cstride + zoff + s_off) : a.zeros;
+        const long step = in ? a.cstride : 0;
+        const float* q = base;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            int cg = ch * CCH + soct * 8 + e;
-            bool ok = (s_off >= 0) & (cg < cin_eff);
-            long zoff = 0;
-            if (ZB) {
-                const int dz = (cg >= a.cin) + (cg >= 2 * a.cin);
-                cg -= dz * a.cin;
-                const int zz = zpl + dz - 1;
-                ok &= (zz >= 0) & (zz < a.zcount);
-                zoff = (long)zz * hw;
-            }
-            const float* p = a.src[0];
-            if (cg >= a.ch[0]) {
-                cg -= a.ch[0];
-                p = a.src[1];
-                if (cg >= a.ch[1]) { cg -= a.ch[1]; p = a.src[2]; }
-            }
-            const float4 t = *reinterpret_cast<const float4*>(ok ? p + (long)cg * a.cstride + zoff + s_off : a.bias);
-            pa[e][0] = ok ? t.x : 0.0f;
-            pa[e][1] = ok ? t.y : 0.0f;
-            pa[e][2] = ok ? t.z : 0.0f;
-            pa[e][3] = ok ? t.w : 0.0f;
+            pa[e] = *reinterpret_cast<const f32x4*>(q);
+            q += (e < emax) ? step : 0;                                // channels past the last real one re-read it
         }
     };
     // A: split + transpose out of the prefetch registers.  B (pre-split by the host, L2-resident, identical for every
-    // workgroup) is copied global -> LDS here rather than held in registers across the multiply phase.
+    // workgroup) is copied global -> LDS (all its loads are issued before the first use; the LDS image is padded to whole
+    // 256-thread passes so the copy needs no predicate).
     auto stash = [&](int ch) {
-        float4 tb[NB4];
+        f32x4 tb[NB4];
 #pragma unroll
         for (int j = 0; j < NB4; ++j) {
             const int u = min(tid + j * 256, NBF - 1);
-            tb[j] = *reinterpret_cast<const float4*>(wbf + ((long)ch * NBF + u) * 8);
+            tb[j] = *reinterpret_cast<const f32x4*>(wbf + ((long)ch * NBF + u) * 8);
         }
         if (stager) {
 #pragma unroll
             for (int px = 0; px < 4; ++px) {
                 bf16x8 hi, lo;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    hi[e] = (__bf16)pa[e][px];
-                    lo[e] = (__bf16)(pa[e][px] - (float)hi[e]);
-                }
-                *reinterpret_cast<bf16x8*>(&lds_ah[s_lds + (px ^ s_sw) * 8]) = hi;
-                *reinterpret_cast<bf16x8*>(&lds_al[s_lds + (px ^ s_sw) * 8]) = lo;
+                split_octet(pa, px, hi, lo);
+                *reinterpret_cast<bf16x8*>(&lds_ah[s_lds + px * 8]) = hi;
+                *reinterpret_cast<bf16x8*>(&lds_al[s_lds + px * 8]) = lo;
             }
         }
 #pragma unroll
-        for (int j = 0; j < NB4; ++j) {
-            const int u = tid + j * 256;
-            if (u < NBF) *reinterpret_cast<float4*>(&lds_b[u * 8]) = tb[j];
-        }
+        for (int j = 0; j < NB4; ++j) *reinterpret_cast<f32x4*>(&lds_b[(tid + j * 256) * 8]) = tb[j];
     };
 
     // fragment addressing: lane (pixel li, quarter lk) owns item 4s + lk = (tap, octet) of K-step s
-    int aoff[MR][NKS];
+    int koff[NKS];
 #pragma unroll
     for (int s_ = 0; s_ < NKS; ++s_) {
         const int item = 4 * s_ + lk;
         const int tap = min(item >> 1, 8), oct = item & 1;               // items 18, 19 are padding (B is zero there)
-#pragma unroll
-        for (int m = 0; m < MR; ++m) {
-            const int p = (wv * MR + m + tap / 3) * AW + li + XOFF + tap % 3;
-            aoff[m][s_] = (oct * APIX + (p ^ ((p >> 3) & 1))) * 8;
-        }
+        koff[s_] = ((wv * MR + tap / 3) * AW + li + XOFF + tap % 3 + oct * APIX) * 8;
     }
 
     f32x4 acc[MR][NT];
@@ -613,8 +702,8 @@ __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs 
             bf16x8 ah[MR], al[MR];
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
-                ah[m] = *reinterpret_cast<const bf16x8*>(&lds_ah[aoff[m][s_]]);
-                al[m] = *reinterpret_cast<const bf16x8*>(&lds_al[aoff[m][s_]]);
+                ah[m] = *reinterpret_cast<const bf16x8*>(&lds_ah[koff[s_] + m * AW * 8]);
+                al[m] = *reinterpret_cast<const bf16x8*>(&lds_al[koff[s_] + m * AW * 8]);
             }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -622,9 +711,10 @@ __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs 
                 const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&lds_b[(((s_ * NT + n) * 2 + 1) * 64 + lane) * 8]);
 #pragma unroll
                 for (int m = 0; m < MR; ++m) {
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh, acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl, acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh, acc[m][n], 0, 0, 0);
+                    // weights x pixels: D[cout][pixel] (transposed fragment, see conv_epilogue_store_t)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[m], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[m], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[m], acc[m][n], 0, 0, 0);
                 }
             }
         }
@@ -635,22 +725,164 @@ __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs 
         }
     }
 
-    const int x = x0 + 4 * lk;
-    float lo = 0.0f, hi = 0.0f;
-    if (EPI == EFFI_EPI_HEAD) { lo = a.disp_range[0]; hi = a.disp_range[a.n_range - 1]; }
+    const int x = x0 + li;                                             // lane = (pixel li, channels 4*lk .. 4*lk+3)
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
         const int y = y0 + wv * MR + m;
         if (y >= h || x >= w) continue;
         const long pix = (long)y * w + x;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int co = n * 16 + li;
-            if (co >= a.cout) continue;
-            const float b = a.bias[co];
-            float v[4] = {acc[m][n][0] + b, acc[m][n][1] + b, acc[m][n][2] + b, acc[m][n][3] + b};
-            conv_epilogue_store<EPI, true>(a, v, co, x, y, pix, hw, zpl, lo, hi);
+        for (int n = 0; n < NT; ++n) conv_epilogue_store_t<EPI>(a, acc[m][n], n * 16 + 4 * lk, pix, hw, zpl);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stride-1 3-D convolution with a ROLLING window of input planes (split precision, same MFMA scheme as above).
+// The z-batched form above re-reads every input plane for each of the three output planes it contributes to; here a
+// workgroup owns an (x, y) tile and a run of ZT consecutive output planes, keeps planes z-1, z, z+1 of all input channels in
+// LDS (bf16 hi/lo, [slot][octet][pixel][8]) and fetches ONE new plane per output plane (into registers while the current
+// plane is multiplied).  cin = 8*NOCT (NOCT in {1, 2}; one or two sources of 8/16 channels), cout <= 16*NT.
+//   * K index = (dz, tap, octet): 27*NOCT items, 4 per K-step -> NKS = 7 (cin 8) or 14 (cin 16) K-steps; the whole B
+//     operand ([NKS][NT][hi|lo][64][8] bf16, 14-56 KB) is copied to LDS once per workgroup.
+//   * a lane's A fragment address = lane base + per-K-step constant + base of the slot that currently holds plane z+dz-1;
+//     the slot bases rotate with z and are re-selected once per plane (NKS selects), row offsets are immediates.
+// ------------------------------------------------------------------------------------------------
+template <int NOCT, int NT, int MR>
+__global__ __launch_bounds__(256) void conv3d_roll_bf16x3_kernel(const Conv2dArgs a, int tiles_x, int ntiles, int zt) {
+    constexpr int TR = 4 * MR, AR = TR + 2, AW = 24, AQ = 6, XOFF = 3, XLEFT = 4;
+    constexpr int APIX = AR * AW, NQ = APIX / 4, NITEMS = NQ * NOCT;
+    constexpr int NIT = 27 * NOCT, NKS = (NIT + 3) / 4;
+    constexpr int NBF = NKS * NT * 2 * 64;                             // 16-byte units of B
+    constexpr int SLOT = NOCT * APIX * 8;                              // bf16 elements per plane slot
+    static_assert(NITEMS <= 256, "one staging item per thread");
+    __shared__ __attribute__((aligned(16))) unsigned short lds_ah[3 * SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned short lds_al[3 * SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned short lds_b[NBF * 8];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int h = a.h, w = a.w, D = a.zcount;
+    const long hw = (long)h * w;
+    const int tile = effi_xcd_remap(blockIdx.x, gridDim.x);
+    if (tile >= ntiles) return;
+    const int ty_ = tile / tiles_x;
+    const int x0 = (tile - ty_ * tiles_x) * 16, y0 = ty_ * TR;
+    const int z0 = blockIdx.y * zt, z1 = min(z0 + zt, D);
+
+    // staging item of this thread: (pixel quad, octet); an octet never straddles the two sources (ch[0] % 8 == 0)
+    const bool stager = tid < NITEMS;
+    const int pq = stager ? tid % NQ : 0, soct = stager ? tid / NQ : 0;
+    const int srow = pq / AQ, sqx = pq - srow * AQ;
+    const int sgy = y0 - 1 + srow, sgx = x0 - XLEFT + 4 * sqx;
+    const int s_off = (stager & (sgy >= 0) & (sgy < h) & (sgx >= 0) & (sgx < w)) ? sgy * w + sgx : -1;
+    const int s_lds = (soct * APIX + srow * AW + 4 * sqx) * 8;
+    const float* s_src = (soct * 8 < a.ch[0]) ? a.src[0] + (long)(soct * 8) * a.cstride
+                                              : a.src[1] + (long)(soct * 8 - a.ch[0]) * a.cstride;     // stagers only: soct < NOCT
+
+    // two register buffers: the plane fetched for iteration z + 2 is in flight during iterations z and z + 1.  The buffers hold
+    // the RAW loads (padding comes from a zero page), so no load is consumed before its conversion.
+    f32x4 pa[2][8];
+    auto prefetch = [&](auto buf_t, int z) {
+        constexpr int bf = decltype(buf_t)::value;
+        const bool ok = (s_off >= 0) & (z >= 0) & (z < D);
+        const float* base = ok ? s_src + ((long)z * hw + s_off) : a.zeros;
+        const long step = ok ? a.cstride : 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pa[bf][e] = *reinterpret_cast<const f32x4*>(base + (long)e * step);
+    };
+    auto stash = [&](auto buf_t, int slot) {
+        constexpr int bf = decltype(buf_t)::value;
+        if (stager) {
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                bf16x8 hi, lo;
+                split_octet(pa[bf], px, hi, lo);
+                *reinterpret_cast<bf16x8*>(&lds_ah[slot * SLOT + s_lds + px * 8]) = hi;
+                *reinterpret_cast<bf16x8*>(&lds_al[slot * SLOT + s_lds + px * 8]) = lo;
+            }
         }
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+
+    // B: whole operand, once
+    {
+        const unsigned short* wbf = reinterpret_cast<const unsigned short*>(a.wpack);
+        for (int u = tid; u < NBF; u += 256)
+            *reinterpret_cast<float4*>(&lds_b[u * 8]) = *reinterpret_cast<const float4*>(wbf + (long)u * 8);
+    }
+
+    // per K-step constants of this lane: element offset inside a slot of item 4s + lk = (dz, tap, oct), dz in the low bits
+    int kconst[NKS];
+#pragma unroll
+    for (int s_ = 0; s_ < NKS; ++s_) {
+        const int item = min(4 * s_ + lk, NIT - 1);                    // padding items read valid data, their B is zero
+        const int oct = item % NOCT, dt = item / NOCT;
+        const int dz = dt / 9, tap = dt - dz * 9;
+        kconst[s_] = ((oct * APIX + (tap / 3) * AW + tap % 3) * 8) * 4 + dz;
+    }
+    const int lane_base = ((wv * MR) * AW + li + XOFF) * 8;
+
+    f32x4 acc[MR][NT];
+    prefetch(B0{}, z0 - 1);
+    prefetch(B1{}, z0);
+    stash(B0{}, 0);
+    prefetch(B0{}, z0 + 1);
+    stash(B1{}, 1);
+    prefetch(B1{}, z0 + 2);
+    int rot = 0;                                                       // slot holding plane z - 1
+    // one output plane: buffer `bt` holds plane z + 1 on entry and is refilled with plane z + 3
+    auto plane = [&](auto bt, int z) {
+        int s2 = rot + 2;
+        s2 -= (s2 >= 3) ? 3 : 0;
+        stash(bt, s2);                                                 // plane z + 1
+        __syncthreads();
+        if (z + 2 < z1) prefetch(bt, z + 3);
+        int s1 = rot + 1;
+        s1 -= (s1 >= 3) ? 3 : 0;
+        const int rb0 = rot * SLOT, rb1 = s1 * SLOT, rb2 = s2 * SLOT;
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s_ = 0; s_ < NKS; ++s_) {
+            const int dz = kconst[s_] & 3;
+            const int off = lane_base + (kconst[s_] >> 2) + (dz == 0 ? rb0 : (dz == 1 ? rb1 : rb2));
+            bf16x8 ah[MR], al[MR];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                ah[m] = *reinterpret_cast<const bf16x8*>(&lds_ah[off + m * AW * 8]);
+                al[m] = *reinterpret_cast<const bf16x8*>(&lds_al[off + m * AW * 8]);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&lds_b[(((s_ * NT + n) * 2 + 0) * 64 + lane) * 8]);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&lds_b[(((s_ * NT + n) * 2 + 1) * 64 + lane) * 8]);
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    // weights x pixels: D[cout][pixel] (transposed fragment, see conv_epilogue_store_t)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[m], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[m], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[m], acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+        const int x = x0 + li;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const int y = y0 + wv * MR + m;
+            if (y >= h || x >= w) continue;
+            const long pix = (long)y * w + x;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) conv_epilogue_store_t<EFFI_EPI_PLAIN>(a, acc[m][n], n * 16 + 4 * lk, pix, hw, z);
+        }
+        __syncthreads();                                               // all reads of slot `rot` done before it is refilled
+        rot = s1;
+    };
+    for (int z = z0; z < z1; z += 2) {
+        plane(B0{}, z);
+        if (z + 1 < z1) plane(B1{}, z + 1);
     }
 }
 
@@ -1016,8 +1248,8 @@ extern "C" int effi_conv2d_k5s2_f32(const float* in, int cin, const float* wpack
 
 // ---- split-bf16 3x3 convolution entry --------------------------------------------------------------------------
 // Rows per wave (MR): 4 rows amortise the B fragments best, but the grid must still cover the 256 CUs (>= ~400 workgroups),
-// and with two N-tiles the 4-row variant drops to 2 workgroups per CU (188 registers) where the 2-row one keeps 4:
-// on large maps the latter wins (measured, MI355X: 32->32 at 592x800 69 -> 57 us).
+// and with two N-tiles the 4-row variant drops to 2 workgroups per CU where the 2-row one keeps 4: on large maps the latter
+// wins.  (Persistent workgroups with cross-tile prefetch were built and measured twice: no gain, more registers.)
 template <int NT, int EPI, bool ZB = false>
 static int launch_bf16x3(const Conv2dArgs& a, hipStream_t st) {
     const long cols = effi_cdiv(a.w, 16);
@@ -1059,12 +1291,15 @@ extern "C" int effi_conv2d_k3_bf16x3_f32(const float* const* srcs, const int* sr
     Conv2dArgs a;
     a.cin = 0;
     for (int i = 0; i < EFFI_MAX_SRC; ++i) {
-        a.src[i] = (i < n_src) ? srcs[i] : nullptr;
+        a.src[i] = (i < n_src) ? srcs[i] : srcs[0];
         a.ch[i] = (i < n_src) ? src_channels[i] : 0;
         if (i < n_src && (!srcs[i] || src_channels[i] < 1)) return EFFI_ERR_BADARG;
+        if (i + 1 < n_src && (src_channels[i] & 7)) return EFFI_ERR_UNSUPPORTED;   // an octet of channels lies in one source
         a.cin += a.ch[i];
     }
     a.kgroups = (a.cin + 3) / 4;
+    a.zeros = effi_zero_page();
+    if (!a.zeros) return EFFI_ERR_LAUNCH;
     a.wpack = reinterpret_cast<const float*>(wpack_bf16);
     a.bias = bias;
     a.cout = cout;
@@ -1115,12 +1350,16 @@ extern "C" int effi_conv3d_k3s1_bf16x3_f32(const float* const* srcs, const int* 
     Conv2dArgs a;
     a.cin = 0;
     for (int i = 0; i < EFFI_MAX_SRC; ++i) {
-        a.src[i] = (i < n_src) ? srcs[i] : nullptr;
+        a.src[i] = (i < n_src) ? srcs[i] : srcs[0];
         a.ch[i] = (i < n_src) ? src_channels[i] : 0;
         if (i < n_src && (!srcs[i] || src_channels[i] < 1)) return EFFI_ERR_BADARG;
+        if (i + 1 < n_src && (src_channels[i] & 7)) return EFFI_ERR_UNSUPPORTED;
         a.cin += a.ch[i];
     }
+    if (a.cin & 7) return EFFI_ERR_UNSUPPORTED;            // an octet of (plane, channel) lies in one plane
     a.kgroups = 0;
+    a.zeros = effi_zero_page();
+    if (!a.zeros) return EFFI_ERR_LAUNCH;
     a.wpack = reinterpret_cast<const float*>(wpack_bf16);
     a.bias = bias;
     a.cout = cout;
@@ -1140,6 +1379,61 @@ extern "C" int effi_conv3d_k3s1_bf16x3_f32(const float* const* srcs, const int* 
         case 2: return launch_bf16x3<2, EFFI_EPI_PLAIN, true>(a, st);
         default: return EFFI_ERR_UNSUPPORTED;
     }
+}
+
+template <int NOCT, int NT>
+static int launch_roll(const Conv2dArgs& a, hipStream_t st) {
+    // rows per wave: 4 when the tile count still covers the chip and the LDS image leaves two workgroups per CU
+    // (cin 8), else 2; planes per workgroup: as many as keep >= ~3 workgroups per CU in flight (fewer re-read planes)
+    const int cols = effi_cdiv(a.w, 16);
+    const long t4 = (long)cols * effi_cdiv(a.h, 16);
+    const int mr = (NOCT == 1 && t4 * effi_cdiv(a.zcount, 8) >= 400) ? 4 : 2;
+    const long tiles = (long)cols * effi_cdiv(a.h, 4 * mr);
+    int zt = a.zcount;
+    while (zt > 2 && tiles * effi_cdiv(a.zcount, zt) < 768) zt = (zt + 1) / 2;
+    static const char* fz = getenv("EFFI_ROLL_ZT");
+    if (fz) zt = atoi(fz);
+    const dim3 grid((unsigned)tiles, (unsigned)effi_cdiv(a.zcount, zt));
+    if (mr == 4) hipLaunchKernelGGL((conv3d_roll_bf16x3_kernel<NOCT, NT, 4>), grid, dim3(256), 0, st, a, cols, (int)tiles, zt);
+    else hipLaunchKernelGGL((conv3d_roll_bf16x3_kernel<NOCT, NT, 2>), grid, dim3(256), 0, st, a, cols, (int)tiles, zt);
+    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+}
+
+extern "C" int effi_conv3d_k3s1_roll_bf16x3_f32(const float* const* srcs, const int* src_channels, int n_src,
+                                                const void* wpack_bf16, const float* bias, int cout, int D, int h, int w,
+                                                int relu, float* out, effi_stream_t stream) {
+    if (!srcs || !src_channels || n_src < 1 || n_src > 2 || !wpack_bf16 || !bias || !out) return EFFI_ERR_BADARG;
+    if (cout < 1 || D < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    Conv2dArgs a;
+    a.cin = 0;
+    for (int i = 0; i < EFFI_MAX_SRC; ++i) {
+        a.src[i] = (i < n_src) ? srcs[i] : nullptr;
+        a.ch[i] = (i < n_src) ? src_channels[i] : 0;
+        if (i < n_src && (!srcs[i] || src_channels[i] < 1)) return EFFI_ERR_BADARG;
+        a.cin += a.ch[i];
+    }
+    if ((w & 3) || (a.cin != 8 && a.cin != 16) || (a.ch[0] & 7) || cout > 32) return EFFI_ERR_UNSUPPORTED;
+    if (n_src == 1) a.src[1] = a.src[0];
+    a.kgroups = 0;
+    a.zeros = effi_zero_page();
+    if (!a.zeros) return EFFI_ERR_LAUNCH;
+    a.wpack = reinterpret_cast<const float*>(wpack_bf16);
+    a.bias = bias;
+    a.cout = cout;
+    a.h = a.hin = h;
+    a.w = a.win = w;
+    a.act = relu ? EFFI_ACT_RELU : EFFI_ACT_NONE;
+    a.hd = 0;
+    a.aux0 = a.aux1 = a.disp_range = nullptr;
+    a.n_range = 0;
+    a.out0 = out;
+    a.out1 = nullptr;
+    a.cstride = a.ostride = (long)D * h * w;
+    a.zcount = D;
+    hipStream_t st = effi_s(stream);
+    const int nt = (cout + 15) / 16;
+    if (a.cin == 8) return nt == 1 ? launch_roll<1, 1>(a, st) : launch_roll<1, 2>(a, st);
+    return nt == 1 ? launch_roll<2, 1>(a, st) : launch_roll<2, 2>(a, st);
 }
 
 extern "C" int effi_conv2d_c1k7_relu_f32(const float* in, const float* weight, const float* bias, int cout, int h,

@@ -53,6 +53,7 @@ class Conv3d(nn.Module):
         self._cache = packing.PackCache()
         self._cache_planes = packing.PackCache()
         self._cache_planes_x3 = packing.PackCache()
+        self._cache_roll = packing.PackCache()
 
     def _packed(self):
         t = [self.conv.weight, self.conv.bias]
@@ -66,6 +67,16 @@ class Conv3d(nn.Module):
         if _triple(self.conv.kernel_size) != (3, 3, 3) or _triple(self.conv.padding) != (1, 1, 1):
             raise NotImplementedError("Conv3d: only kernel 3 / padding 1 is instantiated on the HIP path")
         t = None
+        cin_total = sum(x.shape[0] for x in srcs)
+        if (skip is None and _triple(self.conv.stride) == (1, 1, 1) and 1 < self.out_channels <= 32 and len(srcs) <= 2
+                and cin_total in (8, 16) and srcs[0].shape[0] % 8 == 0 and srcs[0].shape[-1] % 4 == 0
+                and ops.get_precision() == "split"):
+            # 8 / 16 input channels: rolling window of input planes in LDS, each plane fetched once
+            t = [self.conv.weight, self.conv.bias]
+            if self.bn is not None:
+                t += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
+            wp, bp = self._cache_roll.get(t, lambda: packing.pack_conv3d_roll_bf16x3(self.conv, self.bn))
+            return ops.conv3d_k3s1_roll(srcs, wp, bp, self.out_channels, relu=self.relu)
         if (skip is None and _triple(self.conv.stride) == (1, 1, 1) and 1 < self.out_channels <= 32
                 and self.conv.in_channels >= 8 and srcs[0].shape[-1] % 4 == 0 and ops.get_precision() == "split"):
             # stride-1 layers with >= 8 input channels: z-batched 2-D convolutions on the bf16 matrix cores in split

@@ -279,6 +279,21 @@ def conv3d_k3s1_bf16x3(srcs, wpack, bias, cout, relu=True):
     return out
 
 
+def conv3d_k3s1_roll(srcs, wpack, bias, cout, relu=True):
+    """srcs: one or two planar [Ci,D,h,w] tensors, 8 or 16 channels in total; stride-1 3-D conv with a rolling window of
+    input planes in split precision (``packing.pack_conv3d_roll_bf16x3``) -> [cout,D,h,w].  w % 4 == 0, cout <= 32."""
+    for s in srcs:
+        _t(s, "conv3d input")
+    _, D, h, w = srcs[0].shape
+    cin = sum(s.shape[0] for s in srcs)
+    out = torch.empty(cout, D, h, w, device=srcs[0].device, dtype=torch.float32)
+    work = lambda: {"flops": 2.0 * 27 * cin * cout * D * h * w, "bytes": 4.0 * (cin + cout) * D * h * w}
+    check(_call(f"conv3d_roll_c{cin}_{cout}", work, _lib.lib().effi_conv3d_k3s1_roll_bf16x3_f32, _ptr_array(srcs),
+                _int_array([s.shape[0] for s in srcs]), len(srcs), _p(wpack), _p(bias), cout, D, h, w, int(relu), _p(out),
+                _stream()), "effi_conv3d_k3s1_roll_bf16x3_f32")
+    return out
+
+
 def deconv3d_k3(x, weight, bias, cout, sz=2, relu=True, skip=None):
     _t(x, "deconv3d input")
     cin, D, h, w = x.shape
@@ -408,7 +423,8 @@ def conv2d(srcs, wpack, bias, cout, ks, epilogue=EPI_PLAIN, act=ACT_NONE, aux0=N
     cin = sum(s.shape[0] for s in srcs)
     if hasattr(wpack, "w32"):                 # packing.Conv2dWeights: both operand orders, pick the arithmetic here
         if (_PRECISION == "split" and wpack.wx is not None and ks == 3 and w % 4 == 0
-                and epilogue in (EPI_PLAIN, EPI_NHWC, EPI_GRU_ZR, EPI_GRU_Q)):
+                and epilogue in (EPI_PLAIN, EPI_NHWC, EPI_GRU_ZR, EPI_GRU_Q)
+                and all(s.shape[0] % 8 == 0 for s in srcs[:-1])):
             return conv2d_k3_bf16x3(srcs, wpack.wx, bias, cout, epilogue=epilogue, act=act, aux0=aux0, aux1=aux1,
                                     out0=out0, out1=out1)
         wpack = wpack.w32
@@ -421,7 +437,8 @@ def conv2d(srcs, wpack, bias, cout, ks, epilogue=EPI_PLAIN, act=ACT_NONE, aux0=N
 
 def conv2d_k3_bf16x3(srcs, wpack, bias, cout, epilogue=EPI_PLAIN, act=ACT_NONE, aux0=None, aux1=None, out0=None, out1=None):
     """3x3 convolution in split precision (hi*hi + hi*lo + lo*hi on the bf16 MFMA, fp32 accumulate); ``wpack`` from
-    ``packing.pack_conv2d_bf16x3``.  Same sources / epilogues as ``conv2d`` (PLAIN, NHWC, GRU_ZR, GRU_Q); w % 4 == 0."""
+    ``packing.pack_conv2d_bf16x3``.  Same sources / epilogues as ``conv2d`` (PLAIN, NHWC, GRU_ZR, GRU_Q); w % 4 == 0 and every
+    source but the last has a multiple of 8 channels (otherwise the library reports UNSUPPORTED)."""
     for s in srcs:
         _t(s, "conv2d input")
     h, w = srcs[0].shape[-2:]

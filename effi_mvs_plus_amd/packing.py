@@ -77,6 +77,34 @@ def pack_conv3d_planes_bf16x3(conv, bn):
     return pack_conv2d_bf16x3(w2, bias)
 
 
+def pack_conv3d_roll_bf16x3(conv, bn):
+    """nn.Conv3d [cout,cin,3,3,3] (+BN), cin in {8,16}, for the rolling-window split-bf16 kernel:
+    K index = (kd, ky, kx, octet, e); K-step s takes items 4s..4s+3 of (kd, ky, kx, octet); lane = q*16 + j holds
+    W[16n+j][oct*8+e][kd][ky][kx] for item 4s+q.  -> (bf16 [NKS, NT, 2, 64, 8], bias fp32 [16*NT])."""
+    w = conv.weight
+    bias = conv.bias
+    if bn is not None:
+        scale, shift = bn_scale_shift(bn)
+        w = w * scale.view(-1, 1, 1, 1, 1)
+        bias = shift if bias is None else bias * scale + shift
+    cout, cin = w.shape[0], w.shape[1]
+    assert cin in (8, 16)
+    noct, nt = cin // 8, (cout + 15) // 16
+    nit = 27 * noct
+    nks = (nit + 3) // 4
+    wz = torch.zeros(nt * 16, 4 * nks, 8, device=w.device, dtype=torch.float32)          # [cout, item, e]
+    # [cout, cin, 27] -> [cout, 27, oct, e] -> items (tap3d, oct)
+    wz[:cout, :nit] = w.reshape(cout, noct, 8, 27).permute(0, 3, 1, 2).reshape(cout, nit, 8).float()
+    wz = wz.view(nt, 16, nks, 4, 8).permute(2, 0, 3, 1, 4).contiguous()                  # [s, n, q, j, e]
+    hi = wz.to(torch.bfloat16)
+    lo = (wz - hi.float()).to(torch.bfloat16)
+    wp = torch.stack([hi, lo], dim=2).contiguous().view(nks, nt, 2, 64, 8)
+    b = torch.zeros(nt * 16, device=w.device, dtype=torch.float32)
+    if bias is not None:
+        b[:cout] = bias.float()
+    return wp, b
+
+
 def pack_deconv3d(conv, bn):
     """nn.ConvTranspose3d [cin,cout,3,3,3] (+BN) -> (weight [cin,27,cout], bias [cout] or None)."""
     w = conv.weight

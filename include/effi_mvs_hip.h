@@ -123,6 +123,13 @@ int effi_conv3d_k3s1_mfma_f32(const float* in, int cin, const float* wpack, cons
 int effi_conv3d_k3s1_bf16x3_f32(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
                                 const float* bias, int cout, int D, int h, int w, int relu, float* out,
                                 effi_stream_t stream);
+/* Same operator for cin in {8, 16} (one or two sources, the first with a multiple of 8 channels), cout <= 32, w % 4 == 0,
+ * with a rolling window of input planes: a workgroup walks a run of output planes and fetches each input plane once
+ * instead of three times.  wpack_bf16 = [ceil(27*cin/32)][ceil(cout/16)][hi|lo][64][8] bf16 with K index
+ * ((kd*9 + ky*3 + kx) * cin/8 + ci/8) * 8 + ci%8 (packing.pack_conv3d_roll_bf16x3); bias [16*ceil(cout/16)]. */
+int effi_conv3d_k3s1_roll_bf16x3_f32(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
+                                     const float* bias, int cout, int D, int h, int w, int relu, float* out,
+                                     effi_stream_t stream);
 /* Transposed 3-D convolution, kernel 3, padding 1, stride (sz,2,2), output_padding (sz-1,1,1):
  * out dims (sz*D, 2h, 2w).  models/module.py:448-450 (sz=2), :508 (sz=1).
  * in planar [cin][D][h][w]; weight [cin][kd][ky][kx][cout] (host-packed from torch's

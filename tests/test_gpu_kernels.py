@@ -176,7 +176,8 @@ def _rand_bn(bn, g):
     (1, 8, (1, 2, 2), (5, 18, 66)),
     # matrix-core path (cout 16/32, stride 1): aligned and unaligned rows, every rows-per-wave variant, real U-Net shapes
     (16, 16, 1, (6, 12, 40)), (32, 32, 1, (4, 8, 52)), (16, 16, 1, (24, 74, 100)), (32, 32, 1, (12, 37, 50)),
-    (16, 16, 1, (48, 40, 64)), (8, 8, 1, (8, 37, 48)), (1, 8, 1, (8, 148, 200))])
+    (16, 16, 1, (48, 40, 64)), (8, 8, 1, (8, 37, 48)), (1, 8, 1, (8, 148, 200)),
+    (8, 8, 1, (48, 148, 200)), (8, 16, 1, (7, 30, 52)), (16, 32, 1, (5, 20, 36))])
 def test_conv3d_block(cin, cout, stride, dims, precision):
     from effi_mvs_plus_amd.models.module import Conv3d
     g = torch.Generator().manual_seed(cin * 100 + cout)
@@ -388,7 +389,7 @@ def test_conv2d_generic(ks, cins, cout, act):
 
 
 @pytest.mark.parametrize("h,w", [(21, 28), (130, 256), (256, 512)])      # rows-per-wave 1, 2 and 4
-@pytest.mark.parametrize("cins,cout,epi", [((5,), 7, 0), ((16,), 16, 0), ((16, 16), 12, 0), ((17, 3, 9), 20, 0), ((48,), 48, 5),
+@pytest.mark.parametrize("cins,cout,epi", [((5,), 7, 0), ((16,), 16, 0), ((16, 16), 12, 0), ((24, 8, 12), 20, 0), ((48,), 48, 5),
                                            ((16, 16), 32, 1), ((48, 48), 96, 1), ((32, 32), 32, 2), ((64,), 64, 0)])
 def test_conv2d_split_bf16(h, w, cins, cout, epi):
     """Split-precision (bf16x3) 3x3 conv against an fp64 F.conv2d: every product carries ~2^-16 relative error, so the
@@ -422,6 +423,27 @@ def test_conv2d_split_bf16(h, w, cins, cout, epi):
         got = ops.conv2d_k3_bf16x3(dx, wp, bp, cout, epilogue=ops.EPI_GRU_Q, aux0=t(hprev, DEV), aux1=t(z, DEV))
         want = (1 - z.double()) * hprev.double() + z.double() * torch.tanh(y)
         check_close("bf16x3 gru q", got, want.float(), **tol)
+
+
+def test_conv2d_split_bf16_refuses_unaligned_sources():
+    """An octet of input channels must lie in one source: (17, 3) is refused by the library, and ops.conv2d keeps such
+    layers on the fp32 kernel."""
+    from effi_mvs_plus_amd import ops, packing
+    from effi_mvs_plus_amd._lib import EffiLibraryError
+    xs = [torch.randn(17, 8, 8).to(DEV), torch.randn(3, 8, 8).to(DEV)]
+    wt = torch.randn(16, 20, 3, 3).to(DEV)
+    wx, bx = packing.pack_conv2d_bf16x3(wt, None)
+    with pytest.raises(EffiLibraryError):
+        ops.conv2d_k3_bf16x3(xs, wx, bx, 16)
+    w2, b2 = packing.pack_conv2d(wt, None)
+    before = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        got = ops.conv2d(xs, w2, b2, 16, 3)
+    finally:
+        ops.set_precision(before)
+    check_close("unaligned sources fall back to fp32 MFMA", got, F.conv2d(torch.cat(xs).unsqueeze(0), wt, padding=1)[0].cpu(),
+                rtol=1e-4, atol=1e-5)
 
 
 @pytest.mark.parametrize("h,w", [(36, 60), (256, 256), (256, 512)])      # rows-per-wave 1, 2 and 4 of the v2 kernel
