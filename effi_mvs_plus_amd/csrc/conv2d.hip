@@ -36,7 +36,8 @@ struct Conv2dArgs {
     // source s is plane z + s - 1 of the SAME [cin][D][h][w] tensor (zero when outside), channel strides are D*h*w
     long cstride;            // input channel stride in floats (hin*win for plain 2-D)
     long ostride;            // output channel stride
-    int zcount;              // D when z-batched, else 0
+    int zcount;              // output planes when z-batched, else 0
+    int zin;                 // input planes (= zcount for stride 1; stride-2 3-D convs read a 2x deeper volume)
     int hin, win;            // input map size (= h, w for stride 1; stride-2 convs read a 2x larger map)
     const float* zeros;      // >= 64 B of zeros in device memory: where padding is read from (split-precision kernels)
 };
@@ -427,10 +428,10 @@ __global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a,
                 if (cg >= a.ch[1]) { cg -= a.ch[1]; srci = 2; }
             }
             const float* p = (srci == 0) ? a.src[0] : (srci == 1 ? a.src[1] : a.src[2]);
-            if (a.zcount) {                                   // source s = plane z + s - 1
-                const int zz = zpl + srci - 1;
-                ok &= (zz >= 0) & (zz < a.zcount);
-                p += (long)max(min(zz, a.zcount - 1), 0) * hwin;
+            if (a.zcount) {                                   // source s = input plane S*z + s - 1
+                const int zz = S * zpl + srci - 1;
+                ok &= (zz >= 0) & (zz < a.zin);
+                p += (long)max(min(zz, a.zin - 1), 0) * hwin;
             }
             if (ALIGNED) {
                 const float4 t = *reinterpret_cast<const float4*>(ok ? p + (long)cg * a.cstride + a_off[j] : a.wpack);
@@ -1109,10 +1110,58 @@ extern "C" int effi_conv3d_k3s1_mfma_f32(const float* in, int cin, const float* 
     a.out1 = nullptr;
     a.cstride = (long)D * h * w;
     a.ostride = (long)D * h * w;
-    a.zcount = D;
+    a.zcount = a.zin = D;
     a.hin = h;
     a.win = w;
     return cout == 16 ? dispatch3d_planes<1>(a, effi_s(stream)) : dispatch3d_planes<2>(a, effi_s(stream));
+}
+
+// Stride-2 form (models/module.py:442,445: conv2 8->16, conv4 16->32): output plane z reads input planes 2z-1, 2z, 2z+1.
+template <int NT, int MR, bool ALIGNED>
+static int launch3d_planes_s2(const Conv2dArgs& a, hipStream_t st) {
+    const int tiles_x = effi_cdiv(a.w, 16), ntiles = tiles_x * effi_cdiv(a.h, 4 * MR);
+    hipLaunchKernelGGL((conv2d_mfma_v2_kernel<3, NT, MR, EFFI_EPI_PLAIN, 8, false, ALIGNED, 2>), dim3(ntiles, a.zcount), dim3(256), 0,
+                       st, a, tiles_x, ntiles);
+    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+}
+
+template <int NT>
+static int dispatch3d_planes_s2(const Conv2dArgs& a, hipStream_t st) {
+    const long cols = effi_cdiv(a.w, 16);
+    const bool al = (a.win & 3) == 0 && (a.w & 3) == 0;
+    if (cols * effi_cdiv(a.h, 8) * a.zcount >= 512) return al ? launch3d_planes_s2<NT, 2, true>(a, st) : launch3d_planes_s2<NT, 2, false>(a, st);
+    return al ? launch3d_planes_s2<NT, 1, true>(a, st) : launch3d_planes_s2<NT, 1, false>(a, st);
+}
+
+extern "C" int effi_conv3d_k3s2_mfma_f32(const float* in, int cin, const float* wpack, const float* bias, int cout, int D,
+                                         int h, int w, int relu, float* out, effi_stream_t stream) {
+    if (!in || !wpack || !bias || !out || cin < 1 || D < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    if (cout != 16 && cout != 32) return EFFI_ERR_UNSUPPORTED;
+    Conv2dArgs a;
+    for (int i = 0; i < EFFI_MAX_SRC; ++i) {       // source s = input plane 2z + s - 1 of the same tensor
+        a.src[i] = in;
+        a.ch[i] = cin;
+    }
+    a.cin = 3 * cin;
+    a.kgroups = (a.cin + 3) / 4;
+    a.wpack = wpack;
+    a.bias = bias;
+    a.cout = cout;
+    a.hin = h;
+    a.win = w;
+    a.h = (h - 1) / 2 + 1;
+    a.w = (w - 1) / 2 + 1;
+    a.zin = D;
+    a.zcount = (D - 1) / 2 + 1;
+    a.act = relu ? EFFI_ACT_RELU : EFFI_ACT_NONE;
+    a.hd = 0;
+    a.aux0 = a.aux1 = a.disp_range = nullptr;
+    a.n_range = 0;
+    a.out0 = out;
+    a.out1 = nullptr;
+    a.cstride = (long)D * h * w;
+    a.ostride = (long)a.zcount * a.h * a.w;
+    return cout == 16 ? dispatch3d_planes_s2<1>(a, effi_s(stream)) : dispatch3d_planes_s2<2>(a, effi_s(stream));
 }
 
 extern "C" int effi_conv2d_f32(const float* const* srcs, const int* src_channels, int n_src, const float* wpack,
@@ -1387,7 +1436,9 @@ static int launch_roll(const Conv2dArgs& a, hipStream_t st) {
     // (cin 8), else 2; planes per workgroup: as many as keep >= ~3 workgroups per CU in flight (fewer re-read planes)
     const int cols = effi_cdiv(a.w, 16);
     const long t4 = (long)cols * effi_cdiv(a.h, 16);
-    const int mr = (NOCT == 1 && t4 * effi_cdiv(a.zcount, 8) >= 400) ? 4 : 2;
+    int mr = (NOCT == 1 && t4 * effi_cdiv(a.zcount, 8) >= 400) ? 4 : 2;
+    static const char* fm = getenv("EFFI_ROLL_MR");
+    if (fm) mr = atoi(fm);
     const long tiles = (long)cols * effi_cdiv(a.h, 4 * mr);
     int zt = a.zcount;
     while (zt > 2 && tiles * effi_cdiv(a.zcount, zt) < 768) zt = (zt + 1) / 2;

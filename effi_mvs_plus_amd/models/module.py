@@ -94,6 +94,14 @@ class Conv3d(nn.Module):
                 t += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
             wp, bp = self._cache_planes.get(t, lambda: packing.pack_conv3d_planes(self.conv, self.bn))
             return ops.conv3d_k3s1_mfma(srcs[0], wp, bp, self.out_channels, relu=self.relu)
+        if (len(srcs) == 1 and skip is None and _triple(self.conv.stride) == (2, 2, 2) and self.out_channels in (16, 32)
+                and self.conv.in_channels >= 8):
+            # down-sampling U-Net levels: z-batched stride-2 2-D convolutions on the matrix cores
+            t = [self.conv.weight, self.conv.bias]
+            if self.bn is not None:
+                t += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
+            wp, bp = self._cache_planes.get(t, lambda: packing.pack_conv3d_planes(self.conv, self.bn))
+            return ops.conv3d_k3s2_mfma(srcs[0], wp, bp, self.out_channels, relu=self.relu)
         w, b = self._packed()
         return ops.conv3d_k3(srcs, w, b, self.out_channels, stride=_triple(self.conv.stride), relu=self.relu, skip=skip)
 

@@ -294,6 +294,18 @@ def conv3d_k3s1_roll(srcs, wpack, bias, cout, relu=True):
     return out
 
 
+def conv3d_k3s2_mfma(x, wpack, bias, cout, relu=True):
+    """x planar [cin,D,h,w]; stride-(2,2,2) 3-D conv as z-batched stride-2 2-D MFMA convs -> [cout,Do,ho,wo]."""
+    _t(x, "conv3d input")
+    cin, D, h, w = x.shape
+    Do, ho, wo = (D - 1) // 2 + 1, (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = torch.empty(cout, Do, ho, wo, device=x.device, dtype=torch.float32)
+    work = lambda: {"flops": 2.0 * 27 * cin * cout * Do * ho * wo, "bytes": 4.0 * (cin * D * h * w + cout * Do * ho * wo)}
+    check(_call(f"conv3d_mfma_s2_nt{cout // 16}", work, _lib.lib().effi_conv3d_k3s2_mfma_f32, _p(x), cin, _p(wpack), _p(bias), cout,
+                D, h, w, int(relu), _p(out), _stream()), "effi_conv3d_k3s2_mfma_f32")
+    return out
+
+
 def deconv3d_k3(x, weight, bias, cout, sz=2, relu=True, skip=None):
     _t(x, "deconv3d input")
     cin, D, h, w = x.shape

@@ -116,6 +116,10 @@ int effi_conv3d_k3_f32(const float* const* srcs, const int* src_channels, int n_
  * as [cout][3*cin][3][3] with input channel index kd*cin + ci; bias [cout]; out planar [cout][D][h][w]. */
 int effi_conv3d_k3s1_mfma_f32(const float* in, int cin, const float* wpack, const float* bias, int cout,
                               int D, int h, int w, int relu, float* out, effi_stream_t stream);
+/* Stride-(2,2,2) form of the same operator (models/module.py:442,445), cout in {16,32}: in planar [cin][D][h][w],
+ * out planar [cout][(D-1)/2+1][(h-1)/2+1][(w-1)/2+1]; same weight packing. */
+int effi_conv3d_k3s2_mfma_f32(const float* in, int cin, const float* wpack, const float* bias, int cout,
+                              int D, int h, int w, int relu, float* out, effi_stream_t stream);
 /* Same operator (stride 1, cout <= 32, w % 4 == 0) in split precision: products as hi*hi + hi*lo + lo*hi on the bf16
  * matrix cores with fp32 accumulation (see effi_conv2d_k3_bf16x3_f32).  Input = channel concatenation of n_src planar
  * tensors [Ci][D][h][w] (models/module.py:513); wpack_bf16 = split-bf16 packing of the weight viewed as

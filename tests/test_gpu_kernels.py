@@ -177,7 +177,9 @@ def _rand_bn(bn, g):
     # matrix-core path (cout 16/32, stride 1): aligned and unaligned rows, every rows-per-wave variant, real U-Net shapes
     (16, 16, 1, (6, 12, 40)), (32, 32, 1, (4, 8, 52)), (16, 16, 1, (24, 74, 100)), (32, 32, 1, (12, 37, 50)),
     (16, 16, 1, (48, 40, 64)), (8, 8, 1, (8, 37, 48)), (1, 8, 1, (8, 148, 200)),
-    (8, 8, 1, (48, 148, 200)), (8, 16, 1, (7, 30, 52)), (16, 32, 1, (5, 20, 36))])
+    (8, 8, 1, (48, 148, 200)), (8, 16, 1, (7, 30, 52)), (16, 32, 1, (5, 20, 36)),
+    # stride-2 levels on the matrix cores: real U-Net shapes and odd sizes
+    (8, 16, 2, (48, 148, 200)), (16, 32, 2, (24, 74, 100)), (8, 16, 2, (7, 15, 21)), (16, 32, 2, (5, 9, 34))])
 def test_conv3d_block(cin, cout, stride, dims, precision):
     from effi_mvs_plus_amd.models.module import Conv3d
     g = torch.Generator().manual_seed(cin * 100 + cout)
