@@ -27,6 +27,7 @@ SIGNATURES = {
     "effi_view_aggregate_f32": [_vp, _vp, _i, _i, _i, _vp, _vp],
     "effi_warpcorr_dyn_f32": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "effi_conv3d_k3_f32": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "effi_deconv3d_k3s2_bf16x3_f32": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "effi_conv3d_k3s2_mfma_f32": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "effi_conv3d_k3s1_mfma_f32": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "effi_deconv3d_k3_f32": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],

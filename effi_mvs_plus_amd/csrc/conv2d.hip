@@ -888,6 +888,174 @@ __global__ __launch_bounds__(256) void conv3d_roll_bf16x3_kernel(const Conv2dArg
 }
 
 // ------------------------------------------------------------------------------------------------
+// Transposed 3-D convolution, kernel 3 / stride 2 / padding 1 / output_padding 1 (U-Net up-sampling levels,
+// models/module.py:448-450) on the bf16 matrix cores in split precision.
+// Per dimension out[2i] = in[i]*W[1] and out[2i+1] = in[i]*W[2] + in[i+1]*W[0].  With output parity P = (pz,py,px) and input
+// neighbour N = (nz,ny,nx) in {0,1}^3 the layer is ONE GEMM per input position: M = 16 input pixels of a row,
+// N = cout per parity (8 parity tiles of 16), K = (neighbour, cin); only neighbours N <= P contribute (27 of 64 blocks), and a
+// K-step (nz,ny; both nx; 16 channels) is skipped for the parities it cannot reach (18 of 32 K-step x parity pairs remain).
+// A tile in LDS: planes z, z+1 x (TR+1) rows x 20 columns x 16 channels (hi/lo bf16); B: the 18 fragments of the chunk.
+// Epilogue: the two x-parities of a channel sit in two accumulators of the same lane -> one float2 store per channel row,
+// 16 lanes = 128 contiguous bytes of the output row; bias, ReLU and the skip tensor (added after the ReLU) are fused.
+// ------------------------------------------------------------------------------------------------
+struct DeconvArgs {
+    const float* in;
+    const void* wpack;       // bf16 [cin/16][18][hi|lo][64][8]
+    const float* bias;       // [16]
+    const float* skip;       // [cout][2D][2h][2w] or null
+    const float* zeros;
+    float* out;
+    int cin, cout, D, h, w, relu;
+};
+
+__host__ __device__ constexpr bool deconv_step_used(int p, int s) { return (s & ~(p >> 1)) == 0; }
+__host__ __device__ constexpr int deconv_slot(int p, int s) {
+    int n = 0;
+    for (int pp = 0; pp < 8; ++pp)
+        for (int ss = 0; ss < 4; ++ss) {
+            if (pp == p && ss == s) return n;
+            if (deconv_step_used(pp, ss)) ++n;
+        }
+    return n;
+}
+
+template <int MR, bool ALIGNED>
+__global__ __launch_bounds__(256) void deconv3d_s2_bf16x3_kernel(const DeconvArgs a, int tiles_x, int tiles_xy) {
+    constexpr int TR = 4 * MR, AR = TR + 1, AW = 20, AQ = 5, APIX = AR * AW, NQ = APIX / 4;
+    constexpr int NITEMS = 4 * NQ;                                     // (octet, plane, pixel quad)
+    constexpr int NSLOT = 18, NBF = NSLOT * 2 * 64;                    // 16-byte units of B per chunk
+    static_assert(NITEMS <= 256, "one staging item per thread");
+    __shared__ __attribute__((aligned(16))) unsigned short lds_ah[4 * APIX * 8];     // [plane][octet][pixel][8]
+    __shared__ __attribute__((aligned(16))) unsigned short lds_al[4 * APIX * 8];
+    __shared__ __attribute__((aligned(16))) unsigned short lds_b[NBF * 8];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int h = a.h, w = a.w, D = a.D;
+    const long hw = (long)h * w, cstride = (long)D * hw;
+    const int z = blockIdx.y;
+    const int t = blockIdx.x;
+    const int ty_ = t / tiles_x;
+    const int x0 = (t - ty_ * tiles_x) * 16, y0 = ty_ * TR;
+
+    // staging item
+    const bool stager = tid < NITEMS;
+    const int it = stager ? tid : 0;
+    const int quad = it % NQ, pl = (it / NQ) & 1, soct = it / (2 * NQ);
+    const int srow = quad / AQ, sqx = quad - srow * AQ;
+    const int gy = y0 + srow, gx = x0 + 4 * sqx, gz = z + pl;
+    const bool rowin = stager & (gy < h) & (gz < D);
+    const long s_off = (long)gz * hw + (long)gy * w + gx;
+    const int s_lds = ((pl * 2 + soct) * APIX + srow * AW + 4 * sqx) * 8;
+
+    int koff[4];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+        const int nz = s_ >> 1, ny = s_ & 1, nx = lk >> 1, oct = lk & 1;
+        koff[s_] = ((nz * 2 + oct) * APIX + (wv * MR + ny) * AW + li + nx) * 8;
+    }
+
+    f32x4 acc[MR][8];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) acc[m][p] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const unsigned short* wbf = reinterpret_cast<const unsigned short*>(a.wpack);
+    const int nchunks = a.cin / 16;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if (ch) __syncthreads();
+        // ---- A: 8 channels x 4 pixels per stager, padding from the zero page ----
+        f32x4 pa[8];
+        {
+            const float* base = a.in + (long)(ch * 16 + soct * 8) * cstride + s_off;
+            if (ALIGNED) {                                             // w % 4 == 0: a quad is inside or outside as a whole
+                const bool in = rowin & (gx < w);
+                const float* q = in ? base : a.zeros;
+                const long step = in ? cstride : 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pa[e] = *reinterpret_cast<const f32x4*>(q + (long)e * step);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool in = rowin & (gx + i < w);
+                    const float* q = in ? base + i : a.zeros;
+                    const long step = in ? cstride : 0;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pa[e][i] = q[(long)e * step];
+                }
+            }
+        }
+        // ---- B: the chunk's 18 fragments ----
+        for (int u = tid; u < NBF; u += 256)
+            *reinterpret_cast<f32x4*>(&lds_b[u * 8]) = *reinterpret_cast<const f32x4*>(wbf + ((long)ch * NBF + u) * 8);
+        if (stager) {
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                bf16x8 hi, lo;
+                split_octet(pa, px, hi, lo);
+                *reinterpret_cast<bf16x8*>(&lds_ah[s_lds + px * 8]) = hi;
+                *reinterpret_cast<bf16x8*>(&lds_al[s_lds + px * 8]) = lo;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            bf16x8 ah[MR], al[MR];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                ah[m] = *reinterpret_cast<const bf16x8*>(&lds_ah[koff[s_] + m * AW * 8]);
+                al[m] = *reinterpret_cast<const bf16x8*>(&lds_al[koff[s_] + m * AW * 8]);
+            }
+#pragma unroll
+            for (int p = 0; p < 8; ++p) {
+                if (!deconv_step_used(p, s_)) continue;
+                const int slot = deconv_slot(p, s_);                    // compile-time after unrolling
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&lds_b[((slot * 2 + 0) * 64 + lane) * 8]);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&lds_b[((slot * 2 + 1) * 64 + lane) * 8]);
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[m], acc[m][p], 0, 0, 0);
+                    acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[m], acc[m][p], 0, 0, 0);
+                    acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[m], acc[m][p], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: lane = (input pixel li, channels 4*lk .. 4*lk+3); parities px = 0/1 pair up into one float2 ----
+    const int x = x0 + li;
+    const int Ho = 2 * h, Wo = 2 * w;
+    const long ostride = (long)(2 * D) * Ho * Wo;
+    float bv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[r] = a.bias[4 * lk + r];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        const int y = y0 + wv * MR + m;
+        if (y >= h || x >= w) continue;
+#pragma unroll
+        for (int pzy = 0; pzy < 4; ++pzy) {
+            const long o = ((long)(2 * z + (pzy >> 1)) * Ho + (2 * y + (pzy & 1))) * Wo + 2 * x;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = 4 * lk + r;
+                if (co >= a.cout) break;
+                float v0 = acc[m][2 * pzy][r] + bv[r], v1 = acc[m][2 * pzy + 1][r] + bv[r];
+                if (a.relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
+                const long oo = (long)co * ostride + o;
+                if (a.skip) {
+                    const float2 sk = *reinterpret_cast<const float2*>(a.skip + oo);
+                    v0 += sk.x;
+                    v1 += sk.y;
+                }
+                *reinterpret_cast<float2*>(a.out + oo) = make_float2(v0, v1);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 7x7 convolution of a single-channel map (convd1, models/update.py:76,90) + ReLU; vector ALUs.
 // ------------------------------------------------------------------------------------------------
 template <int COUT>
@@ -1485,6 +1653,40 @@ extern "C" int effi_conv3d_k3s1_roll_bf16x3_f32(const float* const* srcs, const 
     const int nt = (cout + 15) / 16;
     if (a.cin == 8) return nt == 1 ? launch_roll<1, 1>(a, st) : launch_roll<1, 2>(a, st);
     return nt == 1 ? launch_roll<2, 1>(a, st) : launch_roll<2, 2>(a, st);
+}
+
+extern "C" int effi_deconv3d_k3s2_bf16x3_f32(const float* in, int cin, const void* wpack_bf16, const float* bias, int cout, int D,
+                                             int h, int w, int relu, const float* skip, float* out, effi_stream_t stream) {
+    if (!in || !wpack_bf16 || !bias || !out || D < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    if (cin < 16 || (cin & 15) || cout < 1 || cout > 16) return EFFI_ERR_UNSUPPORTED;
+    DeconvArgs a;
+    a.in = in;
+    a.wpack = wpack_bf16;
+    a.bias = bias;
+    a.skip = skip;
+    a.zeros = effi_zero_page();
+    if (!a.zeros) return EFFI_ERR_LAUNCH;
+    a.out = out;
+    a.cin = cin;
+    a.cout = cout;
+    a.D = D;
+    a.h = h;
+    a.w = w;
+    a.relu = relu;
+    const int tiles_x = effi_cdiv(w, 16);
+    const bool al = (w & 3) == 0;
+    hipStream_t st = effi_s(stream);
+    // rows per wave: 2 when that still gives ~2 workgroups per CU
+    if ((long)tiles_x * effi_cdiv(h, 8) * D >= 512) {
+        const dim3 grid(tiles_x * effi_cdiv(h, 8), D);
+        if (al) hipLaunchKernelGGL((deconv3d_s2_bf16x3_kernel<2, true>), grid, dim3(256), 0, st, a, tiles_x, (int)grid.x);
+        else hipLaunchKernelGGL((deconv3d_s2_bf16x3_kernel<2, false>), grid, dim3(256), 0, st, a, tiles_x, (int)grid.x);
+    } else {
+        const dim3 grid(tiles_x * effi_cdiv(h, 4), D);
+        if (al) hipLaunchKernelGGL((deconv3d_s2_bf16x3_kernel<1, true>), grid, dim3(256), 0, st, a, tiles_x, (int)grid.x);
+        else hipLaunchKernelGGL((deconv3d_s2_bf16x3_kernel<1, false>), grid, dim3(256), 0, st, a, tiles_x, (int)grid.x);
+    }
+    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
 
 extern "C" int effi_conv2d_c1k7_relu_f32(const float* in, const float* weight, const float* bias, int cout, int h,

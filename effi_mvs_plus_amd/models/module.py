@@ -121,6 +121,7 @@ class Deconv3d(nn.Module):
         self.bn = nn.BatchNorm3d(out_channels, momentum=bn_momentum) if bn else None
         self.relu = relu
         self._cache = packing.PackCache()
+        self._cache_x3 = packing.PackCache()
 
     def _packed(self):
         t = [self.conv.weight, self.conv.bias]
@@ -134,6 +135,12 @@ class Deconv3d(nn.Module):
         if _triple(self.conv.kernel_size) != (3, 3, 3) or pad != (1, 1, 1) or st[1:] != (2, 2) or \
                 op != (st[0] - 1, 1, 1) or st[0] not in (1, 2):
             raise NotImplementedError("Deconv3d: only k3 / p1 / stride (s,2,2) / output_padding (s-1,1,1) is instantiated")
+        if st == (2, 2, 2) and x.shape[0] % 16 == 0 and self.out_channels <= 16 and ops.get_precision() == "split":
+            t = [self.conv.weight, self.conv.bias]
+            if self.bn is not None:
+                t += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
+            wp, bp = self._cache_x3.get(t, lambda: packing.pack_deconv3d_s2_bf16x3(self.conv, self.bn))
+            return ops.deconv3d_k3s2_x3(x, wp, bp, self.out_channels, relu=self.relu, skip=skip)
         w, b = self._packed()
         return ops.deconv3d_k3(x, w, b, self.out_channels, sz=st[0], relu=self.relu, skip=skip)
 

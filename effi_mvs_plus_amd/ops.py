@@ -320,6 +320,22 @@ def deconv3d_k3(x, weight, bias, cout, sz=2, relu=True, skip=None):
     return out
 
 
+def deconv3d_k3s2_x3(x, wpack, bias, cout, relu=True, skip=None):
+    """Transposed 3-D conv, stride (2,2,2), on the bf16 matrix cores in split precision
+    (``packing.pack_deconv3d_s2_bf16x3``): x [cin,D,h,w] -> [cout,2D,2h,2w] (+ skip after the ReLU)."""
+    _t(x, "deconv3d input")
+    cin, D, h, w = x.shape
+    out = torch.empty(cout, 2 * D, 2 * h, 2 * w, device=x.device, dtype=torch.float32)
+    if skip is not None:
+        _t(skip, "skip")
+        assert skip.shape == out.shape, f"skip {tuple(skip.shape)} vs out {tuple(out.shape)}"
+    work = lambda: {"flops": 2.0 * 27 * cin * cout * D * h * w,
+                    "bytes": 4.0 * (cin * D * h * w + cout * 8 * D * h * w * (2 if skip is not None else 1))}
+    check(_call(f"deconv3d_x3_c{cin}_{cout}", work, _lib.lib().effi_deconv3d_k3s2_bf16x3_f32, _p(x), cin, _p(wpack), _p(bias), cout,
+                D, h, w, int(relu), _p(skip), _p(out), _stream()), "effi_deconv3d_k3s2_bf16x3_f32")
+    return out
+
+
 def softmax_regress_conf(logits, depth):
     """logits [D,h,w]; depth [D] / [D,h,w] -> (depth [h,w], confidence [h,w])."""
     D, h, w = logits.shape

@@ -118,6 +118,50 @@ def pack_deconv3d(conv, bn):
     return wp, (None if bias is None else bias.contiguous().float())
 
 
+def deconv_s2_slots():
+    """(parity p, K-step s) pairs of the stride-2 transposed conv GEMM in kernel order: p = pz*4+py*2+px,
+    s = nz*2+ny; K-step s reaches parity p iff nz <= pz and ny <= py."""
+    return [(p, s) for p in range(8) for s in range(4) if (s & ~(p >> 1)) == 0]
+
+
+def pack_deconv3d_s2_bf16x3(conv, bn):
+    """nn.ConvTranspose3d [cin,cout,3,3,3] (+BN), stride 2 / padding 1 / output_padding 1, cin % 16 == 0, cout <= 16 ->
+    (bf16 [cin/16, 18, 2(hi|lo), 64, 8], bias fp32 [16]).  Per dimension parity 0 takes tap 1 of neighbour 0; parity 1 takes
+    tap 2 of neighbour 0 and tap 0 of neighbour 1.  Lane = q*16 + j of slot (p, s): neighbour (nz, ny, nx = q >> 1),
+    octet q & 1, output channel j, element e = input channel chunk*16 + octet*8 + e."""
+    w = conv.weight
+    bias = conv.bias
+    if bn is not None:
+        scale, shift = bn_scale_shift(bn)
+        w = w * scale.view(1, -1, 1, 1, 1)
+        bias = shift if bias is None else bias * scale + shift
+    cin, cout = w.shape[0], w.shape[1]
+    assert cin % 16 == 0 and cout <= 16
+    nch = cin // 16
+    tap = {(0, 0): 1, (1, 0): 2, (1, 1): 0}                 # (parity, neighbour) -> kernel index; (0, 1) contributes nothing
+    slots = deconv_s2_slots()
+    wp = torch.zeros(nch, len(slots), 4, 16, 8, device=w.device, dtype=torch.float32)      # [chunk, slot, q, j, e]
+    wf = w.float()
+    for si, (p, s_) in enumerate(slots):
+        pz, py, px = p >> 2, (p >> 1) & 1, p & 1
+        nz, ny = s_ >> 1, s_ & 1
+        for q in range(4):
+            nx, octet = q >> 1, q & 1
+            if (pz, nz) not in tap or (py, ny) not in tap or (px, nx) not in tap:
+                continue
+            kz, ky, kx = tap[(pz, nz)], tap[(py, ny)], tap[(px, nx)]
+            blk = wf[:, :, kz, ky, kx].reshape(nch, 2, 8, cout)[:, octet]                 # [chunk, e, cout]
+            wp[:, si, q, :cout, :] = blk.permute(0, 2, 1)
+    wp = wp.view(nch, len(slots), 64, 8)
+    hi = wp.to(torch.bfloat16)
+    lo = (wp - hi.float()).to(torch.bfloat16)
+    out = torch.stack([hi, lo], dim=2).contiguous()                                      # [chunk, slot, hl, lane, e]
+    b = torch.zeros(16, device=w.device, dtype=torch.float32)
+    if bias is not None:
+        b[:cout] = bias.float()
+    return out, b
+
+
 def pack_conv2d_mfma(weight, bias, scale=1.0):
     """[cout,cin,ks,ks] (+bias [cout]) -> (wpack [ceil(cin/4), ks*ks, ceil(cout/16), 64], bias [16*NT]).
 

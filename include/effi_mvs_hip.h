@@ -141,6 +141,11 @@ int effi_conv3d_k3s1_roll_bf16x3_f32(const float* const* srcs, const int* src_ch
 int effi_deconv3d_k3_f32(const float* in, int cin, const float* weight, const float* bias, int cout,
                          int D, int h, int w, int sz, int relu, const float* skip,
                          float* out, effi_stream_t stream);
+/* The stride-(2,2,2) case with cin % 16 == 0, cout <= 16 on the bf16 matrix cores in split precision (one GEMM per input
+ * position over output parity x input neighbour, models/module.py:448-450).  wpack_bf16 =
+ * packing.pack_deconv3d_s2_bf16x3: [cin/16][18][hi|lo][64][8] bf16; bias [16]; out = relu?(deconv + bias) (+ skip). */
+int effi_deconv3d_k3s2_bf16x3_f32(const float* in, int cin, const void* wpack_bf16, const float* bias, int cout,
+                                  int D, int h, int w, int relu, const float* skip, float* out, effi_stream_t stream);
 
 /* ---- K7: softmax over D, soft-argmin depth, 4-window confidence.
  * models/Effi_MVS_plus.py:79-88, models/module.py:518-524.

@@ -208,8 +208,10 @@ def test_conv3d_two_sources(dims, precision):
 
 @pytest.mark.parametrize("cin,cout,stride,dims,skip", [
     (32, 16, 2, (3, 5, 7), True), (16, 8, 2, (6, 10, 37), True), (16, 8, 2, (4, 9, 33), False),
-    (8, 1, (1, 2, 2), (8, 12, 20), False), (8, 1, (1, 2, 2), (5, 9, 35), False)])
-def test_deconv3d_block(cin, cout, stride, dims, skip):
+    (8, 1, (1, 2, 2), (8, 12, 20), False), (8, 1, (1, 2, 2), (5, 9, 35), False),
+    # real U-Net shapes (unaligned and aligned rows, both rows-per-wave variants of the matrix-core kernel)
+    (32, 16, 2, (12, 37, 50), True), (16, 8, 2, (24, 74, 100), True), (16, 16, 2, (5, 13, 24), False)])
+def test_deconv3d_block(cin, cout, stride, dims, skip, precision):
     from effi_mvs_plus_amd.models.module import Deconv3d
     g = torch.Generator().manual_seed(cin * 10 + cout)
     op = 1 if stride == 2 else (0, 1, 1)
@@ -225,7 +227,7 @@ def test_deconv3d_block(cin, cout, stride, dims, skip):
         want = sk + want
     else:
         got = m(t(x, DEV))
-    check_close(f"Deconv3d {cin}->{cout} s={stride} {dims} skip={skip}", got, want, rtol=1e-4, atol=1e-5)
+    check_close(f"Deconv3d {cin}->{cout} s={stride} {dims} skip={skip}", got, want, **conv_tol(precision, want, 1e-4, 1e-5))
 
 
 def test_costregnet_and_cost_up_small(model, O):
