@@ -273,7 +273,7 @@ def conv3d_k3s1_bf16x3(srcs, wpack, bias, cout, relu=True):
     cin = sum(s.shape[0] for s in srcs)
     out = torch.empty(cout, D, h, w, device=srcs[0].device, dtype=torch.float32)
     work = lambda: {"flops": 2.0 * 27 * cin * cout * D * h * w, "bytes": 4.0 * (cin + cout) * D * h * w}
-    check(_call(f"conv3d_x3_c{cin}_{cout}", work, _lib.lib().effi_conv3d_k3s1_bf16x3_f32, _ptr_array(srcs),
+    check(_call(f"conv3d_x3_nt{(cout + 15) // 16}", work, _lib.lib().effi_conv3d_k3s1_bf16x3_f32, _ptr_array(srcs),
                 _int_array([s.shape[0] for s in srcs]), len(srcs), _p(wpack), _p(bias), cout, D, h, w, int(relu), _p(out),
                 _stream()), "effi_conv3d_k3s1_bf16x3_f32")
     return out
@@ -288,7 +288,7 @@ def conv3d_k3s1_roll(srcs, wpack, bias, cout, relu=True):
     cin = sum(s.shape[0] for s in srcs)
     out = torch.empty(cout, D, h, w, device=srcs[0].device, dtype=torch.float32)
     work = lambda: {"flops": 2.0 * 27 * cin * cout * D * h * w, "bytes": 4.0 * (cin + cout) * D * h * w}
-    check(_call(f"conv3d_roll_c{cin}_{cout}", work, _lib.lib().effi_conv3d_k3s1_roll_bf16x3_f32, _ptr_array(srcs),
+    check(_call(f"conv3d_roll_oct{cin // 8}_nt{(cout + 15) // 16}", work, _lib.lib().effi_conv3d_k3s1_roll_bf16x3_f32, _ptr_array(srcs),
                 _int_array([s.shape[0] for s in srcs]), len(srcs), _p(wpack), _p(bias), cout, D, h, w, int(relu), _p(out),
                 _stream()), "effi_conv3d_k3s1_roll_bf16x3_f32")
     return out
@@ -331,7 +331,7 @@ def deconv3d_k3s2_x3(x, wpack, bias, cout, relu=True, skip=None):
         assert skip.shape == out.shape, f"skip {tuple(skip.shape)} vs out {tuple(out.shape)}"
     work = lambda: {"flops": 2.0 * 27 * cin * cout * D * h * w,
                     "bytes": 4.0 * (cin * D * h * w + cout * 8 * D * h * w * (2 if skip is not None else 1))}
-    check(_call(f"deconv3d_x3_c{cin}_{cout}", work, _lib.lib().effi_deconv3d_k3s2_bf16x3_f32, _p(x), cin, _p(wpack), _p(bias), cout,
+    check(_call("deconv3d_x3", work, _lib.lib().effi_deconv3d_k3s2_bf16x3_f32, _p(x), cin, _p(wpack), _p(bias), cout,
                 D, h, w, int(relu), _p(skip), _p(out), _stream()), "effi_deconv3d_k3s2_bf16x3_f32")
     return out
 

@@ -21,6 +21,18 @@ def key_of(name):
     m = re.match(r"conv2d_mfma_v2_kernel<(\d+), (\d+), (\d+), (\d+)", n)
     if m:
         return f"conv2d_k{m.group(1)}_nt{m.group(2)}_epi{m.group(4)}", 2.0
+    m = re.match(r"conv2d_k3_bf16x3_kernel<(\d+), (\d+), (\d+), (true|false)", n)
+    if m:
+        return (f"conv2d_k3x3_nt{m.group(1)}_epi{m.group(3)}" if m.group(4) == "false" else f"conv3d_x3_nt{m.group(1)}"), 2.0
+    m = re.match(r"conv3d_roll_bf16x3_kernel<(\d+), (\d+)", n)
+    if m:
+        return f"conv3d_roll_oct{m.group(1)}_nt{m.group(2)}", 2.0
+    m = re.match(r"deconv3d_s2_bf16x3_kernel", n)
+    if m:
+        return "deconv3d_x3", 2.0
+    m = re.match(r"getcost_conv1x1_kernel", n)
+    if m:
+        return "getcost_conv1x1", 1.0
     m = re.match(r"conv2d_mfma_kernel<(\d+), (\d+), (\d+)", n)
     if m:
         return f"conv2d_k{m.group(1)}_nt{m.group(2)}_epi{m.group(3)}", 1.0
