@@ -284,10 +284,14 @@ class Effi_MVS_plus(nn.Module):
                 D = self.depth_stage_nums[s]
                 sim, samples = ops.warpcorr_dyn(nhwc[0], nhwc[1:], rt, preds[-1], misc[s:s + 1], weights, D)
                 x = sim.unsqueeze(0)
+                # the two cross-scale blocks are independent chains of 5 kernels: CSP_C goes to the side stream
+                with ops.Branch() as br:
+                    prior_c = ops.vol_lookup1d(cur_vol, samples, lo_prev, hi_prev, h // 2, w // 2)
+                    cur_new = self.CSP_C[s - 1].run(x, prior_c.unsqueeze(0))[0][0]
                 prior = ops.vol_lookup1d(reg_vol, samples, lo_prev, hi_prev, h // 2, w // 2)
                 reg_vol = self.CSP_R[s - 1].run(x, prior.unsqueeze(0))[0][0]
-                prior = ops.vol_lookup1d(cur_vol, samples, lo_prev, hi_prev, h // 2, w // 2)
-                cur_vol = self.CSP_C[s - 1].run(x, prior.unsqueeze(0))[0][0]
+                br.join(cur_new)
+                cur_vol = cur_new
                 lo_cur, hi_cur = samples[D - 1], samples[0]      # depth_min2 / depth_max2 (:508-509)
             if want_intermediates:
                 inter["view_weights"] = weights

@@ -123,23 +123,27 @@ class ProjectionInput(nn.Module):
 
     def run(self, disp, cost, context, bufs=None, cor1=None):
         """disp [1,h,w], cost [2*nq,h,w], context [cd,h,w] -> [hidden,h,w].  ``bufs``: optional dict of
-        scratch tensors reused across GRU iterations; ``cor1``: relu(convc1(cost)) when the lookup kernel already
-        produced it (then ``cost`` is not needed)."""
+        scratch tensors reused across GRU iterations; ``cor1``: relu(convc1(cost)), or a callable returning it, when the
+        lookup kernel produces it (then ``cost`` is not needed)."""
         hd = self.convc1.out_channels
         if self.convd1.in_channels != 1:
             raise NotImplementedError("ProjectionInput: depth_num must be 1 on the HIP path")
         g = (lambda k: bufs.get(k)) if bufs is not None else (lambda k: None)
-        if cor1 is None:
+        # the depth branch (7x7 -> 3x3) does not depend on the cost branch: it goes to the side stream
+        with ops.Branch() as br:
+            w7, b7 = self._caches["d1"].get([self.convd1.weight, self.convd1.bias],
+                                            lambda: packing.pack_conv2d_c1k7(self.convd1.weight, self.convd1.bias))
+            dfm = ops.conv2d_c1k7_relu(disp, w7, b7, hd, out=g("dfm1"))
+            w, b = _pack(self._caches["d2"], self.convd2)
+            dfm = ops.conv2d([dfm], w, b, hd, 3, act=ops.ACT_RELU, out0=g("dfm2"))
+        if callable(cor1):                     # produced by the lookup kernel, enqueued after the fork so both chains overlap
+            cor1 = cor1()
+        elif cor1 is None:
             w, b = _pack(self._caches["c1"], self.convc1)
             cor1 = ops.conv2d([cost], w, b, hd, 1, act=ops.ACT_RELU, out0=g("cor1"))
-        cor = cor1
         w, b = _pack(self._caches["c2"], self.convc2)
-        cor = ops.conv2d([cor], w, b, hd, 3, act=ops.ACT_RELU, out0=g("cor2"))
-        w7, b7 = self._caches["d1"].get([self.convd1.weight, self.convd1.bias],
-                                        lambda: packing.pack_conv2d_c1k7(self.convd1.weight, self.convd1.bias))
-        dfm = ops.conv2d_c1k7_relu(disp, w7, b7, hd, out=g("dfm1"))
-        w, b = _pack(self._caches["d2"], self.convd2)
-        dfm = ops.conv2d([dfm], w, b, hd, 3, act=ops.ACT_RELU, out0=g("dfm2"))
+        cor = ops.conv2d([cor1], w, b, hd, 3, act=ops.ACT_RELU, out0=g("cor2"))
+        br.join(dfm)
         w, b = _pack(self._caches["d"], self.convd)
         mix = ops.conv2d([cor, dfm], w, b, self.convd.out_channels, 3, act=ops.ACT_NONE, out0=g("mix"))
         w, b = _pack(self._caches["c"], self.convc)
@@ -192,16 +196,23 @@ class BasicUpdateBlock(nn.Module):
         for i in range(seq_len):
             if fuse_c1:      # lookup + convc1 + ReLU in one kernel: the cost map never reaches HBM
                 wc1, bc1 = self.encoder.convc1_raw()
-                x = self.encoder.run(inv_depth, None, context, bufs, cor1=lookup.conv1x1(inv_depth, wc1, bc1, hd, bufs["cor1"]))
+                x = self.encoder.run(inv_depth, None, context, bufs,
+                                     cor1=lambda d=inv_depth: lookup.conv1x1(d, wc1, bc1, hd, bufs["cor1"]))
             else:
                 cost_buf = lookup(inv_depth, cost_buf)
                 x = self.encoder.run(inv_depth, cost_buf, context, bufs)
             net = self.depth_gru.run(net, [x], z_buf, rh_buf)          # fresh tensor: callers keep every state
+            want_mask = self.UpMask and i == seq_len - 1
+            if want_mask:                      # the mask head only needs the new hidden state: side stream
+                with ops.Branch() as br:
+                    mask = self.run_mask(net)
             hid = self.depth_head.run_hidden(net, head_buf)
             inv_depth, depth = self.depth_head.run_update(hid, inv_depth, disp_range)
+            if want_mask:
+                br.join(mask)
             inv_list.append(inv_depth)
             depth_list.append(depth)
-            mask_list.append(self.run_mask(net) if (self.UpMask and i == seq_len - 1) else inv_depth)
+            mask_list.append(mask if want_mask else inv_depth)
         return net, mask_list, inv_list, depth_list
 
     def forward(self, net, depth_cost_func, inv_depth, context, seq_len=4, scale_inv_depth=None):

@@ -66,6 +66,10 @@ def set_profile(p):
     _PROF = p
 
 
+def get_profile():
+    return _PROF
+
+
 def _call(key, work, fn, *args):
     p = _PROF
     if p is None or (p.keys is not None and key not in p.keys):
@@ -92,6 +96,61 @@ def _t(x: torch.Tensor, name: str, contiguous=True) -> torch.Tensor:
 
 def _p(x):
     return C.c_void_p(x.data_ptr()) if x is not None else C.c_void_p(0)
+
+
+# Independent kernel chains (the two encoder branches of the update block, the two cross-scale blocks, the mask head) are
+# enqueued on a second HIP stream so that layers which do not fill the 256 CUs on their own overlap.  Results are identical
+# (no atomics; every kernel still sees its producers through stream events).  EFFI_MVS_BRANCHES=0 keeps one stream.
+_BRANCHES = os.environ.get("EFFI_MVS_BRANCHES", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+def set_branches(enabled):
+    """Enable / disable the second stream (profiling passes want serial kernel durations)."""
+    global _BRANCHES
+    _BRANCHES = bool(enabled)
+
+
+def get_branches():
+    return _BRANCHES
+
+
+class Branch:
+    """``with Branch() as br: <enqueue the side chain>`` ... main chain ... ``br.join(outputs...)``.
+
+    The side stream first waits for everything already enqueued on the current (main) stream; ``join`` makes the main
+    stream wait for the side chain and tells the caching allocator that the given side-allocated tensors are now used on
+    the main stream."""
+
+    def __init__(self):
+        self.enabled = _BRANCHES
+        if self.enabled:
+            self.main = torch.cuda.current_stream()
+            key = (self.main.device.index, self.main.cuda_stream)
+            side = _SIDE_STREAMS.get(key)
+            if side is None:
+                side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=self.main.device)
+            self.side = side
+            self._ctx = None
+
+    def __enter__(self):
+        if self.enabled:
+            self.side.wait_stream(self.main)
+            self._ctx = torch.cuda.stream(self.side)
+            self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            self._ctx.__exit__(*exc)
+        return False
+
+    def join(self, *tensors):
+        if self.enabled:
+            self.main.wait_stream(self.side)
+            for t_ in tensors:
+                if t_ is not None:
+                    t_.record_stream(self.main)
 
 
 def _stream():

@@ -166,6 +166,30 @@ def test_full_forward_including_fpn():
     assert tuple(out["photometric_confidence"].shape) == tuple(g["photometric_confidence"].shape)
 
 
+def test_hip_graph_replay_is_bitwise_equal_to_eager(precision):
+    """effi_mvs_plus_amd.graph.HotPathGraph: capture once, replay with fresh inputs copied into the static buffers."""
+    from effi_mvs_plus_amd.graph import HotPathGraph
+    net, sd = build_model("8,8,8", seed=4, device=DEV)
+    samples = []
+    with torch.no_grad():
+        for seed in (21, 22):
+            imgs, pm, dv = synth.synth_sample(128, 160, 3, seed=seed)
+            imgs = imgs.to(DEV)
+            feats = [net.feature(imgs[:, v]) for v in range(3)]
+            ctx = net.cnet_depth(imgs[:, 0])
+            samples.append((feats, ctx, {k: v.to(DEV) for k, v in pm.items()}, dv.to(DEV)))
+        g = HotPathGraph(net, *samples[0])
+        for smp in (samples[1], samples[0], samples[1]):
+            want = net.forward_hot(*smp)
+            got = g(*smp)
+            assert len(got["depth"]) == 13
+            for a, b in zip(got["depth"], want["depth"]):
+                assert torch.equal(a, b)
+            assert torch.equal(got["photometric_confidence"], want["photometric_confidence"])
+        with pytest.raises(ValueError):
+            g(samples[0][0][:2], *samples[0][1:])
+
+
 def test_training_mode_and_cpu_are_refused():
     from effi_mvs_plus_amd._lib import EffiLibraryError
     net, _ = build_model("8,8,8", seed=1, device=DEV)
