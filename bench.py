@@ -131,9 +131,12 @@ def main():
         for i in range(max(1, args.warmup - 1)):
             step(i)
         prof = ops.KernelProfile()
+        br0 = ops.get_branches()
+        ops.set_branches(False)                   # one stream: per-kernel durations are not inflated by overlap
         ops.set_profile(prof)
         step(0)
         ops.set_profile(None)
+        ops.set_branches(br0)
         disc = prof.summary()
         key = args.profile_key or max(disc, key=lambda k: disc[k]["ms"])
         step(1)                                   # last warm-up step, no instrumentation

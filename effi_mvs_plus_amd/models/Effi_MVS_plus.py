@@ -264,13 +264,22 @@ class Effi_MVS_plus(nn.Module):
         conf = None
         weights = reg_vol = cur_vol = None
         lo_prev, hi_prev = g_min, g_max          # depth range the PREVIOUS stage's volumes are sampled on
-        for s in range(self.num_stage):
+
+        def prepare(s):      # per-stage inputs that depend on nothing but the features / cameras / context
             key = "stage{}".format(s + 1)
             maps = [f[key] for f in feats]
-            nhwc = ops.to_nhwc(maps)
-            rt = ops.compose_rel_proj(pairs[key])
-            _, h, w = maps[0].shape
-            hidden, inp = ops.split_tanh_relu(ctx[key].contiguous(), self.hdim_stage[s], self.cdim_stage[s])
+            hid, inp_ = ops.split_tanh_relu(ctx[key].contiguous(), self.hdim_stage[s], self.cdim_stage[s])
+            return ops.to_nhwc(maps), ops.compose_rel_proj(pairs[key]), maps[0].shape, hid, inp_
+
+        prep = {0: prepare(0)}
+        with ops.Branch() as prep_branch:        # stages 2 and 3 are prepared on the side stream while stage 1 runs
+            for s in range(1, self.num_stage):
+                prep[s] = prepare(s)
+        for s in range(self.num_stage):
+            if s == 1:
+                prep_branch.join(*[t_ for k in range(1, self.num_stage) for t_ in
+                                   (list(prep[k][0]) + [prep[k][1], prep[k][3], prep[k][4]])])
+            nhwc, rt, (_, h, w), hidden, inp = prep[s]
             if s == 0:
                 sim_views, entropy = ops.warpcorr_views(nhwc[0], nhwc[1:], rt, hyp, D1)
                 weights = self.PixelwiseNet.run(entropy)
