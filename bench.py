@@ -54,6 +54,10 @@ def main():
     ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
                     help="graph (default): the step copies its inputs into the static buffers of a captured hipGraph of the hot path "
                          "and replays it (one launch); eager: ~150 launches enqueued from Python (host-bound at this kernel speed)")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="graph launch only: reference views in flight at once, each on its own stream and input slot (throughput "
+                         "metric: while one view is in its low-resolution stages, which cannot fill 256 CUs, the other uses them); "
+                         "1 = strictly one view after the other")
     ap.add_argument("--no-other-precision", action="store_true", help="skip the secondary run in the other conv arithmetic (profiling runs)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1: nccl (= RCCL over xGMI, the real path) or gloo (rehearsal of the "
@@ -110,15 +114,17 @@ def main():
         from effi_mvs_plus_amd.graph import HotPathGraph
         # double-buffered input slots (as a producer of features would fill them); the two synthetic views are loaded
         # into the slots before the timed region -- "inputs resident in HBM" -- and a step replays the slot's graph
-        graphed = HotPathGraph(net, *inputs[0], slots=n_scenes)
-        for i in range(n_scenes):
-            graphed.load(i, *inputs[i])
+        n_slots = max(n_scenes, args.in_flight)
+        graphed = HotPathGraph(net, *inputs[0], slots=n_slots)
+        for i in range(n_slots):
+            graphed.load(i, *inputs[i % n_scenes])
         torch.cuda.synchronize()
+        lanes = [torch.cuda.Stream() for _ in range(max(1, args.in_flight))]
 
     def step(i):
         f, c, p, d = inputs[i % n_scenes]
         if graphed is not None and ops.get_profile() is None and ops.get_precision() == precision:
-            return graphed.replay(i % n_scenes)      # one graph launch
+            return graphed.replay(i % n_slots)       # one graph launch
         return net.forward_hot(f, c, p, d)
 
     def barrier():
@@ -150,14 +156,27 @@ def main():
         finals, confs = [], []
         barrier()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            out = step(i)
-            if graphed is not None:                   # static output buffers: keep copies (inside the timed region)
-                finals.append(out["depth"][-1].clone())
-                confs.append(out["photometric_confidence"].clone())
-            else:
-                finals.append(out["depth"][-1])
-                confs.append(out["photometric_confidence"])
+        if graphed is not None and args.in_flight > 1:
+            # views i and i+1 are independent: step i runs on stream i % in_flight (its own input slot and graph)
+            cur = torch.cuda.current_stream()
+            for st_ in lanes:
+                st_.wait_stream(cur)
+            for i in range(args.steps):
+                with torch.cuda.stream(lanes[i % len(lanes)]):
+                    out = step(i)
+                    finals.append(out["depth"][-1].clone())          # static output buffers: keep copies
+                    confs.append(out["photometric_confidence"].clone())
+            for st_ in lanes:
+                cur.wait_stream(st_)
+        else:
+            for i in range(args.steps):
+                out = step(i)
+                if graphed is not None:               # static output buffers: keep copies (inside the timed region)
+                    finals.append(out["depth"][-1].clone())
+                    confs.append(out["photometric_confidence"].clone())
+                else:
+                    finals.append(out["depth"][-1])
+                    confs.append(out["photometric_confidence"])
         if distributed:
             # the path's only collective: ONE RCCL gather per tensor of this rank's finished maps to rank 0
             to = (lambda t_: t_) if args.backend == "nccl" else (lambda t_: t_.cpu())   # gloo gathers host tensors
@@ -224,10 +243,12 @@ def main():
             "config": {"workload": f"{args.workload}: DTU-shaped {W}x{H}, N={N} views (S={N - 1} sources), 3-stage cascade "
                                    f"ndepths={nd}, GRU iters 3,3,3, seeded-random weights, features of the stock FPN resident in HBM",
                        "launch": ("hipGraph replay of the captured hot path (two streams) on double-buffered static input slots that hold the "
-                                  "two synthetic views; each step replays one slot and clones the outputs it keeps, inside the timed region"
+                                  f"synthetic views; each step replays one slot and clones the outputs it keeps, inside the timed region; "
+                                  f"{max(1, args.in_flight)} independent view(s) in flight, one stream each"
                                   if graphed is not None else "eager: every kernel enqueued from Python"),
                        "parallelism": f"view-sharded x{world}, {'RCCL' if args.backend == 'nccl' else 'gloo (rehearsal)'} gather of "
                                       f"depth+confidence to rank 0 inside the timed region" if world > 1 else "single GPU"},
+            "in_flight": (max(1, args.in_flight) if graphed is not None else 1),
             "roofline": roof,
             "kernel_breakdown_ms": {k: round(v["ms"], 4) for k, v in sorted(disc.items(), key=lambda kv: -kv[1]["ms"])},
         }
