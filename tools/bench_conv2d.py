@@ -45,9 +45,18 @@ for name, h, w, cins, cout, ks, epi in shapes:
         for _ in range(3):
             outx = ops.conv2d_k3_bf16x3(xs, wx, bx, cout, **kw)
         torch.cuda.synchronize()
+        # EFFI_ROTATE=R: cycle through R distinct input / output buffer sets so the working set exceeds the 256 MB MALL
+        # (in the pipeline a layer's input was written several hundred MB of traffic earlier)
+        R = int(os.environ.get("EFFI_ROTATE", "1"))
+        xsets = [xs] + [[x.clone() for x in xs] for _ in range(R - 1)]
+        outs = [torch.empty_like(outx[0] if isinstance(outx, tuple) else outx) for _ in range(R)]
+        outs1 = [torch.empty_like(outx[1]) for _ in range(R)] if isinstance(outx, tuple) else [None] * R
+        for r_ in range(R):
+            ops.conv2d_k3_bf16x3(xsets[r_], wx, bx, cout, out0=outs[r_], out1=outs1[r_], **kw)
+        torch.cuda.synchronize()
         e0.record()
-        for _ in range(n):
-            ops.conv2d_k3_bf16x3(xs, wx, bx, cout, **kw)
+        for i_ in range(n):
+            ops.conv2d_k3_bf16x3(xsets[i_ % R], wx, bx, cout, out0=outs[i_ % R], out1=outs1[i_ % R], **kw)
         e1.record()
         torch.cuda.synchronize()
         usx = e0.elapsed_time(e1) / n * 1e3
