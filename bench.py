@@ -320,6 +320,35 @@ def main():
                                    "note": "images resident in HBM -> 13 depth maps + confidence; N feature nets + 1 context net + hot path"}
         del imgs
 
+    # ---- secondary (rank 0, N = 1): scope row n3, the consumer of the path's depth maps -- dynamic geometric-consistency
+    # filter + depth averaging (misc/fusion.py, test_tank.py:466-512) on full-resolution synthetic depth maps
+    if rank == 0 and world == 1 and not args.no_whole_forward:
+        from oracle import effi_oracle as Of
+        Vf = 10
+        dmaps, fcams = synth.synth_depth_maps(H, W, Vf + 1, seed=4)
+        dmaps, fcams = dmaps.to(dev), fcams.to(dev)
+        fconf = torch.rand(H, W, device=dev)
+        fargs = (dmaps[0].contiguous(), dmaps[1:].contiguous(), fcams[0].contiguous(), fcams[1:].contiguous(), fconf, 0.3, 2, 4.0, 1.3)
+        with torch.no_grad():
+            hip_ms = timed(lambda: ops.fusion_dynamic_filter(*fargs), n=10)
+        fbytes = 4.0 * H * W * (1 + Vf + 1 + 1 + 3) + 3.0 * H * W
+        result["fusion_filter"] = {"views_per_s": 1e3 / hip_ms, "ms_per_ref_view": hip_ms, "src_views": Vf,
+                                   "algorithmic_GBps": fbytes / hip_ms / 1e6,
+                                   "note": f"{W}x{H} depth maps, {Vf} source views, dh_view_num 2, one fused kernel per reference view"}
+        if not args.no_cpu_baseline:
+            # the reference's op sequence (oracle restatement of misc/fusion.py) on the host cores, quarter of the pixels.
+            # (Its PyTorch-ROCm form is not timed: the 19M-batch 3x3 matmul it issues at this size faults inside the BLAS library.)
+            hq, wq = H // 2, W // 2
+            dq, cq = synth.synth_depth_maps(hq, wq, Vf + 1, seed=4)
+            with torch.no_grad():
+                t0 = time.perf_counter()
+                Of.fusion_dynamic_filter(dq[0][None, None], dq[1:][None, :, None], cq[0][None], cq[1:][None], torch.rand(1, hq, wq),
+                                         0.3, 2, 4.0, 1.3)
+                tq = time.perf_counter() - t0
+            result["fusion_filter"]["cpu_reference_ops"] = {"ms_per_ref_view": tq * 1e3, "size": f"{wq}x{hq} (a quarter of the pixels)",
+                                                            "cores": torch.get_num_threads(), "kind": "port"}
+        del dmaps
+
     # ---- baselines (rank 0, N = 1 only): bounded samples of the same workload ------------------------
     if rank == 0 and world == 1:
         from oracle import effi_oracle as O

@@ -13,11 +13,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libeffimvs_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "effi_mvs_hip.h")
 
-_vp, _i, _l = C.c_void_p, C.c_int, C.c_long
+_vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 
 # name -> argtypes (restype is int for all but effi_error_string)
 SIGNATURES = {
     "effi_version": [],
+    "effi_fusion_dynamic_filter_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _f, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                       _vp, _vp],
     "effi_compose_rel_proj_f32": [_vp, _i, _vp, _vp],
     "effi_rel_proj_f32": [_vp, _vp, _vp, _vp],
     "effi_planar_to_nhwc_f32": [_vp, _vp, _i, _i, _i, _vp],

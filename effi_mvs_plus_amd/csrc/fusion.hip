@@ -1,0 +1,200 @@
+// Scope row n3: the dynamic geometric-consistency filter and depth averaging that consume the
+// path's depth maps (reference: misc/fusion.py:8-46,117-181 and the tensor part of test_tank.py:466-512).
+// One thread per reference pixel walks all source views: project into the source view, bilinear-sample its depth
+// (F.grid_sample, align_corners=True, zero padding), project the sampled point back, compare position and depth against
+// the V+1-thres_view threshold pairs, count, and finish with the averaged depth, the dynamic view-count rule, the
+// photometric mask and the world-space point -- nothing of the reference's [n,v,3,h,w] intermediates is materialised
+// unless the caller asks for reproj_xyd.  Arithmetic is fp32 in the reference's operation order; the 3x3 / 4x4 inverses
+// are formed once per view on the device in fp64 and rounded (torch.inverse in fp32 differs from that by ~1e-7 relative).
+#include "common.hpp"
+
+namespace {
+
+constexpr int FUS_MAX_VIEWS = 16;
+constexpr int MAT_STRIDE = 52;        // per view: K[9] Kinv[9] E[16] Einv[16] (+2 pad)
+
+__device__ void fus_invert(const double* A, int n, double* inv) {           // Gauss-Jordan, partial pivoting, n <= 4
+    double M[4][8];
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < n; ++c) {
+            M[r][c] = A[r * n + c];
+            M[r][c + n] = (r == c) ? 1.0 : 0.0;
+        }
+    for (int col = 0; col < n; ++col) {
+        int piv = col;
+        double best = fabs(M[col][col]);
+        for (int r = col + 1; r < n; ++r)
+            if (fabs(M[r][col]) > best) { best = fabs(M[r][col]); piv = r; }
+        if (piv != col)
+            for (int c = 0; c < 2 * n; ++c) { const double t = M[col][c]; M[col][c] = M[piv][c]; M[piv][c] = t; }
+        const double d = 1.0 / M[col][col];
+        for (int c = 0; c < 2 * n; ++c) M[col][c] *= d;
+        for (int r = 0; r < n; ++r) {
+            if (r == col) continue;
+            const double f = M[r][col];
+            for (int c = 0; c < 2 * n; ++c) M[r][c] -= f * M[col][c];
+        }
+    }
+    for (int r = 0; r < n; ++r)
+        for (int c = 0; c < n; ++c) inv[r * n + c] = M[r][c + n];
+}
+
+// cams: view 0 = reference ([2][4][4]: extrinsic, intrinsic in the top-left 3x3), views 1..V = sources
+__global__ void fusion_prepare_kernel(const float* __restrict__ ref_cam, const float* __restrict__ src_cams, int V,
+                                      float* __restrict__ mats) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v > V) return;
+    const float* cam = (v == 0) ? ref_cam : src_cams + (long)(v - 1) * 32;
+    double K[9], Ki[9], E[16], Ei[16];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) K[r * 3 + c] = (double)cam[16 + r * 4 + c];
+    for (int i = 0; i < 16; ++i) E[i] = (double)cam[i];
+    fus_invert(K, 3, Ki);
+    fus_invert(E, 4, Ei);
+    float* m = mats + (long)v * MAT_STRIDE;
+    for (int i = 0; i < 9; ++i) { m[i] = (float)K[i]; m[9 + i] = (float)Ki[i]; }
+    for (int i = 0; i < 16; ++i) { m[18 + i] = (float)E[i]; m[34 + i] = (float)Ei[i]; }
+}
+
+struct V3 { float x, y, z; };
+struct V4 { float x, y, z, w; };
+
+__device__ __forceinline__ V3 mul3(const float* M, V3 p) {
+    return {M[0] * p.x + M[1] * p.y + M[2] * p.z, M[3] * p.x + M[4] * p.y + M[5] * p.z, M[6] * p.x + M[7] * p.y + M[8] * p.z};
+}
+__device__ __forceinline__ V4 mul4(const float* M, V4 p) {
+    return {M[0] * p.x + M[1] * p.y + M[2] * p.z + M[3] * p.w, M[4] * p.x + M[5] * p.y + M[6] * p.z + M[7] * p.w,
+            M[8] * p.x + M[9] * p.y + M[10] * p.z + M[11] * p.w, M[12] * p.x + M[13] * p.y + M[14] * p.z + M[15] * p.w};
+}
+// idx_img2cam (misc/fusion.py:23-28): K^-1 [u v 1], normalised by its z (+1e-9), times depth; homogeneous w = 1
+__device__ __forceinline__ V4 img2cam(const float* Kinv, float u, float v, float depth) {
+    V3 c = mul3(Kinv, {u, v, 1.0f});
+    const float d = c.z + 1e-9f;
+    return {c.x / d * depth, c.y / d * depth, c.z / d * depth, 1.0f};
+}
+// idx_cam2world / idx_world2cam (:31-40): 4x4 times the point, normalised by w (+1e-9)
+__device__ __forceinline__ V4 xform(const float* M, V4 p) {
+    V4 q = mul4(M, p);
+    const float d = q.w + 1e-9f;
+    return {q.x / d, q.y / d, q.z / d, q.w / d};
+}
+// idx_cam2img (:43-47)
+__device__ __forceinline__ V3 cam2img(const float* K, V4 c) {
+    const float d = c.w + 1e-9f;
+    V3 i = mul3(K, {c.x / d, c.y / d, c.z / d});
+    const float e = i.z + 1e-9f;
+    return {i.x / e, i.y / e, i.z / e};
+}
+
+__device__ __forceinline__ float sample_bilinear_zero(const float* __restrict__ img, int h, int w, float u, float v) {
+    // F.grid_sample(mode=bilinear, padding_mode=zeros, align_corners=True) on coordinates normalised as the reference does
+    const float gx = u / ((float)(w - 1) / 2.0f) - 1.0f, gy = v / ((float)(h - 1) / 2.0f) - 1.0f;
+    const float ix = ((gx + 1.0f) / 2.0f) * (float)(w - 1), iy = ((gy + 1.0f) / 2.0f) * (float)(h - 1);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float tx = ix - fx, ty = iy - fy;
+    auto at = [&](int yy, int xx) { return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? img[(long)yy * w + xx] : 0.0f; };
+    const float nw = (1.0f - tx) * (1.0f - ty), ne = tx * (1.0f - ty), sw = (1.0f - tx) * ty, se = tx * ty;
+    return at(y0, x0) * nw + at(y0, x0 + 1) * ne + at(y0 + 1, x0) * sw + at(y0 + 1, x0 + 1) * se;
+}
+
+__global__ __launch_bounds__(256) void fusion_dynamic_filter_kernel(
+    const float* __restrict__ ref_depth, const float* __restrict__ src_depths, int V, int h, int w,
+    const float* __restrict__ mats, const float* __restrict__ conf, int ch, int cw, float prob_thr, int dh, float dist_base,
+    float rel_base, int relative, float* __restrict__ out_depth, unsigned char* __restrict__ out_geo,
+    unsigned char* __restrict__ out_prob, unsigned char* __restrict__ out_mask, float* __restrict__ out_points,
+    float* __restrict__ out_xyd) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const long hw = (long)h * w;
+    if (p >= hw) return;
+    const int y = p / w, x = p - y * w;
+    const float u = (float)x + 0.5f, vv = (float)y + 0.5f;
+    const float* Mr = mats;
+    const float dref = ref_depth[p];
+    const V4 ref_cam_pt = img2cam(Mr + 9, u, vv, dref);
+    const V4 world = xform(Mr + 34, ref_cam_pt);
+    int counts[FUS_MAX_VIEWS + 1];
+#pragma unroll
+    for (int i = 0; i <= FUS_MAX_VIEWS; ++i) counts[i] = 0;
+    const int nthr = V + 1 - dh;                                   // thresholds i = dh .. V
+    float dsum = 0.0f;
+    int nvis = 0;
+    for (int s = 0; s < V; ++s) {
+        const float* Ms = mats + (long)(s + 1) * MAT_STRIDE;
+        const V4 c = xform(Ms + 18, world);
+        const V3 im = cam2img(Ms, c);
+        const float ds = sample_bilinear_zero(src_depths + (long)s * hw, h, w, im.x, im.y);
+        const V4 sc = img2cam(Ms + 9, im.x, im.y, ds);
+        const V4 sw = xform(Ms + 34, sc);
+        const V4 rc = xform(Mr + 18, sw);
+        const float reproj_depth = rc.z;
+        const V3 ri = cam2img(Mr, rc);
+        if (out_xyd) {
+            out_xyd[((long)s * 3 + 0) * hw + p] = ri.x;
+            out_xyd[((long)s * 3 + 1) * hw + p] = ri.y;
+            out_xyd[((long)s * 3 + 2) * hw + p] = reproj_depth;
+        }
+        const float dx = ri.x - u, dy = ri.y - vv;
+        const float cdiff = sqrtf(dx * dx + dy * dy);
+        float ddiff = fabsf(dref - reproj_depth);
+        if (relative) ddiff = ddiff / dref;
+#pragma unroll
+        for (int k = 0; k <= FUS_MAX_VIEWS; ++k) {
+            if (k < nthr) {
+                const float step = (float)(dh + k);
+                const bool m = (cdiff < step / dist_base) & (ddiff < step / rel_base);
+                counts[k] += m ? 1 : 0;
+                if (k == nthr - 1 && m) {                           // vis_mask = loosest threshold (misc/fusion.py:179)
+                    dsum += reproj_depth;
+                    nvis += 1;
+                }
+            }
+        }
+    }
+    const float davg = (dsum + dref) / (float)(nvis + 1);           // test_tank.py:498-499
+    bool geo = nvis >= V + 1;                                        // :502 (never true; kept for fidelity)
+#pragma unroll
+    for (int k = 0; k <= FUS_MAX_VIEWS; ++k)
+        if (k < nthr && k < V + 1 - dh) geo = geo | (counts[k] >= dh + k);   // :503-504
+    bool pm = true;
+    if (conf) {                                                     // F.interpolate(nearest) of the confidence, :471-473
+        const int sy = min((int)floorf((float)y * ((float)ch / (float)h)), ch - 1);
+        const int sx = min((int)floorf((float)x * ((float)cw / (float)w)), cw - 1);
+        pm = conf[(long)sy * cw + sx] > prob_thr;
+    }
+    out_depth[p] = davg;
+    if (out_geo) out_geo[p] = geo ? 1 : 0;
+    if (out_prob) out_prob[p] = pm ? 1 : 0;
+    if (out_mask) out_mask[p] = (geo & pm) ? 1 : 0;
+    if (out_points) {                                               // :507-509
+        const V4 pc = img2cam(Mr + 9, u, vv, davg);
+        const V4 pw = xform(Mr + 34, pc);
+        out_points[p] = pw.x;
+        out_points[hw + p] = pw.y;
+        out_points[2 * hw + p] = pw.z;
+    }
+}
+
+}  // namespace
+
+extern "C" int effi_fusion_dynamic_filter_f32(const float* ref_depth, const float* src_depths, const float* ref_cam,
+                                              const float* src_cams, int n_src, int h, int w, const float* ref_conf, int conf_h,
+                                              int conf_w, float prob_threshold, int dh_view_num, float dist_base,
+                                              float rel_diff_base, int relative, float* mats_scratch, float* out_depth,
+                                              unsigned char* out_geo_mask, unsigned char* out_prob_mask,
+                                              unsigned char* out_mask, float* out_points, float* out_reproj_xyd,
+                                              effi_stream_t stream) {
+    if (!ref_depth || !src_depths || !ref_cam || !src_cams || !mats_scratch || !out_depth) return EFFI_ERR_BADARG;
+    if (n_src < 1 || h < 2 || w < 2 || dh_view_num < 1 || dh_view_num > n_src || dist_base <= 0.0f || rel_diff_base <= 0.0f)
+        return EFFI_ERR_BADARG;
+    if (n_src > FUS_MAX_VIEWS) return EFFI_ERR_UNSUPPORTED;
+    if (ref_conf && (conf_h < 1 || conf_w < 1)) return EFFI_ERR_BADARG;
+    hipStream_t st = effi_s(stream);
+    hipLaunchKernelGGL(fusion_prepare_kernel, dim3(1), dim3(64), 0, st, ref_cam, src_cams, n_src, mats_scratch);
+    EFFI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fusion_dynamic_filter_kernel, dim3(effi_cdiv((long)h * w, 256)), dim3(256), 0, st, ref_depth, src_depths,
+                       n_src, h, w, mats_scratch, ref_conf, conf_h, conf_w, prob_threshold, dh_view_num, dist_base, rel_diff_base,
+                       relative, out_depth, out_geo_mask, out_prob_mask, out_mask, out_points, out_reproj_xyd);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}

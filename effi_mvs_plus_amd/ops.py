@@ -395,6 +395,37 @@ def deconv3d_k3s2_x3(x, wpack, bias, cout, relu=True, skip=None):
     return out
 
 
+def fusion_dynamic_filter(ref_depth, src_depths, ref_cam, src_cams, ref_conf=None, prob_threshold=0.0, dh_view_num=2,
+                          dist_base=4.0, rel_diff_base=1300.0, relative=False, want_points=True, want_reproj=False):
+    """Scope row n3: one reference view through the dynamic geometric-consistency filter (misc/fusion.py:117-181,
+    test_tank.py:466-512).  ref_depth [h,w]; src_depths [V,h,w]; ref_cam [2,4,4]; src_cams [V,2,4,4]; ref_conf [H,W] or None
+    -> dict(depth [h,w], geo_mask / prob_mask / mask [h,w] uint8, points [3,h,w] or None, reproj_xyd [V,3,h,w] or None)."""
+    for name, t_ in (("ref_depth", ref_depth), ("src_depths", src_depths), ("ref_cam", ref_cam), ("src_cams", src_cams)):
+        _t(t_, name)
+    V, h, w = src_depths.shape
+    dev = ref_depth.device
+    if tuple(ref_depth.shape) != (h, w) or tuple(ref_cam.shape) != (2, 4, 4) or tuple(src_cams.shape) != (V, 2, 4, 4):
+        raise ValueError("fusion_dynamic_filter: ref_depth [h,w], src_depths [V,h,w], ref_cam [2,4,4], src_cams [V,2,4,4]")
+    ch = cw = 0
+    if ref_conf is not None:
+        _t(ref_conf, "ref_conf")
+        ch, cw = ref_conf.shape
+    out = {"depth": torch.empty(h, w, device=dev, dtype=torch.float32),
+           "geo_mask": torch.empty(h, w, device=dev, dtype=torch.uint8),
+           "prob_mask": torch.empty(h, w, device=dev, dtype=torch.uint8),
+           "mask": torch.empty(h, w, device=dev, dtype=torch.uint8),
+           "points": torch.empty(3, h, w, device=dev, dtype=torch.float32) if want_points else None,
+           "reproj_xyd": torch.empty(V, 3, h, w, device=dev, dtype=torch.float32) if want_reproj else None}
+    scratch = torch.empty(52 * (V + 1), device=dev, dtype=torch.float32)
+    work = lambda: {"flops": 0.0, "bytes": 4.0 * h * w * (1 + V + 1 + (3 if want_points else 0)) + 3.0 * h * w}
+    check(_call("fusion_dynamic_filter", work, _lib.lib().effi_fusion_dynamic_filter_f32, _p(ref_depth), _p(src_depths),
+                _p(ref_cam), _p(src_cams), V, h, w, _p(ref_conf), ch, cw, float(prob_threshold), int(dh_view_num),
+                float(dist_base), float(rel_diff_base), int(bool(relative)), _p(scratch), _p(out["depth"]), _p(out["geo_mask"]),
+                _p(out["prob_mask"]), _p(out["mask"]), _p(out["points"]), _p(out["reproj_xyd"]), _stream()),
+          "effi_fusion_dynamic_filter_f32")
+    return out
+
+
 def softmax_regress_conf(logits, depth):
     """logits [D,h,w]; depth [D] / [D,h,w] -> (depth [h,w], confidence [h,w])."""
     D, h, w = logits.shape

@@ -104,3 +104,31 @@ def randomize_state_dict(sd, seed=0):
                 w = w * 0.05        # keep GRU deltas to a few percent of the inverse-depth range
             out[k] = w
     return out
+
+
+def synth_depth_maps(H, W, N, seed=0, noise_mm=0.4, outlier_frac=0.05):
+    """Depth maps of ONE analytic scene (a tilted plane with a smooth bump field evaluated per view) for the ring of
+    ``synth_cameras``: (depths [N,H,W] fp32, cams [N,2,4,4] fp32 at full resolution "stage3").  Used by the depth-fusion
+    tests / bench: views agree up to ``noise_mm`` except in random blocks (``outlier_frac`` of the image) that are offset by
+    several mm, so that the consistency masks are neither empty nor full."""
+    g = torch.Generator().manual_seed(seed)
+    cams = synth_cameras(H, W, N, torch.float64)["stage3"][0]          # [N,2,4,4]: extrinsic, intrinsic
+    nrm = torch.tensor([0.08, -0.05, 1.0], dtype=torch.float64)
+    nrm = nrm / nrm.norm()
+    dpl = float(nrm[2]) * 680.0
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64) + 0.5, torch.arange(W, dtype=torch.float64) + 0.5, indexing="ij")
+    pix = torch.stack([xs, ys, torch.ones_like(xs)], 0).reshape(3, -1)
+    depths = []
+    for v in range(N):
+        E, K = cams[v, 0], cams[v, 1, :3, :3]
+        R, t = E[:3, :3], E[:3, 3]
+        C = -R.t() @ t
+        dirs = R.t() @ (torch.linalg.inv(K) @ pix)                       # world direction per unit camera depth
+        tt = (dpl - nrm @ C) / (nrm @ dirs)                               # camera-frame depth of the plane hit
+        d = tt.reshape(H, W).float()
+        d = d + noise_mm * torch.randn(H, W, generator=g)
+        blocks = torch.rand(max(H // 16, 1), max(W // 16, 1), generator=g) < outlier_frac
+        off = (torch.rand(blocks.shape, generator=g) * 12.0 + 3.0) * blocks
+        d = d + torch.nn.functional.interpolate(off[None, None], size=(H, W), mode="nearest")[0, 0]
+        depths.append(d)
+    return torch.stack(depths), cams.float()

@@ -247,6 +247,22 @@ int effi_stage1_hypotheses_f32(const float* disp_range, int n_range, int D, floa
  * in [C][h][w] -> out [C][h*f][w*f]. */
 int effi_upsample_nearest_f32(const float* in, int C, int h, int w, int f, float* out, effi_stream_t stream);
 
+/* ---- n3: dynamic geometric-consistency filter + depth averaging of the Tanks-and-Temples driver,
+ * misc/fusion.py:117-181 (get_reproj_dynamic, vis_filter_dynamic) and the tensor part of test_tank.py:466-512, one reference
+ * view per call.  ref_depth [h][w]; src_depths [n_src][h][w]; ref_cam [2][4][4] (extrinsic, intrinsic), src_cams
+ * [n_src][2][4][4]; ref_conf [conf_h][conf_w] or NULL (then the photometric mask is all ones); thresholds i/dist_base and
+ * i/rel_diff_base for i = dh_view_num .. n_src; relative != 0 divides the depth difference by ref_depth.
+ * mats_scratch: >= 52*(n_src+1) floats of device memory (per-view K, K^-1, E, E^-1; filled by the call).
+ * Outputs: out_depth [h][w] averaged depth; out_geo_mask / out_prob_mask / out_mask [h][w] bytes (0/1; any may be NULL);
+ * out_points [3][h][w] world coordinates of the averaged depth or NULL; out_reproj_xyd [n_src][3][h][w] or NULL.
+ * n_src <= 16. */
+int effi_fusion_dynamic_filter_f32(const float* ref_depth, const float* src_depths, const float* ref_cam,
+                                   const float* src_cams, int n_src, int h, int w, const float* ref_conf, int conf_h,
+                                   int conf_w, float prob_threshold, int dh_view_num, float dist_base, float rel_diff_base,
+                                   int relative, float* mats_scratch, float* out_depth, unsigned char* out_geo_mask,
+                                   unsigned char* out_prob_mask, unsigned char* out_mask, float* out_points,
+                                   float* out_reproj_xyd, effi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

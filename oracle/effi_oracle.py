@@ -495,3 +495,109 @@ def full_forward(sd, imgs, proj_matrices, depth_values, **kw):
     features = [feature_net(sd, "feature", imgs[:, v]) for v in range(imgs.size(1))]
     context = feature_net(sd, "cnet_depth", imgs[:, 0])
     return hot_path(sd, features, context, proj_matrices, depth_values, **kw)
+
+
+# =============================================================================================
+# n3: dynamic geometric-consistency filter + depth averaging of the Tanks-and-Temples driver
+# (reference: misc/fusion.py:8-46,117-181 and the tensor part of test_tank.py:466-512).  Device agnostic
+# (the reference's get_pixel_grids hard-codes .cuda()); same operations in the same order, fp32.
+# =============================================================================================
+def fusion_pixel_grids(height, width, device=None):
+    """misc/fusion.py:8-13 -> [h,w,3,1] pixel centres (x+0.5, y+0.5, 1)."""
+    x = (torch.arange(width, dtype=torch.float32, device=device) + 0.5).repeat(height, 1)
+    y = (torch.arange(height, dtype=torch.float32, device=device) + 0.5).repeat(width, 1).t()
+    return torch.stack([x, y, torch.ones_like(x)], dim=-1).unsqueeze(-1)
+
+
+def fusion_idx_img2cam(idx_img_homo, depth, cam):
+    """misc/fusion.py:23-28."""
+    idx_cam = cam[:, 1:2, :3, :3].unsqueeze(1).inverse() @ idx_img_homo
+    idx_cam = idx_cam / (idx_cam[..., -1:, :] + 1e-9) * depth.permute(0, 2, 3, 1).unsqueeze(4)
+    return torch.cat([idx_cam, torch.ones_like(idx_cam[..., -1:, :])], dim=-2)
+
+
+def fusion_idx_cam2world(idx_cam_homo, cam):
+    """misc/fusion.py:31-34."""
+    w = cam[:, 0:1, ...].unsqueeze(1).inverse() @ idx_cam_homo
+    return w / (w[..., -1:, :] + 1e-9)
+
+
+def fusion_idx_world2cam(idx_world_homo, cam):
+    """misc/fusion.py:37-40."""
+    c = cam[:, 0:1, ...].unsqueeze(1) @ idx_world_homo
+    return c / (c[..., -1:, :] + 1e-9)
+
+
+def fusion_idx_cam2img(idx_cam_homo, cam):
+    """misc/fusion.py:43-47."""
+    idx_cam = idx_cam_homo[..., :3, :] / (idx_cam_homo[..., 3:4, :] + 1e-9)
+    img = cam[:, 1:2, :3, :3].unsqueeze(1) @ idx_cam
+    return img / (img[..., -1:, :] + 1e-9)
+
+
+def fusion_get_reproj_dynamic(ref_depth, srcs_depth, ref_cam, srcs_cam):
+    """misc/fusion.py:117-156: ref pixel -> src view (bilinear depth sample) -> back to the ref view.
+    ref_depth [n,1,h,w], srcs_depth [n,v,1,h,w], cams [n,(v,)2,4,4] -> (reproj_xyd [n,v,3,h,w], ref_idx_cam, src2ref_idx_cam)."""
+    n, v, _, h, w = srcs_depth.size()
+    srcs_depth_f = srcs_depth.reshape(n * v, 1, h, w)
+    srcs_cam_f = srcs_cam.reshape(n * v, 2, 4, 4)
+    ref_cam_r = ref_cam.unsqueeze(1).repeat(1, v, 1, 1, 1).view(n * v, 2, 4, 4)
+    ref_depth_f = ref_depth.unsqueeze(1).repeat(1, v, 1, 1, 1).view(n * v, 1, h, w)
+    idx_img = fusion_pixel_grids(h, w, ref_depth.device).unsqueeze(0)
+    ref_idx_cam = fusion_idx_img2cam(idx_img, ref_depth_f, ref_cam_r)
+    ref_idx_world = fusion_idx_cam2world(ref_idx_cam, ref_cam_r)
+    ref2src_idx_cam = fusion_idx_world2cam(ref_idx_world, srcs_cam_f)
+    ref2src_idx_img = fusion_idx_cam2img(ref2src_idx_cam, srcs_cam_f)
+    warp_coord = ref2src_idx_img[..., :2, 0]
+    px = warp_coord[..., 0] / ((w - 1) / 2) - 1
+    py = warp_coord[..., 1] / ((h - 1) / 2) - 1
+    warped = F.grid_sample(srcs_depth_f, torch.stack((px, py), dim=-1), mode="bilinear", padding_mode="zeros", align_corners=True)
+    warp_homo = torch.cat([warp_coord, torch.ones_like(warp_coord[..., -1:])], dim=-1).unsqueeze(-1)
+    src_idx_cam = fusion_idx_img2cam(warp_homo, warped, srcs_cam_f)
+    src_idx_world = fusion_idx_cam2world(src_idx_cam, srcs_cam_f)
+    src2ref_idx_cam = fusion_idx_world2cam(src_idx_world, ref_cam_r)
+    reproj_depth = src2ref_idx_cam[:, :, :, 2, 0].clone()
+    src2ref_img = fusion_idx_cam2img(src2ref_idx_cam, ref_cam_r)
+    xyd = torch.cat([src2ref_img[..., :2, 0], reproj_depth.unsqueeze(-1)], dim=-1).permute(0, 3, 1, 2)
+    return xyd.reshape(n, v, 3, h, w), ref_idx_cam, src2ref_idx_cam
+
+
+def fusion_vis_filter_dynamic(ref_depth, reproj_xyd, dist_base=4, rel_diff_base=1300, thres_view=2, relative=False):
+    """misc/fusion.py:159-181 -> (masks [n,v,v+1-thres_view,h,w] bool, mask = masks of the loosest threshold [n,v,1,h,w])."""
+    n, v, _, h, w = reproj_xyd.size()
+    xy = fusion_pixel_grids(h, w, reproj_xyd.device).permute(3, 2, 0, 1).unsqueeze(1)[:, :, :2]
+    corrd_diff = (reproj_xyd[:, :, :2, :, :] - xy).norm(dim=2, keepdim=True)
+    depth_diff = (ref_depth.unsqueeze(1) - reproj_xyd[:, :, 2:, :, :]).abs()
+    if relative:
+        depth_diff = depth_diff / ref_depth.unsqueeze(1)
+    steps = torch.arange(thres_view, v + 1, device=reproj_xyd.device).reshape(1, 1, -1, 1, 1).repeat(n, v, 1, 1, 1)
+    masks = torch.min(corrd_diff < steps / dist_base, depth_diff < steps / rel_diff_base)
+    return masks, masks[:, :, -1:, :, :]
+
+
+def fusion_dynamic_filter(ref_depth, src_depths, ref_cam, src_cams, ref_conf, prob_threshold, dh_view_num, dist_filter,
+                          depth_filter, relative=False):
+    """Tensor part of ``dynamic_filter_depth`` (test_tank.py:466-512) for one reference view.
+    ref_depth [n,1,h,w]; src_depths [n,v,1,h,w]; ref_conf [n,H,W] -> dict(depth [n,1,h,w] averaged depth, geo_mask / prob_mask /
+    mask [n,1,h,w] bool, points [n,3,h,w] world coordinates of the averaged depth)."""
+    n, v, _, h, w = src_depths.size()
+    dy_range = v + 1
+    conf = F.interpolate(ref_conf.unsqueeze(1), size=[h, w], mode="nearest")
+    prob_mask = (conf > prob_threshold).squeeze(1)
+    reproj_xyd, _, _ = fusion_get_reproj_dynamic(ref_depth, src_depths, ref_cam, src_cams)
+    vis_masks, vis_mask = fusion_vis_filter_dynamic(ref_depth, reproj_xyd, dist_base=dist_filter, rel_diff_base=depth_filter,
+                                                    thres_view=dh_view_num, relative=relative)
+    reproj_depth = reproj_xyd[:, :, -1].clone()
+    reproj_depth[~vis_mask.squeeze(2)] = 0
+    geo_mask_sums = vis_masks.sum(dim=1)
+    geo_mask_sum = vis_mask.sum(dim=1)
+    depth_avg = (torch.sum(reproj_depth, dim=1, keepdim=True) + ref_depth) / (geo_mask_sum + 1)
+    geo_mask = geo_mask_sum >= dy_range
+    for i in range(dh_view_num, dy_range):
+        geo_mask = torch.logical_or(geo_mask, geo_mask_sums[:, i - dh_view_num] >= i)
+    mask = torch.min(prob_mask, geo_mask)
+    idx_img = fusion_pixel_grids(h, w, ref_depth.device).unsqueeze(0)
+    idx_cam = fusion_idx_img2cam(idx_img, depth_avg, ref_cam)
+    points = fusion_idx_cam2world(idx_cam, ref_cam)[..., :3, 0].permute(0, 3, 1, 2)
+    return {"depth": depth_avg, "geo_mask": geo_mask.reshape(n, 1, h, w), "prob_mask": prob_mask.reshape(n, 1, h, w),
+            "mask": mask.reshape(n, 1, h, w), "points": points, "reproj_xyd": reproj_xyd}
