@@ -312,10 +312,18 @@ def main():
             return net.forward_hot(f, net.cnet_depth.forward_torch(imgs[:, 0]), pm_d, dv_d)
 
         with torch.no_grad():
+            fg_ms = None
+            if graphed is not None:
+                from effi_mvs_plus_amd.graph import ForwardGraph
+                fg = ForwardGraph(net, imgs, pm_d, dv_d)
+                fg_ms = timed(fg.replay)
+                del fg
             full_ms = timed(lambda: net(imgs, pm_d, dv_d))
             fpn_ms = timed(lambda: ([net.feature(imgs[:, v]) for v in range(N)], net.cnet_depth(imgs[:, 0])))
             full_torch_fpn_ms = timed(fwd_torch_fpn)
-        result["whole_forward"] = {"ms_per_view": full_ms, "views_per_s": 1e3 / full_ms, "feature_pyramids_ms": fpn_ms,
+        best_ms = full_ms if fg_ms is None else min(fg_ms, full_ms)
+        result["whole_forward"] = {"ms_per_view": best_ms, "views_per_s": 1e3 / best_ms, "ms_per_view_graph_replay": fg_ms,
+                                   "ms_per_view_eager": full_ms, "feature_pyramids_ms": fpn_ms,
                                    "ms_per_view_with_stock_pytorch_pyramid": full_torch_fpn_ms,
                                    "note": "images resident in HBM -> 13 depth maps + confidence; N feature nets + 1 context net + hot path"}
         del imgs

@@ -37,10 +37,13 @@ def _clone_tree(obj):
     return obj
 
 
-class HotPathGraph:
-    def __init__(self, net, features, cnet_depth, proj_matrices, depth_values, warmup=2, slots=1):
-        self.net = net
-        example = (features, cnet_depth, proj_matrices, depth_values)
+class ReplayGraph:
+    """hipGraph replay of ``fn(*inputs)`` for a fixed input geometry (see the module docstring); ``fn`` must be free of
+    host synchronisation and of data-dependent host control flow (``forward_hot`` and ``forward`` are)."""
+
+    def __init__(self, fn, example, warmup=2, slots=1):
+        self.fn = fn
+        example = tuple(example)
         self.inputs = [_clone_tree(example) for _ in range(slots)]
         self._flat_in = [_flatten(inp, []) for inp in self.inputs]
         self._sig = [(tuple(t.shape), t.dtype) for t in self._flat_in[0]]
@@ -48,31 +51,46 @@ class HotPathGraph:
         side.wait_stream(torch.cuda.current_stream())
         with torch.no_grad(), torch.cuda.stream(side):
             for _ in range(warmup):                     # packs weights, creates the zero page, warms the allocator
-                net.forward_hot(*self.inputs[0])
+                fn(*self.inputs[0])
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graphs, self.outputs = [], []
         for inp in self.inputs:
             g = torch.cuda.CUDAGraph()
             with torch.no_grad(), torch.cuda.graph(g):
-                out = net.forward_hot(*inp)
+                out = fn(*inp)
             self.graphs.append(g)
             self.outputs.append(out)
 
-    def load(self, slot, features, cnet_depth, proj_matrices, depth_values):
+    def load(self, slot, *inputs):
         """Device-to-device copy of one view's inputs into a slot's static buffers."""
-        flat = _flatten((features, cnet_depth, proj_matrices, depth_values), [])
+        flat = _flatten(tuple(inputs), [])
         if len(flat) != len(self._sig):
-            raise ValueError("HotPathGraph: input structure differs from the captured one")
+            raise ValueError("ReplayGraph: input structure differs from the captured one")
         for src, (shape, dtype) in zip(flat, self._sig):
             if tuple(src.shape) != shape or src.dtype != dtype:
-                raise ValueError(f"HotPathGraph: input {tuple(src.shape)}/{src.dtype} differs from the captured {shape}/{dtype}")
+                raise ValueError(f"ReplayGraph: input {tuple(src.shape)}/{src.dtype} differs from the captured {shape}/{dtype}")
         torch._foreach_copy_(self._flat_in[slot], flat)
 
     def replay(self, slot=0):
         self.graphs[slot].replay()
         return self.outputs[slot]
 
-    def __call__(self, features, cnet_depth, proj_matrices, depth_values, slot=0):
-        self.load(slot, features, cnet_depth, proj_matrices, depth_values)
+    def __call__(self, *inputs, slot=0):
+        self.load(slot, *inputs)
         return self.replay(slot)
+
+
+class HotPathGraph(ReplayGraph):
+    """``Effi_MVS_plus.forward_hot(features, cnet_depth, proj_matrices, depth_values)`` as a replayable graph."""
+
+    def __init__(self, net, features, cnet_depth, proj_matrices, depth_values, warmup=2, slots=1):
+        super().__init__(net.forward_hot, (features, cnet_depth, proj_matrices, depth_values), warmup=warmup, slots=slots)
+
+
+class ForwardGraph(ReplayGraph):
+    """The whole ``Effi_MVS_plus.forward(imgs, proj_matrices, depth_values)`` (feature / context pyramids + hot path) as a
+    replayable graph -- what the reference's drivers time per view (test_dtu_dypcd.py:437-442)."""
+
+    def __init__(self, net, imgs, proj_matrices, depth_values, warmup=2, slots=1):
+        super().__init__(net.forward, (imgs, proj_matrices, depth_values), warmup=warmup, slots=slots)

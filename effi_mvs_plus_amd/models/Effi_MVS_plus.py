@@ -354,6 +354,15 @@ class Effi_MVS_plus(nn.Module):
         disp_max = depth_values[:, -1, None, None, None]
         self.scale_inv_depth = partial(disp_to_depth, min_depth=1. / disp_max, max_depth=1. / disp_min)
         self.scale_inv_depth.effi_disp_range = depth_values
-        features = [self.feature(imgs[:, v]) for v in range(imgs.size(1))]
-        cnet_depth = self.cnet_depth(imgs[:, 0])
+        # the N + 1 pyramid passes are independent: odd views and the context net go to the side stream (their coarse layers
+        # do not fill the chip on their own)
+        n_views = imgs.size(1)
+        features = [None] * n_views
+        with ops.Branch() as br:
+            for v in range(1, n_views, 2):
+                features[v] = self.feature(imgs[:, v])
+            cnet_depth = self.cnet_depth(imgs[:, 0])
+        for v in range(0, n_views, 2):
+            features[v] = self.feature(imgs[:, v])
+        br.join(*[t_ for v in range(1, n_views, 2) for t_ in features[v].values()], *cnet_depth.values())
         return self.forward_hot(features, cnet_depth, proj_matrices, depth_values)
