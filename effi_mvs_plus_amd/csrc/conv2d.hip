@@ -596,9 +596,14 @@ __device__ __forceinline__ void split_octet(const f32x4 (&pa)[8], int px, bf16x8
     }
 }
 
-template <int NT, int MR, int EPI, bool ZB = false>
+// WIDE: the workgroup's tile is 4 rows x 16*MR columns (one row per wave, MR column groups per wave) instead of 4*MR rows x 16
+// columns: same LDS image size and halo factor, but every row segment the tile reads (64*MR + 32 bytes) and writes (64*MR bytes)
+// is MR times longer, which is what HBM likes once the working set no longer fits the 256 MB MALL.
+template <int NT, int MR, int EPI, bool ZB = false, bool WIDE = false>
 __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs a, int tiles_x, int ntiles) {
-    constexpr int TR = 4 * MR, AR = TR + 2, AW = 24, AQ = 6, XOFF = 3, XLEFT = 4, CCH = 16, NKS = 5;
+    constexpr int TR = WIDE ? 4 : 4 * MR, TW = WIDE ? 16 * MR : 16;
+    constexpr int AR = TR + 2, AW = TW + 8, AQ = AW / 4, XOFF = 3, XLEFT = 4, CCH = 16, NKS = 5;
+    constexpr int MROW = WIDE ? 0 : AW * 8, MCOL = WIDE ? 16 * 8 : 0;   // LDS element step between a wave's MR sub-tiles
     constexpr int APIX = AR * AW, NITEMS = (APIX / 4) * 2;             // staging work items: (pixel quad, octet)
     constexpr int NBF = NKS * NT * 2 * 64;                             // 16-byte units of B per chunk
     constexpr int NB4 = (NBF + 255) / 256;
@@ -615,7 +620,7 @@ __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs 
     const int tile = effi_xcd_remap(blockIdx.x, gridDim.x);
     if (tile >= ntiles) return;
     const int ty_ = tile / tiles_x;
-    const int x0 = (tile - ty_ * tiles_x) * 16, y0 = ty_ * TR;
+    const int x0 = (tile - ty_ * tiles_x) * TW, y0 = ty_ * TR;
     const int zpl = ZB ? (int)blockIdx.y : 0;
 
     // staging item of this thread
@@ -684,7 +689,7 @@ __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs 
     for (int s_ = 0; s_ < NKS; ++s_) {
         const int item = 4 * s_ + lk;
         const int tap = min(item >> 1, 8), oct = item & 1;               // items 18, 19 are padding (B is zero there)
-        koff[s_] = ((wv * MR + tap / 3) * AW + li + XOFF + tap % 3 + oct * APIX) * 8;
+        koff[s_] = (((WIDE ? wv : wv * MR) + tap / 3) * AW + li + XOFF + tap % 3 + oct * APIX) * 8;
     }
 
     f32x4 acc[MR][NT];
@@ -703,8 +708,8 @@ __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs 
             bf16x8 ah[MR], al[MR];
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
-                ah[m] = *reinterpret_cast<const bf16x8*>(&lds_ah[koff[s_] + m * AW * 8]);
-                al[m] = *reinterpret_cast<const bf16x8*>(&lds_al[koff[s_] + m * AW * 8]);
+                ah[m] = *reinterpret_cast<const bf16x8*>(&lds_ah[koff[s_] + m * (MROW + MCOL)]);
+                al[m] = *reinterpret_cast<const bf16x8*>(&lds_al[koff[s_] + m * (MROW + MCOL)]);
             }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -726,10 +731,10 @@ __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs 
         }
     }
 
-    const int x = x0 + li;                                             // lane = (pixel li, channels 4*lk .. 4*lk+3)
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
-        const int y = y0 + wv * MR + m;
+        const int x = x0 + li + (WIDE ? 16 * m : 0);                   // lane = (pixel li, channels 4*lk .. 4*lk+3)
+        const int y = y0 + (WIDE ? wv : wv * MR + m);
         if (y >= h || x >= w) continue;
         const long pix = (long)y * w + x;
 #pragma unroll
@@ -1478,6 +1483,18 @@ static int launch_bf16x3(const Conv2dArgs& a, hipStream_t st) {
     else mr = 1;
     static const char* force = getenv("EFFI_FORCE_MR");
     if (force) mr = atoi(force);
+    // wide tiles (4 rows x 64 columns) pay off on the large maps only (measured with an HBM-cold working set, 592x800:
+    // 16->16 23.8 -> 22.6 us, 32->12 33.3 -> 30.7, 32->16 GRU update 41.9 -> 38.6; 296x400: 38 -> 49 us for 64->64)
+    static const char* wide_env = getenv("EFFI_WIDE_TILES");
+    const bool wide = wide_env ? atoi(wide_env) != 0 : (mr == 4 && a.w >= 512 && !ZB);
+    if (wide) {
+        const int tiles_x = effi_cdiv(a.w, 16 * mr), ntiles = tiles_x * effi_cdiv(a.h, 4);
+        const dim3 grid(ntiles, (unsigned)planes);
+        if (mr == 4) hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 4, EPI, ZB, true>), grid, dim3(256), 0, st, a, tiles_x, ntiles);
+        else if (mr == 2) hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 2, EPI, ZB, true>), grid, dim3(256), 0, st, a, tiles_x, ntiles);
+        else hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 1, EPI, ZB, true>), grid, dim3(256), 0, st, a, tiles_x, ntiles);
+        return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+    }
     const int tiles_x = (int)cols, ntiles = tiles_x * effi_cdiv(a.h, 4 * mr);
     const dim3 grid(ntiles, (unsigned)planes);
     if (mr == 4) hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 4, EPI, ZB>), grid, dim3(256), 0, st, a, tiles_x, ntiles);
