@@ -578,6 +578,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 //   * fp32 -> (hi, lo) uses the packed conversion (v_cvt_pk_bf16_f32) on channel pairs;
 //   * A fragments sit at lane_base + koff[s] + m*row with the row term as an immediate (no address swizzle: the stores are then
 //     4-way instead of 2-way conflicted, ~0.5k LDS cycles per tile, against ~150 address instructions per wave).
+#define EFFI_EPI_K1 6        // internal: the 3x3 result (+ extra channels) goes through a fused 1x1 convolution (see below)
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -609,6 +611,7 @@ __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs 
     constexpr int NB4 = (NBF + 255) / 256;
     static_assert(NITEMS <= 256, "one staging item per thread");
     static_assert(EPI != EFFI_EPI_HEAD && EPI != EFFI_EPI_ADD_UP2, "epilogue not instantiated for the split-precision kernel");
+    static_assert(EPI != EFFI_EPI_K1 || !ZB, "the fused 1x1 epilogue is 2-D only");
     __shared__ __attribute__((aligned(16))) unsigned short lds_ah[APIX * CCH];
     __shared__ __attribute__((aligned(16))) unsigned short lds_al[APIX * CCH];
     __shared__ __attribute__((aligned(16))) unsigned short lds_b[NB4 * 256 * 8];
@@ -731,6 +734,78 @@ __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs 
         }
     }
 
+    if (EPI == EFFI_EPI_K1) {
+        // Fused 1x1 convolution (convd -> convc of the encoder, models/update.py:78-80,93-96): the 3x3 result of a lane
+        // -- channels 4*lk..4*lk+3 of pixel li, per N-tile -- is exactly the B fragment of v_mfma_f32_16x16x16_bf16 (K = 16
+        // channels), so out2[co2][px] = sum_k W2[co2][k] * cat(conv3x3 + b1, extra)[k][px] needs no data movement: one K = 16 step
+        // per N-tile plus one for the extra (context) channels, weights W2 as A fragments from a small L2-resident table.
+        // Fields reused: aux0 = extra [c_extra][h][w], hd = c_extra, aux1 = W2 fragments (bf16 [NT2][NT+1][hi|lo][64][4]),
+        // disp_range = bias2, n_range = cout2, act = activation of the 1x1 result.
+        const unsigned short* w2 = reinterpret_cast<const unsigned short*>(a.aux1);
+        const int nt2 = a.n_range >> 4;
+        // B fragments of all the wave's pixels first (the extra-channel loads are issued together), then per output tile
+        // the W2 fragments are fetched once and reused for the MR sub-tiles
+        bf16x4 xh[MR][NT + 1], xl[MR][NT + 1];
+        bool inside[MR];
+        long pixm[MR];
+        f32x4 ex[MR];
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const int x = x0 + li + (WIDE ? 16 * m : 0);
+            const int y = y0 + (WIDE ? wv : wv * MR + m);
+            inside[m] = (y < h) & (x < w);
+            pixm[m] = inside[m] ? (long)y * w + x : 0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 4 * lk + r;
+                ex[m][r] = (c < a.hd) ? a.aux0[(long)c * hw + pixm[m]] : 0.0f;   // a.hd == 0: aux0 is a valid dummy, never read
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+#pragma unroll
+            for (int n = 0; n <= NT; ++n) {
+                f32x4 vf;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    vf[r] = (n < NT) ? acc[m][n][r] + a.bias[n * 16 + 4 * lk + r] : (inside[m] ? ex[m][r] : 0.0f);
+                xh[m][n] = __builtin_convertvector(vf, bf16x4);
+                xl[m][n] = __builtin_convertvector(vf - __builtin_convertvector(xh[m][n], f32x4), bf16x4);
+            }
+        }
+        for (int t = 0; t < nt2; ++t) {
+            bf16x4 wh[NT + 1], wl[NT + 1];
+#pragma unroll
+            for (int n = 0; n <= NT; ++n) {
+                const long f = ((long)(t * (NT + 1) + n) * 2) * 64 + lane;
+                wh[n] = *reinterpret_cast<const bf16x4*>(w2 + f * 4);
+                wl[n] = *reinterpret_cast<const bf16x4*>(w2 + (f + 64) * 4);
+            }
+            const int co = t * 16 + 4 * lk;
+            float b2[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b2[r] = a.disp_range[co + r];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int n = 0; n <= NT; ++n) {
+                    o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[n], xh[m][n], o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wl[n], xh[m][n], o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[n], xl[m][n], o, 0, 0, 0);
+                }
+                if (inside[m]) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = o[r] + b2[r];
+                        if (a.act == EFFI_ACT_RELU) v = fmaxf(v, 0.0f);
+                        a.out0[(long)(co + r) * hw + pixm[m]] = v;
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int m = 0; m < MR; ++m) {
         const int x = x0 + li + (WIDE ? 16 * m : 0);                   // lane = (pixel li, channels 4*lk .. 4*lk+3)
@@ -738,7 +813,7 @@ __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs 
         if (y >= h || x >= w) continue;
         const long pix = (long)y * w + x;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) conv_epilogue_store_t<EPI>(a, acc[m][n], n * 16 + 4 * lk, pix, hw, zpl);
+        for (int n = 0; n < NT; ++n) conv_epilogue_store_t<(EPI == EFFI_EPI_K1 ? EFFI_EPI_PLAIN : EPI)>(a, acc[m][n], n * 16 + 4 * lk, pix, hw, zpl);
     }
 }
 
@@ -1572,6 +1647,50 @@ extern "C" int effi_conv2d_k3_bf16x3_f32(const float* const* srcs, const int* sr
             return EFFI_ERR_UNSUPPORTED;
         default:
             return EFFI_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int effi_conv2d_k3_k1_bf16x3_f32(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
+                                            const float* bias, int cout1, const float* extra, int c_extra, const void* w2pack_bf16,
+                                            const float* bias2, int cout2, int relu, int h, int w, float* out,
+                                            effi_stream_t stream) {
+    if (!srcs || !src_channels || n_src < 1 || n_src > EFFI_MAX_SRC || !wpack_bf16 || !bias || !w2pack_bf16 || !bias2 || !out)
+        return EFFI_ERR_BADARG;
+    if (cout1 < 1 || cout2 < 16 || h < 1 || w < 1 || c_extra < 0 || (c_extra > 0 && !extra)) return EFFI_ERR_BADARG;
+    if ((w & 3) || cout1 > 48 || c_extra > 16 || (cout2 & 15) || cout2 > 96) return EFFI_ERR_UNSUPPORTED;
+    Conv2dArgs a;
+    a.cin = 0;
+    for (int i = 0; i < EFFI_MAX_SRC; ++i) {
+        a.src[i] = (i < n_src) ? srcs[i] : srcs[0];
+        a.ch[i] = (i < n_src) ? src_channels[i] : 0;
+        if (i < n_src && (!srcs[i] || src_channels[i] < 1)) return EFFI_ERR_BADARG;
+        if (i + 1 < n_src && (src_channels[i] & 7)) return EFFI_ERR_UNSUPPORTED;
+        a.cin += a.ch[i];
+    }
+    a.kgroups = 0;
+    a.zeros = effi_zero_page();
+    if (!a.zeros) return EFFI_ERR_LAUNCH;
+    a.wpack = reinterpret_cast<const float*>(wpack_bf16);
+    a.bias = bias;
+    a.cout = cout1;
+    a.h = a.hin = h;
+    a.w = a.win = w;
+    a.act = relu ? EFFI_ACT_RELU : EFFI_ACT_NONE;
+    a.hd = c_extra;
+    a.aux0 = c_extra ? extra : bias2;
+    a.aux1 = reinterpret_cast<const float*>(w2pack_bf16);
+    a.disp_range = bias2;
+    a.n_range = cout2;
+    a.out0 = out;
+    a.out1 = nullptr;
+    a.cstride = a.ostride = (long)h * w;
+    a.zcount = a.zin = 0;
+    hipStream_t st = effi_s(stream);
+    switch ((cout1 + 15) / 16) {
+        case 1: return launch_bf16x3<1, EFFI_EPI_K1>(a, st);
+        case 2: return launch_bf16x3<2, EFFI_EPI_K1>(a, st);
+        case 3: return launch_bf16x3<3, EFFI_EPI_K1>(a, st);
+        default: return EFFI_ERR_UNSUPPORTED;
     }
 }
 

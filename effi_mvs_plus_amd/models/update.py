@@ -112,7 +112,7 @@ class ProjectionInput(nn.Module):
         self.convc = nn.Conv2d(hidden_dim, hidden_dim, 1, padding=0)
         self.out_chs = hidden_dim
         self.dropout = nn.Dropout2d(p=0.1)
-        self._caches = {k: packing.PackCache() for k in ("c1", "c1raw", "c2", "d1", "d2", "d", "c")}
+        self._caches = {k: packing.PackCache() for k in ("c1", "c1raw", "c2", "d1", "d2", "d", "c", "c_after")}
 
     def convc1_raw(self):
         """convc1 as ([cost_dim, hidden] weight, [hidden] bias) for the lookup kernel that applies it in place."""
@@ -145,7 +145,14 @@ class ProjectionInput(nn.Module):
         cor = ops.conv2d([cor1], w, b, hd, 3, act=ops.ACT_RELU, out0=g("cor2"))
         br.join(dfm)
         w, b = _pack(self._caches["d"], self.convd)
-        mix = ops.conv2d([cor, dfm], w, b, self.convd.out_channels, 3, act=ops.ACT_NONE, out0=g("mix"))
+        cmix, cd = self.convd.out_channels, context.shape[0]
+        if (ops.get_precision() == "split" and w.wx is not None and cor.shape[-1] % 4 == 0 and hd % 8 == 0 and hd % 16 == 0
+                and cmix <= 48 and cd <= 16 and self.convc.in_channels == cmix + cd):
+            # convd (3x3) and convc (1x1 over [convd, context], ReLU) in one kernel: the intermediate stays in registers
+            w2, b2 = self._caches["c_after"].get([self.convc.weight, self.convc.bias],
+                                                 lambda: packing.pack_conv1x1_after(self.convc.weight, self.convc.bias, cmix, cd))
+            return ops.conv2d_k3_k1_x3([cor, dfm], w.wx, b, cmix, context, w2, b2, hd, relu=True, out=g("enc"))
+        mix = ops.conv2d([cor, dfm], w, b, cmix, 3, act=ops.ACT_NONE, out0=g("mix"))
         w, b = _pack(self._caches["c"], self.convc)
         return ops.conv2d([mix, context], w, b, hd, 1, act=ops.ACT_RELU, out0=g("enc"))
 

@@ -123,7 +123,7 @@ class Branch:
     the main stream."""
 
     def __init__(self):
-        self.enabled = _BRANCHES
+        self.enabled = _BRANCHES and torch.cuda.is_available()      # CPU tensors must reach the ops' own loud failure
         if self.enabled:
             self.main = torch.cuda.current_stream()
             key = (self.main.device.index, self.main.cuda_stream)
@@ -576,6 +576,27 @@ def conv2d_k3_bf16x3(srcs, wpack, bias, cout, epilogue=EPI_PLAIN, act=ACT_NONE, 
                 _int_array([s.shape[0] for s in srcs]), len(srcs), _p(wpack), _p(bias), cout, h, w, epilogue, act,
                 _p(aux0), _p(aux1), None, 0, _p(out0), _p(out1), _stream()), "effi_conv2d_k3_bf16x3_f32")
     return (out0, out1) if out1 is not None else out0
+
+
+def conv2d_k3_k1_x3(srcs, wpack, bias, cout1, extra, w2pack, bias2, cout2, relu=True, out=None):
+    """3x3 split-precision conv (no activation) + the 1x1 conv over cat(result, ``extra``) in one kernel
+    (``packing.pack_conv2d_bf16x3`` / ``packing.pack_conv1x1_after``) -> [cout2,h,w]."""
+    for s in srcs:
+        _t(s, "conv2d input")
+    h, w = srcs[0].shape[-2:]
+    c_extra = 0
+    if extra is not None:
+        _t(extra, "extra channels")
+        c_extra = extra.shape[0]
+    if out is None:
+        out = torch.empty(cout2, h, w, device=srcs[0].device, dtype=torch.float32)
+    cin = sum(s.shape[0] for s in srcs)
+    work = lambda: {"flops": 2.0 * h * w * (cin * cout1 * 9 + (cout1 + c_extra) * cout2),
+                    "bytes": 4.0 * h * w * (cin + c_extra + cout2)}
+    check(_call(f"conv2d_k3k1_nt{(cout1 + 15) // 16}", work, _lib.lib().effi_conv2d_k3_k1_bf16x3_f32, _ptr_array(srcs),
+                _int_array([s.shape[0] for s in srcs]), len(srcs), _p(wpack), _p(bias), cout1, _p(extra), c_extra, _p(w2pack),
+                _p(bias2), cout2, int(relu), h, w, _p(out), _stream()), "effi_conv2d_k3_k1_bf16x3_f32")
+    return out
 
 
 def conv2d_k5s2(x, wpack, bias, cout, act=ACT_RELU):

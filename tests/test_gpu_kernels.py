@@ -429,6 +429,31 @@ def test_conv2d_split_bf16(h, w, cins, cout, epi):
         check_close("bf16x3 gru q", got, want.float(), **tol)
 
 
+@pytest.mark.parametrize("h,w", [(21, 28), (130, 256), (148, 200), (72, 520)])
+@pytest.mark.parametrize("cins,cout1,c_extra,cout2", [((16, 16), 12, 4, 16), ((32, 32), 24, 8, 32), ((48, 48), 36, 12, 48),
+                                                      ((16,), 16, 0, 16), ((8, 8), 5, 3, 32)])
+def test_conv3x3_then_1x1_fused(h, w, cins, cout1, c_extra, cout2):
+    """convd -> convc of the encoder in one kernel (effi_conv2d_k3_k1_bf16x3_f32) against the two fp64 convolutions."""
+    from effi_mvs_plus_amd import ops, packing
+    g = torch.Generator().manual_seed(cout1 * 100 + h)
+    xs = [torch.randn(c, h, w, generator=g) for c in cins]
+    cin = sum(cins)
+    w1 = torch.randn(cout1, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b1 = 0.1 * torch.randn(cout1, generator=g)
+    extra = torch.randn(c_extra, h, w, generator=g) if c_extra else None
+    w2 = torch.randn(cout2, cout1 + c_extra, 1, 1, generator=g) * (2.0 / (cout1 + c_extra)) ** 0.5
+    b2 = 0.1 * torch.randn(cout2, generator=g)
+    mid = F.conv2d(torch.cat(xs).unsqueeze(0).double(), w1.double(), b1.double(), padding=1)
+    if c_extra:
+        mid = torch.cat([mid, extra.unsqueeze(0).double()], 1)
+    want = F.relu(F.conv2d(mid, w2.double(), b2.double()))[0]
+    wx, bx = packing.pack_conv2d_bf16x3(w1.to(DEV), b1.to(DEV))
+    w2p, b2p = packing.pack_conv1x1_after(w2.to(DEV), b2.to(DEV), cout1, c_extra)
+    got = ops.conv2d_k3_k1_x3([t(x, DEV) for x in xs], wx, bx, cout1, None if extra is None else t(extra, DEV), w2p, b2p, cout2)
+    check_close(f"3x3+1x1 {cins}->{cout1}(+{c_extra})->{cout2} {h}x{w}", got, want.float(), rtol=0.0,
+                atol=6e-5 * float(want.abs().max()))
+
+
 def test_conv2d_split_bf16_refuses_unaligned_sources():
     """An octet of input channels must lie in one source: (17, 3) is refused by the library, and ops.conv2d keeps such
     layers on the fp32 kernel."""
