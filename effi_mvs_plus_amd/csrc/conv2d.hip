@@ -1138,35 +1138,41 @@ __global__ __launch_bounds__(256) void deconv3d_s2_bf16x3_kernel(const DeconvArg
 // ------------------------------------------------------------------------------------------------
 // 7x7 convolution of a single-channel map (convd1, models/update.py:76,90) + ReLU; vector ALUs.
 // ------------------------------------------------------------------------------------------------
+// A workgroup computes 16 output channels (blockIdx.z = channel group) of a 32 x 8 pixel tile: the coarse stages have few
+// pixels and 32 / 48 channels, so the channel groups are what fills the chip there and what keeps the per-thread FMA chain
+// short (784 instead of 2352 at 48 channels).  COUT (the weight row stride) is a template parameter so that every weight is a
+// scalar load at a compile-time offset from the group's base.
 template <int COUT>
 __global__ __launch_bounds__(256) void conv2d_c1k7_relu_kernel(const float* __restrict__ in,
                                                                const float* __restrict__ wgt,
                                                                const float* __restrict__ bias, int h, int w,
                                                                float* __restrict__ out) {
-    constexpr int TXX = 32, TYY = 8, IWX = TXX + 6, IHY = TYY + 6;
+    constexpr int TXX = 32, TYY = 8, IWX = TXX + 6, IHY = TYY + 6, CG = 16;
     __shared__ float tile[IHY * IWX];
     const int tx = threadIdx.x % TXX, ty = threadIdx.x / TXX;
     const int x0 = blockIdx.x * TXX, y0 = blockIdx.y * TYY;
+    const int c0 = blockIdx.z * CG;
     for (int e = threadIdx.x; e < IHY * IWX; e += 256) {
         const int yy = e / IWX, xx = e - yy * IWX;
         const int gy = y0 - 3 + yy, gx = x0 - 3 + xx;
         tile[e] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? in[(long)gy * w + gx] : 0.0f;
     }
     __syncthreads();
-    float acc[COUT];
+    const float* __restrict__ wg = wgt + c0;
+    float acc[CG];
 #pragma unroll
-    for (int c = 0; c < COUT; ++c) acc[c] = bias[c];
+    for (int c = 0; c < CG; ++c) acc[c] = bias[c0 + c];
 #pragma unroll
     for (int k = 0; k < 49; ++k) {
         const float v = tile[(ty + k / 7) * IWX + tx + k % 7];
 #pragma unroll
-        for (int c = 0; c < COUT; ++c) acc[c] = fmaf(v, wgt[k * COUT + c], acc[c]);
+        for (int c = 0; c < CG; ++c) acc[c] = fmaf(v, wg[k * COUT + c], acc[c]);
     }
     const int x = x0 + tx, y = y0 + ty;
     if (x >= w || y >= h) return;
     const long hw = (long)h * w, pix = (long)y * w + x;
 #pragma unroll
-    for (int c = 0; c < COUT; ++c) out[c * hw + pix] = fmaxf(acc[c], 0.0f);
+    for (int c = 0; c < CG; ++c) out[(c0 + c) * hw + pix] = fmaxf(acc[c], 0.0f);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1828,7 +1834,7 @@ extern "C" int effi_deconv3d_k3s2_bf16x3_f32(const float* in, int cin, const voi
 extern "C" int effi_conv2d_c1k7_relu_f32(const float* in, const float* weight, const float* bias, int cout, int h,
                                          int w, float* out, effi_stream_t stream) {
     if (!in || !weight || !bias || !out || h < 1 || w < 1) return EFFI_ERR_BADARG;
-    dim3 grid(effi_cdiv(w, 32), effi_cdiv(h, 8));
+    dim3 grid(effi_cdiv(w, 32), effi_cdiv(h, 8), cout / 16);
     hipStream_t st = effi_s(stream);
     switch (cout) {
         case 16: hipLaunchKernelGGL(conv2d_c1k7_relu_kernel<16>, grid, dim3(256), 0, st, in, weight, bias, h, w, out); break;
