@@ -10,7 +10,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libeffimvs_hip.so")
+LIB_PATH = os.environ.get("EFFI_MVS_LIB") or os.path.join(_HERE, "libeffimvs_hip.so")   # override: A/B runs of two builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "effi_mvs_hip.h")
 
 _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
