@@ -208,8 +208,9 @@ def main():
         bytes_per_launch = ksum["bytes"] / ksum["launches"]
         intensity = flops_per_launch / max(bytes_per_launch, 1.0)
         # split-precision kernels: three bf16 MFMAs per fp32-equivalent product
-        mfma_peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if key.startswith("conv2d_k3x3") else PEAK_FP32_MFMA_TFLOPS
-        if key.startswith("conv") and intensity > mfma_peak * 1e12 / (PEAK_HBM_GBPS * 1e9):
+        split_keys = ("conv2d_k3x3", "conv2d_k3k1", "conv3d_x3", "conv3d_roll", "deconv3d_x3")
+        mfma_peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if key.startswith(split_keys) else PEAK_FP32_MFMA_TFLOPS
+        if key.startswith(("conv", "deconv")) and intensity > mfma_peak * 1e12 / (PEAK_HBM_GBPS * 1e9):
             roof = {"bound": "mfma", "achieved": flops_per_launch / (avg_ms * 1e-3) / 1e12, "peak": mfma_peak,
                     "unit": "TFLOP/s"}
         else:
