@@ -110,15 +110,23 @@ def main():
     torch.cuda.synchronize()
 
     graphed = None
+    graph_fallback = None
     if args.launch == "graph":
         from effi_mvs_plus_amd.graph import HotPathGraph
         # double-buffered input slots (as a producer of features would fill them); the two synthetic views are loaded
         # into the slots before the timed region -- "inputs resident in HBM" -- and a step replays the slot's graph
         n_slots = max(n_scenes, args.in_flight)
-        graphed = HotPathGraph(net, *inputs[0], slots=n_slots)
-        for i in range(n_slots):
-            graphed.load(i, *inputs[i % n_scenes])
-        torch.cuda.synchronize()
+        try:
+            graphed = HotPathGraph(net, *inputs[0], slots=n_slots)
+            for i in range(n_slots):
+                graphed.load(i, *inputs[i % n_scenes])
+            torch.cuda.synchronize()
+        except Exception as exc:      # capture refused by the runtime (never seen on one GPU): keep measuring, eagerly
+            print(f"[bench] rank {rank}: hipGraph capture failed ({type(exc).__name__}: {exc}); falling back to eager launches",
+                  file=sys.stderr)
+            graphed = None
+            graph_fallback = f"{type(exc).__name__}: {exc}"
+            torch.cuda.synchronize()
         lanes = [torch.cuda.Stream() for _ in range(max(1, args.in_flight))]
 
     def step(i):
@@ -250,6 +258,7 @@ def main():
                        "parallelism": f"view-sharded x{world}, {'RCCL' if args.backend == 'nccl' else 'gloo (rehearsal)'} gather of "
                                       f"depth+confidence to rank 0 inside the timed region" if world > 1 else "single GPU"},
             "in_flight": (max(1, args.in_flight) if graphed is not None else 1),
+            **({"graph_fallback": graph_fallback} if graph_fallback else {}),
             "roofline": roof,
             "kernel_breakdown_ms": {k: round(v["ms"], 4) for k, v in sorted(disc.items(), key=lambda kv: -kv[1]["ms"])},
         }

@@ -57,7 +57,9 @@ class ReplayGraph:
         self.graphs, self.outputs = [], []
         for inp in self.inputs:
             g = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(g):
+            # thread_local: CUDA/HIP calls of other threads (e.g. the RCCL watchdog of torch.distributed) do not
+            # invalidate the capture
+            with torch.no_grad(), torch.cuda.graph(g, capture_error_mode="thread_local"):
                 out = fn(*inp)
             self.graphs.append(g)
             self.outputs.append(out)
