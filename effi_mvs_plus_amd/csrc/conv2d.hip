@@ -999,11 +999,25 @@ __host__ __device__ constexpr int deconv_slot(int p, int s) {
     return n;
 }
 
-template <int MR, bool ALIGNED>
+// HALF (cout <= 8): the two x-parities of a channel share ONE N-tile (row j = px*8 + co), i.e. 4 parity tiles (pz,py), 9 B
+// fragments and half the MFMAs; the x-parities then sit in lanes lk and lk+2 of the same store instruction, which together
+// still cover 128 contiguous bytes of the output row.
+__host__ __device__ constexpr int deconv_slot_half(int pzy, int s) {       // fragment index when only (pz,py) tiles exist
+    int n = 0;
+    for (int pp = 0; pp < 4; ++pp)
+        for (int ss = 0; ss < 4; ++ss) {
+            if (pp == pzy && ss == s) return n;
+            if (deconv_step_used(2 * pp, ss)) ++n;
+        }
+    return n;
+}
+
+template <int MR, bool ALIGNED, bool HALF>
 __global__ __launch_bounds__(256) void deconv3d_s2_bf16x3_kernel(const DeconvArgs a, int tiles_x, int tiles_xy) {
     constexpr int TR = 4 * MR, AR = TR + 1, AW = 20, AQ = 5, APIX = AR * AW, NQ = APIX / 4;
     constexpr int NITEMS = 4 * NQ;                                     // (octet, plane, pixel quad)
-    constexpr int NSLOT = 18, NBF = NSLOT * 2 * 64;                    // 16-byte units of B per chunk
+    constexpr int NP = HALF ? 4 : 8;                                    // parity tiles
+    constexpr int NSLOT = HALF ? 9 : 18, NBF = NSLOT * 2 * 64;         // 16-byte units of B per chunk
     static_assert(NITEMS <= 256, "one staging item per thread");
     __shared__ __attribute__((aligned(16))) unsigned short lds_ah[4 * APIX * 8];     // [plane][octet][pixel][8]
     __shared__ __attribute__((aligned(16))) unsigned short lds_al[4 * APIX * 8];
@@ -1035,11 +1049,11 @@ __global__ __launch_bounds__(256) void deconv3d_s2_bf16x3_kernel(const DeconvArg
         koff[s_] = ((nz * 2 + oct) * APIX + (wv * MR + ny) * AW + li + nx) * 8;
     }
 
-    f32x4 acc[MR][8];
+    f32x4 acc[MR][NP];
 #pragma unroll
     for (int m = 0; m < MR; ++m)
 #pragma unroll
-        for (int p = 0; p < 8; ++p) acc[m][p] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int p = 0; p < NP; ++p) acc[m][p] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     const unsigned short* wbf = reinterpret_cast<const unsigned short*>(a.wpack);
     const int nchunks = a.cin / 16;
@@ -1088,9 +1102,10 @@ __global__ __launch_bounds__(256) void deconv3d_s2_bf16x3_kernel(const DeconvArg
                 al[m] = *reinterpret_cast<const bf16x8*>(&lds_al[koff[s_] + m * AW * 8]);
             }
 #pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                if (!deconv_step_used(p, s_)) continue;
-                const int slot = deconv_slot(p, s_);                    // compile-time after unrolling
+            for (int p = 0; p < NP; ++p) {
+                const int pfull = HALF ? 2 * p : p;                     // (pz,py) decide which K-steps reach a parity
+                if (!deconv_step_used(pfull, s_)) continue;
+                const int slot = HALF ? deconv_slot_half(p, s_) : deconv_slot(p, s_);   // compile-time after unrolling
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&lds_b[((slot * 2 + 0) * 64 + lane) * 8]);
                 const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&lds_b[((slot * 2 + 1) * 64 + lane) * 8]);
 #pragma unroll
@@ -1103,10 +1118,38 @@ __global__ __launch_bounds__(256) void deconv3d_s2_bf16x3_kernel(const DeconvArg
         }
     }
 
-    // ---- epilogue: lane = (input pixel li, channels 4*lk .. 4*lk+3); parities px = 0/1 pair up into one float2 ----
+    // ---- epilogue ----
     const int x = x0 + li;
     const int Ho = 2 * h, Wo = 2 * w;
     const long ostride = (long)(2 * D) * Ho * Wo;
+    if (HALF) {
+        // lane = (input pixel li, tile rows 4*lk .. 4*lk+3) with row j = px*8 + co: px = lk >> 1, co = 4*(lk & 1) + r
+        const int px = lk >> 1, cb = 4 * (lk & 1);
+        float bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = a.bias[cb + r];
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const int y = y0 + wv * MR + m;
+            if (y >= h || x >= w) continue;
+#pragma unroll
+            for (int pzy = 0; pzy < 4; ++pzy) {
+                const long o = ((long)(2 * z + (pzy >> 1)) * Ho + (2 * y + (pzy & 1))) * Wo + 2 * x + px;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = cb + r;
+                    if (co >= a.cout) break;
+                    float v = acc[m][pzy][r] + bv[r];
+                    if (a.relu) v = fmaxf(v, 0.0f);
+                    const long oo = (long)co * ostride + o;
+                    if (a.skip) v += a.skip[oo];
+                    a.out[oo] = v;
+                }
+            }
+        }
+        return;
+    }
+    // lane = (input pixel li, channels 4*lk .. 4*lk+3); parities px = 0/1 pair up into one float2
     float bv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) bv[r] = a.bias[4 * lk + r];
@@ -1121,7 +1164,7 @@ __global__ __launch_bounds__(256) void deconv3d_s2_bf16x3_kernel(const DeconvArg
             for (int r = 0; r < 4; ++r) {
                 const int co = 4 * lk + r;
                 if (co >= a.cout) break;
-                float v0 = acc[m][2 * pzy][r] + bv[r], v1 = acc[m][2 * pzy + 1][r] + bv[r];
+                float v0 = acc[m][HALF ? 0 : 2 * pzy][r] + bv[r], v1 = acc[m][HALF ? 0 : 2 * pzy + 1][r] + bv[r];
                 if (a.relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
                 const long oo = (long)co * ostride + o;
                 if (a.skip) {
@@ -1816,18 +1859,21 @@ extern "C" int effi_deconv3d_k3s2_bf16x3_f32(const float* in, int cin, const voi
     a.w = w;
     a.relu = relu;
     const int tiles_x = effi_cdiv(w, 16);
-    const bool al = (w & 3) == 0;
+    const bool al = (w & 3) == 0, half = cout <= 8;       // cout <= 8: packing with 9 fragments per chunk (see the kernel)
     hipStream_t st = effi_s(stream);
     // rows per wave: 2 when that still gives ~2 workgroups per CU
-    if ((long)tiles_x * effi_cdiv(h, 8) * D >= 512) {
-        const dim3 grid(tiles_x * effi_cdiv(h, 8), D);
-        if (al) hipLaunchKernelGGL((deconv3d_s2_bf16x3_kernel<2, true>), grid, dim3(256), 0, st, a, tiles_x, (int)grid.x);
-        else hipLaunchKernelGGL((deconv3d_s2_bf16x3_kernel<2, false>), grid, dim3(256), 0, st, a, tiles_x, (int)grid.x);
+    const bool mr2 = (long)tiles_x * effi_cdiv(h, 8) * D >= 512;
+    const dim3 grid(tiles_x * effi_cdiv(h, mr2 ? 8 : 4), D);
+#define EFFI_DC(MRV, ALV, HFV) \
+    hipLaunchKernelGGL((deconv3d_s2_bf16x3_kernel<MRV, ALV, HFV>), grid, dim3(256), 0, st, a, tiles_x, (int)grid.x)
+    if (mr2) {
+        if (al) { if (half) EFFI_DC(2, true, true); else EFFI_DC(2, true, false); }
+        else { if (half) EFFI_DC(2, false, true); else EFFI_DC(2, false, false); }
     } else {
-        const dim3 grid(tiles_x * effi_cdiv(h, 4), D);
-        if (al) hipLaunchKernelGGL((deconv3d_s2_bf16x3_kernel<1, true>), grid, dim3(256), 0, st, a, tiles_x, (int)grid.x);
-        else hipLaunchKernelGGL((deconv3d_s2_bf16x3_kernel<1, false>), grid, dim3(256), 0, st, a, tiles_x, (int)grid.x);
+        if (al) { if (half) EFFI_DC(1, true, true); else EFFI_DC(1, true, false); }
+        else { if (half) EFFI_DC(1, false, true); else EFFI_DC(1, false, false); }
     }
+#undef EFFI_DC
     return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
 

@@ -126,7 +126,7 @@ def deconv_s2_slots():
 
 def pack_deconv3d_s2_bf16x3(conv, bn):
     """nn.ConvTranspose3d [cin,cout,3,3,3] (+BN), stride 2 / padding 1 / output_padding 1, cin % 16 == 0, cout <= 16 ->
-    (bf16 [cin/16, 18, 2(hi|lo), 64, 8], bias fp32 [16]).  Per dimension parity 0 takes tap 1 of neighbour 0; parity 1 takes
+    (bf16 [cin/16, 18 (9 when cout <= 8), 2(hi|lo), 64, 8], bias fp32 [16]).  Per dimension parity 0 takes tap 1 of neighbour 0; parity 1 takes
     tap 2 of neighbour 0 and tap 0 of neighbour 1.  Lane = q*16 + j of slot (p, s): neighbour (nz, ny, nx = q >> 1),
     octet q & 1, output channel j, element e = input channel chunk*16 + octet*8 + e."""
     w = conv.weight
@@ -139,19 +139,22 @@ def pack_deconv3d_s2_bf16x3(conv, bn):
     assert cin % 16 == 0 and cout <= 16
     nch = cin // 16
     tap = {(0, 0): 1, (1, 0): 2, (1, 1): 0}                 # (parity, neighbour) -> kernel index; (0, 1) contributes nothing
-    slots = deconv_s2_slots()
+    half = cout <= 8            # the two x-parities share one 16-row tile: row j = px*8 + co (9 fragments instead of 18)
+    slots = [(p, s_) for (p, s_) in deconv_s2_slots() if not half or (p & 1) == 0]
     wp = torch.zeros(nch, len(slots), 4, 16, 8, device=w.device, dtype=torch.float32)      # [chunk, slot, q, j, e]
     wf = w.float()
     for si, (p, s_) in enumerate(slots):
-        pz, py, px = p >> 2, (p >> 1) & 1, p & 1
+        pz, py = p >> 2, (p >> 1) & 1
         nz, ny = s_ >> 1, s_ & 1
         for q in range(4):
             nx, octet = q >> 1, q & 1
-            if (pz, nz) not in tap or (py, ny) not in tap or (px, nx) not in tap:
-                continue
-            kz, ky, kx = tap[(pz, nz)], tap[(py, ny)], tap[(px, nx)]
-            blk = wf[:, :, kz, ky, kx].reshape(nch, 2, 8, cout)[:, octet]                 # [chunk, e, cout]
-            wp[:, si, q, :cout, :] = blk.permute(0, 2, 1)
+            for px in ((0, 1) if half else (p & 1,)):
+                if (pz, nz) not in tap or (py, ny) not in tap or (px, nx) not in tap:
+                    continue
+                kz, ky, kx = tap[(pz, nz)], tap[(py, ny)], tap[(px, nx)]
+                blk = wf[:, :, kz, ky, kx].reshape(nch, 2, 8, cout)[:, octet]             # [chunk, e, cout]
+                j0 = px * 8 if half else 0
+                wp[:, si, q, j0:j0 + cout, :] = blk.permute(0, 2, 1)
     wp = wp.view(nch, len(slots), 64, 8)
     hi = wp.to(torch.bfloat16)
     lo = (wp - hi.float()).to(torch.bfloat16)
