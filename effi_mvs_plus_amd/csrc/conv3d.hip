@@ -31,7 +31,10 @@ __device__ __forceinline__ const float* src_channel(const SrcSet& s, int c, long
 // ------------------------------------------------------------------------------------------------
 // forward convolution, stride (SZ, SXY, SXY)
 // ------------------------------------------------------------------------------------------------
-template <int COUT_T, int SZ, int SXY, int ZPT>
+// DENSE: cout == COUT_T (every layer still on this kernel: cout 8 or 1), so the weight row stride is a compile-time constant
+// and all 27*COUT_T weights of a channel are scalar loads at immediate offsets from one base (measured before: as many scalar
+// ALU instructions as vector ones, spent on per-tap address arithmetic with the runtime stride).
+template <int COUT_T, int SZ, int SXY, int ZPT, bool DENSE = false>
 __global__ __launch_bounds__(256) void conv3d_k3_kernel(SrcSet src, int cin, const float* __restrict__ wgt,
                                                         const float* __restrict__ bias, int cout,
                                                         int D, int h, int w, int Do, int ho, int wo,
@@ -117,7 +120,8 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(SrcSet src, int cin, con
         const bool more = (c0 + CC < cin);
         if (PF && more) prefetch(c0 + CC);
         for (int c = 0; c < ccn; ++c) {
-            const float* __restrict__ wc = wgt + (long)(c0 + c) * 27 * cout + co0;
+            const int wstride = DENSE ? COUT_T : cout;
+            const float* __restrict__ wc = wgt + (long)(c0 + c) * 27 * wstride + (DENSE ? 0 : co0);
             const float* tc = tile + c * PLANE + (ty * SXY) * IX + tx * SXY;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(SrcSet src, int cin, con
                     for (int z = 0; z < IZ; ++z) col[z] = tc[z * (IY * IX) + ky * IX + kx];
 #pragma unroll
                     for (int kd = 0; kd < 3; ++kd) {
-                        const float* __restrict__ wk = wc + (kd * 9 + ky * 3 + kx) * cout;
+                        const float* __restrict__ wk = wc + (kd * 9 + ky * 3 + kx) * wstride;
 #pragma unroll
                         for (int z = 0; z < ZPT; ++z)
 #pragma unroll
@@ -327,8 +331,12 @@ int launch_conv_z(const SrcSet& s, int cin, const float* wgt, const float* bias,
                   int relu, const float* skip, float* out, hipStream_t st) {
     const int Do = (D - 1) / SZ + 1, ho = (h - 1) / SXY + 1, wo = (w - 1) / SXY + 1;
     dim3 grid(effi_cdiv(wo, TX) * effi_cdiv(ho, TY) * effi_cdiv(Do, ZPT) * effi_cdiv(cout, COUT_T));
-    hipLaunchKernelGGL((conv3d_k3_kernel<COUT_T, SZ, SXY, ZPT>), grid, dim3(256), 0, st, s, cin, wgt, bias, cout, D, h, w,
-                       Do, ho, wo, relu, skip, out);
+    if (cout == COUT_T)
+        hipLaunchKernelGGL((conv3d_k3_kernel<COUT_T, SZ, SXY, ZPT, true>), grid, dim3(256), 0, st, s, cin, wgt, bias, cout, D, h, w,
+                           Do, ho, wo, relu, skip, out);
+    else
+        hipLaunchKernelGGL((conv3d_k3_kernel<COUT_T, SZ, SXY, ZPT, false>), grid, dim3(256), 0, st, s, cin, wgt, bias, cout, D, h, w,
+                           Do, ho, wo, relu, skip, out);
     return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
 
