@@ -259,7 +259,8 @@ __global__ __launch_bounds__(256) void deconv3d_k3_kernel(const float* __restric
         const bool more = (c0 + CC < cin);
         if (more) prefetch(c0 + CC);
         for (int c = 0; c < ccn; ++c) {
-            const float* __restrict__ wc = wgt + (long)(c0 + c) * 27 * cout + co0;
+            const int wstride = (COUT_T == 1) ? 1 : cout;       // the single-channel instance is only launched with cout == 1
+            const float* __restrict__ wc = wgt + (long)(c0 + c) * 27 * wstride + co0;
             const float* tc = tile + c * PLANE + ty * IX + tx;
 #pragma unroll
             for (int lz = 0; lz < IZ; ++lz)
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) void deconv3d_k3_kernel(const float* __restric
                                     if (SZ == 2) kd = (lz == 0) ? (az == 0 ? 1 : 2) : (az == 1 ? 0 : -1);
                                     else kd = az + 2 - lz;          // lz = az + 2 - kd
                                     if (kd < 0 || kd > 2) continue;
-                                    const float* __restrict__ wk = wc + (kd * 9 + ky * 3 + kx) * cout;
+                                    const float* __restrict__ wk = wc + (kd * 9 + ky * 3 + kx) * wstride;
 #pragma unroll
                                     for (int co = 0; co < COUT_T; ++co)
                                         acc[az][ay][ax][co] = fmaf(v, wk[co], acc[az][ay][ax][co]);
