@@ -41,7 +41,7 @@ SIGNATURES = {
     "effi_conv2d_f32": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "effi_conv3d_k3s1_roll_bf16x3_f32": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "effi_conv3d_k3s1_bf16x3_f32": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
-    "effi_conv2d_k3_k1_bf16x3_f32": [_vp, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "effi_conv2d_k3_k1_bf16x3_f32": [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "effi_conv2d_k3_bf16x3_f32": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "effi_conv2d_k5s2_f32": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "effi_conv2d_c1k7_relu_f32": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],

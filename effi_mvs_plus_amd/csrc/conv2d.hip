@@ -740,9 +740,11 @@ __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs 
         // channels), so out2[co2][px] = sum_k W2[co2][k] * cat(conv3x3 + b1, extra)[k][px] needs no data movement: one K = 16 step
         // per N-tile plus one for the extra (context) channels, weights W2 as A fragments from a small L2-resident table.
         // Fields reused: aux0 = extra [c_extra][h][w], hd = c_extra, aux1 = W2 fragments (bf16 [NT2][NT+1][hi|lo][64][4]),
-        // disp_range = bias2, n_range = cout2, act = activation of the 1x1 result.
+        // disp_range = bias2 (padded to 16*NT2), n_range = cout2, act = activation of the 1x1 result, kgroups = 1 if the 3x3
+        // result passes through a ReLU first (mask head, models/update.py:112-114).
         const unsigned short* w2 = reinterpret_cast<const unsigned short*>(a.aux1);
-        const int nt2 = a.n_range >> 4;
+        const int nt2 = (a.n_range + 15) >> 4;
+        const bool relu1 = a.kgroups != 0;
         // B fragments of all the wave's pixels first (the extra-channel loads are issued together), then per output tile
         // the W2 fragments are fetched once and reused for the MR sub-tiles
         bf16x4 xh[MR][NT + 1], xl[MR][NT + 1];
@@ -769,6 +771,10 @@ __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs 
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     vf[r] = (n < NT) ? acc[m][n][r] + a.bias[n * 16 + 4 * lk + r] : (inside[m] ? ex[m][r] : 0.0f);
+                if (relu1 && n < NT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vf[r] = fmaxf(vf[r], 0.0f);
+                }
                 xh[m][n] = __builtin_convertvector(vf, bf16x4);
                 xl[m][n] = __builtin_convertvector(vf - __builtin_convertvector(xh[m][n], f32x4), bf16x4);
             }
@@ -799,7 +805,7 @@ __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs 
                     for (int r = 0; r < 4; ++r) {
                         float v = o[r] + b2[r];
                         if (a.act == EFFI_ACT_RELU) v = fmaxf(v, 0.0f);
-                        a.out0[(long)(co + r) * hw + pixm[m]] = v;
+                        if (co + r < a.n_range) a.out0[(long)(co + r) * hw + pixm[m]] = v;
                     }
                 }
             }
@@ -1700,13 +1706,13 @@ extern "C" int effi_conv2d_k3_bf16x3_f32(const float* const* srcs, const int* sr
 }
 
 extern "C" int effi_conv2d_k3_k1_bf16x3_f32(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
-                                            const float* bias, int cout1, const float* extra, int c_extra, const void* w2pack_bf16,
-                                            const float* bias2, int cout2, int relu, int h, int w, float* out,
-                                            effi_stream_t stream) {
+                                            const float* bias, int cout1, int relu1, const float* extra, int c_extra,
+                                            const void* w2pack_bf16, const float* bias2, int cout2, int relu, int h, int w,
+                                            float* out, effi_stream_t stream) {
     if (!srcs || !src_channels || n_src < 1 || n_src > EFFI_MAX_SRC || !wpack_bf16 || !bias || !w2pack_bf16 || !bias2 || !out)
         return EFFI_ERR_BADARG;
-    if (cout1 < 1 || cout2 < 16 || h < 1 || w < 1 || c_extra < 0 || (c_extra > 0 && !extra)) return EFFI_ERR_BADARG;
-    if ((w & 3) || cout1 > 48 || c_extra > 16 || (cout2 & 15) || cout2 > 96) return EFFI_ERR_UNSUPPORTED;
+    if (cout1 < 1 || cout2 < 1 || h < 1 || w < 1 || c_extra < 0 || (c_extra > 0 && !extra)) return EFFI_ERR_BADARG;
+    if ((w & 3) || cout1 > 96 || c_extra > 16 || cout2 > 96) return EFFI_ERR_UNSUPPORTED;
     Conv2dArgs a;
     a.cin = 0;
     for (int i = 0; i < EFFI_MAX_SRC; ++i) {
@@ -1716,7 +1722,7 @@ extern "C" int effi_conv2d_k3_k1_bf16x3_f32(const float* const* srcs, const int*
         if (i + 1 < n_src && (src_channels[i] & 7)) return EFFI_ERR_UNSUPPORTED;
         a.cin += a.ch[i];
     }
-    a.kgroups = 0;
+    a.kgroups = relu1 ? 1 : 0;
     a.zeros = effi_zero_page();
     if (!a.zeros) return EFFI_ERR_LAUNCH;
     a.wpack = reinterpret_cast<const float*>(wpack_bf16);
@@ -1739,6 +1745,8 @@ extern "C" int effi_conv2d_k3_k1_bf16x3_f32(const float* const* srcs, const int*
         case 1: return launch_bf16x3<1, EFFI_EPI_K1>(a, st);
         case 2: return launch_bf16x3<2, EFFI_EPI_K1>(a, st);
         case 3: return launch_bf16x3<3, EFFI_EPI_K1>(a, st);
+        case 4: return launch_bf16x3<4, EFFI_EPI_K1>(a, st);
+        case 6: return launch_bf16x3<6, EFFI_EPI_K1>(a, st);
         default: return EFFI_ERR_UNSUPPORTED;
     }
 }

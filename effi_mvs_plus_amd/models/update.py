@@ -177,13 +177,20 @@ class BasicUpdateBlock(nn.Module):
         self.Inverse = Inverse
         self.mask = nn.Sequential(nn.Conv2d(hidden_dim, hidden_dim * 2, 3, padding=1), nn.ReLU(inplace=True),
                                   nn.Conv2d(hidden_dim * 2, ratio * ratio * 9, 1, padding=0))
-        self._m0, self._m2 = packing.PackCache(), packing.PackCache()
+        self._m0, self._m2, self._m2x = packing.PackCache(), packing.PackCache(), packing.PackCache()
         self.last_depths = None     # depths of the last forward's iterations (filled on the fused path)
 
     def run_mask(self, net):
         """0.25 * mask(net); the factor is folded into the 1x1 conv's weights and bias (exact: power of two)."""
         w, b = _pack(self._m0, self.mask[0])
-        hid = ops.conv2d([net], w, b, self.mask[0].out_channels, 3, act=ops.ACT_RELU)
+        c1, c2 = self.mask[0].out_channels, self.mask[2].out_channels
+        if (ops.get_precision() == "split" and w.wx is not None and net.shape[-1] % 4 == 0 and c1 <= 96 and c1 // 16 in (1, 2, 3, 4, 6)
+                and c1 % 16 == 0 and c2 <= 96):
+            # 3x3 + ReLU + 1x1 (x0.25) in one kernel: the 2*hidden-channel intermediate stays in registers
+            w2, b2 = self._m2x.get([self.mask[2].weight, self.mask[2].bias],
+                                   lambda: packing.pack_conv1x1_after(self.mask[2].weight, self.mask[2].bias, c1, 0, scale=0.25))
+            return ops.conv2d_k3_k1_x3([net], w.wx, b, c1, None, w2, b2, c2, relu=False, relu1=True)
+        hid = ops.conv2d([net], w, b, c1, 3, act=ops.ACT_RELU)
         w, b = _pack(self._m2, self.mask[2], scale=0.25)
         return ops.conv2d([hid], w, b, self.mask[2].out_channels, 1, act=ops.ACT_NONE)
 

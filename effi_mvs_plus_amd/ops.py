@@ -578,8 +578,8 @@ def conv2d_k3_bf16x3(srcs, wpack, bias, cout, epilogue=EPI_PLAIN, act=ACT_NONE, 
     return (out0, out1) if out1 is not None else out0
 
 
-def conv2d_k3_k1_x3(srcs, wpack, bias, cout1, extra, w2pack, bias2, cout2, relu=True, out=None):
-    """3x3 split-precision conv (no activation) + the 1x1 conv over cat(result, ``extra``) in one kernel
+def conv2d_k3_k1_x3(srcs, wpack, bias, cout1, extra, w2pack, bias2, cout2, relu=True, out=None, relu1=False):
+    """3x3 split-precision conv (ReLU if ``relu1``) + the 1x1 conv over cat(result, ``extra``) in one kernel
     (``packing.pack_conv2d_bf16x3`` / ``packing.pack_conv1x1_after``) -> [cout2,h,w]."""
     for s in srcs:
         _t(s, "conv2d input")
@@ -594,8 +594,8 @@ def conv2d_k3_k1_x3(srcs, wpack, bias, cout1, extra, w2pack, bias2, cout2, relu=
     work = lambda: {"flops": 2.0 * h * w * (cin * cout1 * 9 + (cout1 + c_extra) * cout2),
                     "bytes": 4.0 * h * w * (cin + c_extra + cout2)}
     check(_call(f"conv2d_k3k1_nt{(cout1 + 15) // 16}", work, _lib.lib().effi_conv2d_k3_k1_bf16x3_f32, _ptr_array(srcs),
-                _int_array([s.shape[0] for s in srcs]), len(srcs), _p(wpack), _p(bias), cout1, _p(extra), c_extra, _p(w2pack),
-                _p(bias2), cout2, int(relu), h, w, _p(out), _stream()), "effi_conv2d_k3_k1_bf16x3_f32")
+                _int_array([s.shape[0] for s in srcs]), len(srcs), _p(wpack), _p(bias), cout1, int(relu1), _p(extra), c_extra,
+                _p(w2pack), _p(bias2), cout2, int(relu), h, w, _p(out), _stream()), "effi_conv2d_k3_k1_bf16x3_f32")
     return out
 
 

@@ -212,24 +212,27 @@ def pack_conv2d_bf16x3(weight, bias, scale=1.0):
     return wp, b
 
 
-def pack_conv1x1_after(weight, bias, cout1, c_extra):
+def pack_conv1x1_after(weight, bias, cout1, c_extra, scale=1.0):
     """1x1 conv [cout2, cout1 + c_extra, 1, 1] applied inside the epilogue of a 3x3 split-precision conv with cout1 outputs
     (``effi_conv2d_k3_k1_bf16x3_f32``): A fragments of v_mfma_f32_16x16x16_bf16 per (output tile t, input tile n):
-    lane = q*16 + j holds W[16t + j][16n + 4q + e] (n < ceil(cout1/16); zero beyond cout1) and, for the last input tile, the
-    extra channels W[16t + j][cout1 + 4q + e] (zero beyond c_extra).  -> (bf16 [NT2, NT1+1, 2, 64, 4], bias fp32 [cout2])."""
+    lane = q*16 + j holds W[16t + j][16n + 4q + e] (n < ceil(cout1/16); zero beyond cout1 / cout2) and, for the last input
+    tile, the extra channels W[16t + j][cout1 + 4q + e] (zero beyond c_extra).
+    -> (bf16 [NT2, NT1+1, 2, 64, 4], bias fp32 [16*NT2]); ``scale`` multiplies weights and bias (exact for powers of two)."""
     cout2 = weight.shape[0]
-    assert cout2 % 16 == 0 and weight.shape[1] == cout1 + c_extra and c_extra <= 16
-    nt1, nt2 = (cout1 + 15) // 16, cout2 // 16
-    w = weight.reshape(cout2, cout1 + c_extra).float()
-    full = torch.zeros(cout2, (nt1 + 1) * 16, device=w.device, dtype=torch.float32)
-    full[:, :cout1] = w[:, :cout1]
-    full[:, nt1 * 16:nt1 * 16 + c_extra] = w[:, cout1:]
+    assert weight.shape[1] == cout1 + c_extra and c_extra <= 16
+    nt1, nt2 = (cout1 + 15) // 16, (cout2 + 15) // 16
+    w = weight.reshape(cout2, cout1 + c_extra).float() * scale
+    full = torch.zeros(nt2 * 16, (nt1 + 1) * 16, device=w.device, dtype=torch.float32)
+    full[:cout2, :cout1] = w[:, :cout1]
+    full[:cout2, nt1 * 16:nt1 * 16 + c_extra] = w[:, cout1:]
     # [t, j, n, q, e] -> [t, n, q, j, e]
     fr = full.view(nt2, 16, nt1 + 1, 4, 4).permute(0, 2, 3, 1, 4).contiguous().view(nt2, nt1 + 1, 64, 4)
     hi = fr.to(torch.bfloat16)
     lo = (fr - hi.float()).to(torch.bfloat16)
     wp = torch.stack([hi, lo], dim=2).contiguous()
-    b = torch.zeros(cout2, device=w.device, dtype=torch.float32) if bias is None else bias.contiguous().float()
+    b = torch.zeros(nt2 * 16, device=w.device, dtype=torch.float32)
+    if bias is not None:
+        b[:cout2] = bias.float() * scale
     return wp, b
 
 

@@ -122,13 +122,15 @@ int effi_conv3d_k3s2_mfma_f32(const float* in, int cin, const float* wpack, cons
                               int D, int h, int w, int relu, float* out, effi_stream_t stream);
 /* 3x3 convolution (split precision, no activation) followed IN THE SAME KERNEL by the 1x1 convolution that consumes it
  * together with c_extra further channels -- convd then convc of the update block's encoder, models/update.py:78-80,93-96:
- * out [cout2][h][w] = relu?(bias2 + W2 . cat(conv3x3(srcs) + bias [cout1], extra [c_extra][h][w])).
- * wpack_bf16 / bias as effi_conv2d_k3_bf16x3_f32 (cout1 <= 48); w2pack_bf16 = packing.pack_conv1x1_after
- * ([cout2/16][ceil(cout1/16)+1][hi|lo][64][4] bf16: A fragments of v_mfma_f32_16x16x16_bf16); bias2 [cout2];
- * cout2 % 16 == 0, c_extra <= 16, w % 4 == 0; the 12..36-channel intermediate never reaches HBM. */
+ * and the mask head's 3x3 + ReLU + 1x1, models/update.py:112-114:
+ * out [cout2][h][w] = relu?(bias2 + W2 . cat(relu1?(conv3x3(srcs) + bias) [cout1], extra [c_extra][h][w])).
+ * wpack_bf16 / bias as effi_conv2d_k3_bf16x3_f32 (cout1 <= 96); w2pack_bf16 = packing.pack_conv1x1_after
+ * ([ceil(cout2/16)][ceil(cout1/16)+1][hi|lo][64][4] bf16: A fragments of v_mfma_f32_16x16x16_bf16); bias2 padded to
+ * 16*ceil(cout2/16); cout2 <= 96, c_extra <= 16, w % 4 == 0; the intermediate never reaches HBM. */
 int effi_conv2d_k3_k1_bf16x3_f32(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
-                                 const float* bias, int cout1, const float* extra, int c_extra, const void* w2pack_bf16,
-                                 const float* bias2, int cout2, int relu, int h, int w, float* out, effi_stream_t stream);
+                                 const float* bias, int cout1, int relu1, const float* extra, int c_extra,
+                                 const void* w2pack_bf16, const float* bias2, int cout2, int relu, int h, int w, float* out,
+                                 effi_stream_t stream);
 /* Same operator (stride 1, cout <= 32, w % 4 == 0) in split precision: products as hi*hi + hi*lo + lo*hi on the bf16
  * matrix cores with fp32 accumulation (see effi_conv2d_k3_bf16x3_f32).  Input = channel concatenation of n_src planar
  * tensors [Ci][D][h][w] (models/module.py:513); wpack_bf16 = split-bf16 packing of the weight viewed as

@@ -430,10 +430,14 @@ def test_conv2d_split_bf16(h, w, cins, cout, epi):
 
 
 @pytest.mark.parametrize("h,w", [(21, 28), (130, 256), (148, 200), (72, 520)])
-@pytest.mark.parametrize("cins,cout1,c_extra,cout2", [((16, 16), 12, 4, 16), ((32, 32), 24, 8, 32), ((48, 48), 36, 12, 48),
-                                                      ((16,), 16, 0, 16), ((8, 8), 5, 3, 32)])
-def test_conv3x3_then_1x1_fused(h, w, cins, cout1, c_extra, cout2):
-    """convd -> convc of the encoder in one kernel (effi_conv2d_k3_k1_bf16x3_f32) against the two fp64 convolutions."""
+@pytest.mark.parametrize("cins,cout1,c_extra,cout2,relu1", [((16, 16), 12, 4, 16, False), ((32, 32), 24, 8, 32, False),
+                                                            ((48, 48), 36, 12, 48, False), ((16,), 16, 0, 16, False),
+                                                            ((8, 8), 5, 3, 32, False),
+                                                            # mask head: 3x3 + ReLU + 1x1 to 36 channels
+                                                            ((16,), 32, 0, 36, True), ((32,), 64, 0, 36, True), ((48,), 96, 0, 36, True)])
+def test_conv3x3_then_1x1_fused(h, w, cins, cout1, c_extra, cout2, relu1):
+    """convd -> convc of the encoder, and the mask head, in one kernel (effi_conv2d_k3_k1_bf16x3_f32) against the two fp64
+    convolutions."""
     from effi_mvs_plus_amd import ops, packing
     g = torch.Generator().manual_seed(cout1 * 100 + h)
     xs = [torch.randn(c, h, w, generator=g) for c in cins]
@@ -444,12 +448,17 @@ def test_conv3x3_then_1x1_fused(h, w, cins, cout1, c_extra, cout2):
     w2 = torch.randn(cout2, cout1 + c_extra, 1, 1, generator=g) * (2.0 / (cout1 + c_extra)) ** 0.5
     b2 = 0.1 * torch.randn(cout2, generator=g)
     mid = F.conv2d(torch.cat(xs).unsqueeze(0).double(), w1.double(), b1.double(), padding=1)
+    if relu1:
+        mid = F.relu(mid)
     if c_extra:
         mid = torch.cat([mid, extra.unsqueeze(0).double()], 1)
-    want = F.relu(F.conv2d(mid, w2.double(), b2.double()))[0]
+    want = F.conv2d(mid, w2.double(), b2.double())[0]
+    if not relu1:
+        want = F.relu(want)
     wx, bx = packing.pack_conv2d_bf16x3(w1.to(DEV), b1.to(DEV))
     w2p, b2p = packing.pack_conv1x1_after(w2.to(DEV), b2.to(DEV), cout1, c_extra)
-    got = ops.conv2d_k3_k1_x3([t(x, DEV) for x in xs], wx, bx, cout1, None if extra is None else t(extra, DEV), w2p, b2p, cout2)
+    got = ops.conv2d_k3_k1_x3([t(x, DEV) for x in xs], wx, bx, cout1, None if extra is None else t(extra, DEV), w2p, b2p, cout2,
+                              relu=not relu1, relu1=relu1)
     check_close(f"3x3+1x1 {cins}->{cout1}(+{c_extra})->{cout2} {h}x{w}", got, want.float(), rtol=0.0,
                 atol=6e-5 * float(want.abs().max()))
 
