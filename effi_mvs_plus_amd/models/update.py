@@ -202,13 +202,14 @@ class BasicUpdateBlock(nn.Module):
         h, w = net.shape[-2:]
         dev = net.device
         mk = lambda c: torch.empty(c, h, w, device=dev, dtype=torch.float32)
-        bufs = {"cor1": mk(hd), "cor2": mk(hd), "dfm1": mk(hd), "dfm2": mk(hd),
-                "mix": mk(self.encoder.convd.out_channels), "enc": mk(hd)}
+        bufs = {"cor1": mk(hd), "cor2": mk(hd), "dfm1": mk(hd), "dfm2": mk(hd)}
         # Buffers are recycled inside an iteration so that its working set stays small (at 592x800 one iteration touched ~390 MB
-        # of 16-channel maps, more than the 256 MB MALL; measured 2.85 -> 2.81 ms per view): z, r*h and the depth head's hidden
-        # map reuse the three encoder intermediates that are dead by then, and the hidden state ping-pongs between two buffers
-        # (only the last state is returned).
-        z_buf, rh_buf, head_buf, cost_buf = bufs["cor1"], bufs["cor2"], bufs["dfm1"], None
+        # of 16-channel maps, more than the 256 MB MALL; measured 2.85 -> 2.80 ms per view): four map buffers serve the eight
+        # intermediates (cor1 -> enc, dfm1 -> z, cor2 -> r*h, dfm2 -> head hidden: each successor is written only after its
+        # predecessor's last reader, on both streams), and the hidden state ping-pongs between two buffers (only the last state
+        # is returned).
+        bufs["enc"] = bufs["cor1"]                # the encoder's output overwrites its first intermediate (dead after convc2)
+        z_buf, rh_buf, head_buf, cost_buf = bufs["dfm1"], bufs["cor2"], bufs["dfm2"], None
         h_bufs = [mk(hd), mk(hd)]
         inv_list, mask_list, depth_list = [], [], []
         fuse_c1 = getattr(lookup, "conv1x1", None) is not None and hd % 8 == 0
