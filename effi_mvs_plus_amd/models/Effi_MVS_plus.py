@@ -265,28 +265,33 @@ class Effi_MVS_plus(nn.Module):
         weights = reg_vol = cur_vol = None
         lo_prev, hi_prev = g_min, g_max          # depth range the PREVIOUS stage's volumes are sampled on
 
-        def prepare(s):      # per-stage inputs that depend on nothing but the features / cameras / context
+        def geometry(s):     # per-stage inputs that depend on nothing but the features / cameras
             key = "stage{}".format(s + 1)
             maps = [f[key] for f in feats]
-            hid, inp_ = ops.split_tanh_relu(ctx[key].contiguous(), self.hdim_stage[s], self.cdim_stage[s])
-            return ops.to_nhwc(maps), ops.compose_rel_proj(pairs[key]), maps[0].shape, hid, inp_
+            return ops.to_nhwc(maps), ops.compose_rel_proj(pairs[key]), maps[0].shape
 
-        prep = {0: prepare(0)}
-        with ops.Branch() as prep_branch:        # stages 2 and 3 are prepared on the side stream while stage 1 runs
+        def states(s):       # hidden state / context input of the update block: tanh / relu halves of the context pyramid
+            return ops.split_tanh_relu(ctx["stage{}".format(s + 1)].contiguous(), self.hdim_stage[s], self.cdim_stage[s])
+
+        geo = {0: geometry(0)}
+        st = {}
+        with ops.Branch() as prep_branch:        # what the stage-1 cost volume does not need: side stream, beside it
+            st[0] = states(0)
             for s in range(1, self.num_stage):
-                prep[s] = prepare(s)
+                geo[s] = geometry(s)
+                st[s] = states(s)
+        prep_joined = False
+        tail_branch = None
         for s in range(self.num_stage):
-            if s == 1:
-                prep_branch.join(*[t_ for k in range(1, self.num_stage) for t_ in
-                                   (list(prep[k][0]) + [prep[k][1], prep[k][3], prep[k][4]])])
-            nhwc, rt, (_, h, w), hidden, inp = prep[s]
+            nhwc, rt, (_, h, w) = geo[s]
             if s == 0:
                 sim_views, entropy = ops.warpcorr_views(nhwc[0], nhwc[1:], rt, hyp, D1)
                 weights = self.PixelwiseNet.run(entropy)
                 cur_vol = ops.view_aggregate(sim_views, weights)
                 reg_vol = self.cost_regularization.run(cur_vol.unsqueeze(0))[0][0]
                 depth, c = ops.softmax_regress_conf(reg_vol, hyp)
-                conf = ops.upsample_nearest(c.unsqueeze(0), 4)[0]
+                with ops.Branch() as tail_branch:      # the confidence map is only an output: off the critical path
+                    conf = ops.upsample_nearest(c.unsqueeze(0), 4)[0]
                 preds.append(depth)
                 lo_cur, hi_cur = g_min, g_max
             else:
@@ -306,6 +311,10 @@ class Effi_MVS_plus(nn.Module):
                 inter["view_weights"] = weights
                 inter["reg_volume{}".format(s + 1)] = reg_vol
                 inter["cur_volume{}".format(s + 1)] = cur_vol
+            if not prep_joined:                   # first use of the side stream's results: the stage-1 update block
+                prep_branch.join(*[t_ for k in st for t_ in st[k]], *[t_ for k in range(1, self.num_stage) for t_ in (list(geo[k][0]) + [geo[k][1]])])
+                prep_joined = True
+            hidden, inp = st[s]
             inv_cur = ops.depth_to_inv(preds[-1], disp_range).unsqueeze(0)
             cur_c, reg_c, lo_c, hi_c, itv = cur_vol, reg_vol, lo_cur, hi_cur, misc[s:s + 1]
 
@@ -323,6 +332,8 @@ class Effi_MVS_plus(nn.Module):
             preds.extend(d[0] for d in depths)
             preds.append(ops.convex_upsample2x(invs[-1], masks[-1], disp_range, want_inv=False)[1])
             lo_prev, hi_prev = lo_cur, hi_cur
+        if tail_branch is not None:
+            tail_branch.join(conf)
         out = {"depth": preds, "photometric_confidence": conf}
         if want_intermediates:
             out["intermediates"] = inter
