@@ -66,3 +66,37 @@ __device__ __forceinline__ float effi_inv_to_depth(float inv, float lo, float hi
     s = fmaxf(s, 1e-4f);
     return 1.0f / s;
 }
+
+// 7x7 convolution of a single-channel map + ReLU, one (32 x 8 pixel, 16 channel) tile of it: shared by
+// conv2d_c1k7_relu_kernel (conv2d.hip) and encoder_inputs_kernel (volume_ops.hip).  Block of 256 threads.
+template <int COUT>
+__device__ __forceinline__ void effi_c1k7_relu_tile(const float* __restrict__ in, const float* __restrict__ wgt,
+                                                    const float* __restrict__ bias, int h, int w, float* __restrict__ out,
+                                                    int bx, int by, int bz) {
+    constexpr int TXX = 32, TYY = 8, IWX = TXX + 6, IHY = TYY + 6, CG = 16;
+    __shared__ float tile[IHY * IWX];
+    const int tx = threadIdx.x % TXX, ty = threadIdx.x / TXX;
+    const int x0 = bx * TXX, y0 = by * TYY;
+    const int c0 = bz * CG;
+    for (int e = threadIdx.x; e < IHY * IWX; e += 256) {
+        const int yy = e / IWX, xx = e - yy * IWX;
+        const int gy = y0 - 3 + yy, gx = x0 - 3 + xx;
+        tile[e] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? in[(long)gy * w + gx] : 0.0f;
+    }
+    __syncthreads();
+    const float* __restrict__ wg = wgt + c0;
+    float acc[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) acc[c] = bias[c0 + c];
+#pragma unroll
+    for (int k = 0; k < 49; ++k) {
+        const float v = tile[(ty + k / 7) * IWX + tx + k % 7];
+#pragma unroll
+        for (int c = 0; c < CG; ++c) acc[c] = fmaf(v, wg[k * COUT + c], acc[c]);
+    }
+    const int x = x0 + tx, y = y0 + ty;
+    if (x >= w || y >= h) return;
+    const long hw = (long)h * w, pix = (long)y * w + x;
+#pragma unroll
+    for (int c = 0; c < CG; ++c) out[(c0 + c) * hw + pix] = fmaxf(acc[c], 0.0f);
+}

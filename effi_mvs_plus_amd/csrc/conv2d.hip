@@ -601,8 +601,8 @@ __device__ __forceinline__ void split_octet(const f32x4 (&pa)[8], int px, bf16x8
 // WIDE: the workgroup's tile is 4 rows x 16*MR columns (one row per wave, MR column groups per wave) instead of 4*MR rows x 16
 // columns: same LDS image size and halo factor, but every row segment the tile reads (64*MR + 32 bytes) and writes (64*MR bytes)
 // is MR times longer, which is what HBM likes once the working set no longer fits the 256 MB MALL.
-template <int NT, int MR, int EPI, bool ZB = false, bool WIDE = false>
-__global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs a, int tiles_x, int ntiles) {
+template <int NT, int MR, int EPI, bool ZB, bool WIDE>
+__device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int tiles_x, int ntiles, int bid, int nbid, int bidy) {
     constexpr int TR = WIDE ? 4 : 4 * MR, TW = WIDE ? 16 * MR : 16;
     constexpr int AR = TR + 2, AW = TW + 8, AQ = AW / 4, XOFF = 3, XLEFT = 4, CCH = 16, NKS = 5;
     constexpr int MROW = WIDE ? 0 : AW * 8, MCOL = WIDE ? 16 * 8 : 0;   // LDS element step between a wave's MR sub-tiles
@@ -620,11 +620,11 @@ __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs 
     const int li = lane & 15, lk = lane >> 4;
     const int h = a.h, w = a.w;
     const long hw = (long)h * w;
-    const int tile = effi_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = effi_xcd_remap(bid, nbid);
     if (tile >= ntiles) return;
     const int ty_ = tile / tiles_x;
     const int x0 = (tile - ty_ * tiles_x) * TW, y0 = ty_ * TR;
-    const int zpl = ZB ? (int)blockIdx.y : 0;
+    const int zpl = ZB ? bidy : 0;
 
     // staging item of this thread
     const bool stager = tid < NITEMS;
@@ -821,6 +821,19 @@ __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs 
 #pragma unroll
         for (int n = 0; n < NT; ++n) conv_epilogue_store_t<(EPI == EFFI_EPI_K1 ? EFFI_EPI_PLAIN : EPI)>(a, acc[m][n], n * 16 + 4 * lk, pix, hw, zpl);
     }
+}
+
+template <int NT, int MR, int EPI, bool ZB = false, bool WIDE = false>
+__global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs a, int tiles_x, int ntiles) {
+    conv2d_k3_bf16x3_tile<NT, MR, EPI, ZB, WIDE>(a, tiles_x, ntiles, blockIdx.x, gridDim.x, blockIdx.y);
+}
+
+// Two independent convolutions of the same shape (NT, h, w) in one launch: blockIdx.y picks the argument set.  Used for the
+// update block's convc2 / convd2 (models/update.py:87,91), which would otherwise be forked onto two streams.
+template <int NT, int MR, bool WIDE>
+__global__ __launch_bounds__(256) void conv2d_k3_bf16x3_pair_kernel(const Conv2dArgs a0, const Conv2dArgs a1, int tiles_x, int ntiles) {
+    if (blockIdx.y == 0) conv2d_k3_bf16x3_tile<NT, MR, EFFI_EPI_PLAIN, false, WIDE>(a0, tiles_x, ntiles, blockIdx.x, gridDim.x, 0);
+    else conv2d_k3_bf16x3_tile<NT, MR, EFFI_EPI_PLAIN, false, WIDE>(a1, tiles_x, ntiles, blockIdx.x, gridDim.x, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1196,32 +1209,7 @@ __global__ __launch_bounds__(256) void conv2d_c1k7_relu_kernel(const float* __re
                                                                const float* __restrict__ wgt,
                                                                const float* __restrict__ bias, int h, int w,
                                                                float* __restrict__ out) {
-    constexpr int TXX = 32, TYY = 8, IWX = TXX + 6, IHY = TYY + 6, CG = 16;
-    __shared__ float tile[IHY * IWX];
-    const int tx = threadIdx.x % TXX, ty = threadIdx.x / TXX;
-    const int x0 = blockIdx.x * TXX, y0 = blockIdx.y * TYY;
-    const int c0 = blockIdx.z * CG;
-    for (int e = threadIdx.x; e < IHY * IWX; e += 256) {
-        const int yy = e / IWX, xx = e - yy * IWX;
-        const int gy = y0 - 3 + yy, gx = x0 - 3 + xx;
-        tile[e] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? in[(long)gy * w + gx] : 0.0f;
-    }
-    __syncthreads();
-    const float* __restrict__ wg = wgt + c0;
-    float acc[CG];
-#pragma unroll
-    for (int c = 0; c < CG; ++c) acc[c] = bias[c0 + c];
-#pragma unroll
-    for (int k = 0; k < 49; ++k) {
-        const float v = tile[(ty + k / 7) * IWX + tx + k % 7];
-#pragma unroll
-        for (int c = 0; c < CG; ++c) acc[c] = fmaf(v, wg[k * COUT + c], acc[c]);
-    }
-    const int x = x0 + tx, y = y0 + ty;
-    if (x >= w || y >= h) return;
-    const long hw = (long)h * w, pix = (long)y * w + x;
-#pragma unroll
-    for (int c = 0; c < CG; ++c) out[(c0 + c) * hw + pix] = fmaxf(acc[c], 0.0f);
+    effi_c1k7_relu_tile<COUT>(in, wgt, bias, h, w, out, blockIdx.x, blockIdx.y, blockIdx.z);     // common.hpp
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1645,6 +1633,82 @@ static int dispatch_bf16x3(const Conv2dArgs& a, int nt, hipStream_t st) {
     }
 }
 
+// Pair launch (see conv2d_k3_bf16x3_pair_kernel): tile shape chosen as launch_bf16x3 does for two planes.
+template <int NT>
+static int launch_bf16x3_pair(const Conv2dArgs& a0, const Conv2dArgs& a1, hipStream_t st) {
+    const long cols = effi_cdiv(a0.w, 16);
+    const long t4 = cols * effi_cdiv(a0.h, 16) * 2, t2 = cols * effi_cdiv(a0.h, 8) * 2;
+    int mr;
+    if (t4 >= 400 && !(NT == 2 && t4 >= 1024)) mr = 4;
+    else if (t2 >= 400) mr = 2;
+    else mr = 1;
+    static const char* force = getenv("EFFI_FORCE_MR");
+    if (force) mr = atoi(force);
+    if (mr == 4 && a0.w >= 512) {
+        const int tiles_x = effi_cdiv(a0.w, 64), ntiles = tiles_x * effi_cdiv(a0.h, 4);
+        hipLaunchKernelGGL((conv2d_k3_bf16x3_pair_kernel<NT, 4, true>), dim3(ntiles, 2), dim3(256), 0, st, a0, a1, tiles_x, ntiles);
+        return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+    }
+    const int tiles_x = (int)cols, ntiles = tiles_x * effi_cdiv(a0.h, 4 * mr);
+    const dim3 grid(ntiles, 2);
+    if (mr == 4) hipLaunchKernelGGL((conv2d_k3_bf16x3_pair_kernel<NT, 4, false>), grid, dim3(256), 0, st, a0, a1, tiles_x, ntiles);
+    else if (mr == 2) hipLaunchKernelGGL((conv2d_k3_bf16x3_pair_kernel<NT, 2, false>), grid, dim3(256), 0, st, a0, a1, tiles_x, ntiles);
+    else hipLaunchKernelGGL((conv2d_k3_bf16x3_pair_kernel<NT, 1, false>), grid, dim3(256), 0, st, a0, a1, tiles_x, ntiles);
+    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+}
+
+static int fill_bf16x3_plain(Conv2dArgs& a, const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
+                             const float* bias, int cout, int h, int w, int act, float* out0) {
+    if (!srcs || !src_channels || n_src < 1 || n_src > EFFI_MAX_SRC || !wpack_bf16 || !bias || !out0) return EFFI_ERR_BADARG;
+    a.cin = 0;
+    for (int i = 0; i < EFFI_MAX_SRC; ++i) {
+        a.src[i] = (i < n_src) ? srcs[i] : srcs[0];
+        a.ch[i] = (i < n_src) ? src_channels[i] : 0;
+        if (i < n_src && (!srcs[i] || src_channels[i] < 1)) return EFFI_ERR_BADARG;
+        if (i + 1 < n_src && (src_channels[i] & 7)) return EFFI_ERR_UNSUPPORTED;
+        a.cin += a.ch[i];
+    }
+    a.kgroups = (a.cin + 3) / 4;
+    a.zeros = effi_zero_page();
+    if (!a.zeros) return EFFI_ERR_LAUNCH;
+    a.wpack = reinterpret_cast<const float*>(wpack_bf16);
+    a.bias = bias;
+    a.cout = cout;
+    a.h = a.hin = h;
+    a.w = a.win = w;
+    a.act = act;
+    a.hd = cout / 2;
+    a.aux0 = a.aux1 = a.disp_range = nullptr;
+    a.n_range = 0;
+    a.out0 = out0;
+    a.out1 = nullptr;
+    a.cstride = a.ostride = (long)h * w;
+    a.zcount = a.zin = 0;
+    return EFFI_OK;
+}
+
+extern "C" int effi_conv2d_k3_bf16x3_pair_f32(const float* const* srcs_a, const int* src_channels_a, int n_src_a,
+                                              const void* wpack_a, const float* bias_a, float* out_a,
+                                              const float* const* srcs_b, const int* src_channels_b, int n_src_b,
+                                              const void* wpack_b, const float* bias_b, float* out_b, int cout, int h, int w,
+                                              int act, effi_stream_t stream) {
+    if (cout < 1 || h < 1 || w < 1 || act < EFFI_ACT_NONE || act > EFFI_ACT_TANH) return EFFI_ERR_BADARG;
+    if (w & 3) return EFFI_ERR_UNSUPPORTED;
+    Conv2dArgs a0, a1;
+    int rc = fill_bf16x3_plain(a0, srcs_a, src_channels_a, n_src_a, wpack_a, bias_a, cout, h, w, act, out_a);
+    if (rc != EFFI_OK) return rc;
+    rc = fill_bf16x3_plain(a1, srcs_b, src_channels_b, n_src_b, wpack_b, bias_b, cout, h, w, act, out_b);
+    if (rc != EFFI_OK) return rc;
+    hipStream_t st = effi_s(stream);
+    switch ((cout + 15) / 16) {
+        case 1: return launch_bf16x3_pair<1>(a0, a1, st);
+        case 2: return launch_bf16x3_pair<2>(a0, a1, st);
+        case 3: return launch_bf16x3_pair<3>(a0, a1, st);
+        case 4: return launch_bf16x3_pair<4>(a0, a1, st);
+        default: return EFFI_ERR_UNSUPPORTED;
+    }
+}
+
 extern "C" int effi_conv2d_k3_bf16x3_f32(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
                                          const float* bias, int cout, int h, int w, int epilogue, int act, const float* aux0,
                                          const float* aux1, const float* disp_range, int n_range, float* out0, float* out1,
@@ -1793,19 +1857,30 @@ extern "C" int effi_conv3d_k3s1_bf16x3_f32(const float* const* srcs, const int* 
 
 template <int NOCT, int NT>
 static int launch_roll(const Conv2dArgs& a, hipStream_t st) {
-    // rows per wave: 4 when the tile count still covers the chip and the LDS image leaves two workgroups per CU
-    // (cin 8), else 2; planes per workgroup: as many as keep >= ~3 workgroups per CU in flight (fewer re-read planes)
-    const int cols = effi_cdiv(a.w, 16);
-    const long t4 = (long)cols * effi_cdiv(a.h, 16);
-    int mr = (NOCT == 1 && t4 * effi_cdiv(a.zcount, 8) >= 400) ? 4 : 2;
+    // Rows per wave (MR) and planes per workgroup (ZT) from a small cost model fitted to sweeps at the cfg3 shapes
+    // (tools/sweep_roll.sh): the chip holds 256 * occ workgroups at a time (occ from the LDS image / register count of the
+    // instantiation), a launch takes ceil(workgroups / that) rounds, and a workgroup costs (ZT + 3) plane steps (3 ~ filling
+    // the window), 1.3x as much with 4 rows per wave as with 2.  E.g. 8->8 at 48x148x200: MR 4 / ZT 6 (1040 workgroups, 3
+    // rounds) 74 us, MR 2 / ZT 16 (741 workgroups, 1 round) 55 us.
+    const int cols = effi_cdiv(a.w, 16), D = a.zcount;
+    int mr = 2, zt = D;
+    double best = 1e30;
+    for (int m = 2; m <= 4; m += 2) {
+        const int occ = (NOCT == 1 && NT == 1) ? (m == 2 ? 3 : 2) : (NOCT == 1 ? 2 : (NT == 1 && m == 2 ? 2 : 1));
+        const long tiles_m = (long)cols * effi_cdiv(a.h, 4 * m), slots = 256L * occ;
+        for (int nz = 1; nz <= D; ++nz) {
+            const int z = effi_cdiv(D, nz);
+            const long wgs = tiles_m * effi_cdiv(D, z);
+            const double cost = (double)effi_cdiv(wgs, slots) * (z + 3) * (m == 4 ? 1.3 : 1.0);
+            if (cost < best - 1e-9) { best = cost; mr = m; zt = z; }
+        }
+    }
     static const char* fm = getenv("EFFI_ROLL_MR");
-    if (fm) mr = atoi(fm);
-    const long tiles = (long)cols * effi_cdiv(a.h, 4 * mr);
-    int zt = a.zcount;
-    while (zt > 2 && tiles * effi_cdiv(a.zcount, zt) < 768) zt = (zt + 1) / 2;
     static const char* fz = getenv("EFFI_ROLL_ZT");
+    if (fm) mr = atoi(fm);
     if (fz) zt = atoi(fz);
-    const dim3 grid((unsigned)tiles, (unsigned)effi_cdiv(a.zcount, zt));
+    const long tiles = (long)cols * effi_cdiv(a.h, 4 * mr);
+    const dim3 grid((unsigned)tiles, (unsigned)effi_cdiv(D, zt));
     if (mr == 4) hipLaunchKernelGGL((conv3d_roll_bf16x3_kernel<NOCT, NT, 4>), grid, dim3(256), 0, st, a, cols, (int)tiles, zt);
     else hipLaunchKernelGGL((conv3d_roll_bf16x3_kernel<NOCT, NT, 2>), grid, dim3(256), 0, st, a, cols, (int)tiles, zt);
     return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
@@ -1869,8 +1944,13 @@ extern "C" int effi_deconv3d_k3s2_bf16x3_f32(const float* in, int cin, const voi
     const int tiles_x = effi_cdiv(w, 16);
     const bool al = (w & 3) == 0, half = cout <= 8;       // cout <= 8: packing with 9 fragments per chunk (see the kernel)
     hipStream_t st = effi_s(stream);
-    // rows per wave: 2 when that still gives ~2 workgroups per CU
-    const bool mr2 = (long)tiles_x * effi_cdiv(h, 8) * D >= 512;
+    // rows per wave from the same rounds model as launch_roll: 256 * occ workgroups at a time (occ 5 / 3 with cout <= 8, 3 / 2
+    // otherwise, for 1 / 2 rows per wave), a workgroup costs (rows per wave + 2); measured 16->8 into 48x148x200: 57 -> 43 us
+    const int occ1 = half ? 5 : 3, occ2 = half ? 3 : 2;
+    const long wg1 = (long)tiles_x * effi_cdiv(h, 4) * D, wg2 = (long)tiles_x * effi_cdiv(h, 8) * D;
+    bool mr2 = effi_cdiv(wg2, 256L * occ2) * 4 < effi_cdiv(wg1, 256L * occ1) * 3;
+    static const char* fdm = getenv("EFFI_DECONV_MR");
+    if (fdm) mr2 = atoi(fdm) == 2;
     const dim3 grid(tiles_x * effi_cdiv(h, mr2 ? 8 : 4), D);
 #define EFFI_DC(MRV, ALV, HFV) \
     hipLaunchKernelGGL((deconv3d_s2_bf16x3_kernel<MRV, ALV, HFV>), grid, dim3(256), 0, st, a, tiles_x, (int)grid.x)

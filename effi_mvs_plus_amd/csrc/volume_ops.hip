@@ -208,15 +208,24 @@ __global__ void getcost_kernel(const float* __restrict__ inv_depth, const float*
 // GetCost followed by the encoder's 1x1 convolution + ReLU (convc1, models/update.py:73,86): the 2*NQ looked-up costs of
 // a pixel stay in registers and go straight through the [2*NQ] -> [cout] matrix (weights through the scalar cache), so the
 // cost map is neither written nor read back.
+struct GetcostConvArgs {
+    const float* inv_depth; const float* disp_range; int n_range; int input_is_depth; const float* interval;
+    const float* cur_vol; long cds, cps; int Dcur;
+    const float* reg_vol; long rds, rps; int Dreg;
+    const float* dmin; const float* dmax; long range_ps;
+    int hw; const float* weight; const float* bias; int cout; int relu; float* out;
+};
+
 template <int NQ>
-__global__ void getcost_conv1x1_kernel(const float* __restrict__ inv_depth, const float* __restrict__ disp_range,
-                                       int n_range, int input_is_depth, const float* __restrict__ interval,
-                                       const float* __restrict__ cur_vol, long cds, long cps, int Dcur,
-                                       const float* __restrict__ reg_vol, long rds, long rps_, int Dreg,
-                                       const float* __restrict__ dmin, const float* __restrict__ dmax, long range_ps,
-                                       int hw, const float* __restrict__ weight, const float* __restrict__ bias, int cout,
-                                       int relu, float* __restrict__ out) {
-    const int p = blockIdx.x * TPB + threadIdx.x;
+__device__ __forceinline__ void getcost_conv1x1_block(const GetcostConvArgs& g, int bx) {
+    const float* __restrict__ inv_depth = g.inv_depth; const float* __restrict__ disp_range = g.disp_range;
+    const int n_range = g.n_range, input_is_depth = g.input_is_depth, Dcur = g.Dcur, Dreg = g.Dreg, hw = g.hw, cout = g.cout;
+    const int relu = g.relu;
+    const float* __restrict__ interval = g.interval; const float* __restrict__ cur_vol = g.cur_vol;
+    const float* __restrict__ reg_vol = g.reg_vol; const float* __restrict__ dmin = g.dmin; const float* __restrict__ dmax = g.dmax;
+    const float* __restrict__ weight = g.weight; const float* __restrict__ bias = g.bias; float* __restrict__ out = g.out;
+    const long cds = g.cds, cps = g.cps, rds = g.rds, rps_ = g.rps, range_ps = g.range_ps;
+    const int p = bx * TPB + threadIdx.x;
     if (p >= hw) return;
     const float itv = interval[0];
     float depth = inv_depth[p];
@@ -245,6 +254,26 @@ __global__ void getcost_conv1x1_kernel(const float* __restrict__ inv_depth, cons
             for (int j = 0; j < 8; ++j) acc[j] = fmaf(cost[k], weight[k * cout + c0 + j], acc[j]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) out[(long)(c0 + j) * hw + p] = relu ? fmaxf(acc[j], 0.0f) : acc[j];
+    }
+}
+
+template <int NQ>
+__global__ __launch_bounds__(TPB) void getcost_conv1x1_kernel(const GetcostConvArgs g) { getcost_conv1x1_block<NQ>(g, blockIdx.x); }
+
+// Both inputs of the update block's encoder in ONE launch (models/update.py:86,90): workgroups [0, n7) are tiles of
+// relu(convd1(inv_depth)) (7x7, effi_c1k7_relu_tile), the rest are blocks of relu(convc1(GetCost(inv_depth))).  The two are
+// independent and each alone underfills the chip at the coarse stages; as two kernels on two streams they overlap as well,
+// but every fork / join of streams inside a captured graph costs ~5 / ~11 us of idle GPU (measured), nine times per view.
+template <int NQ, int COUT>
+__global__ __launch_bounds__(TPB) void encoder_inputs_kernel(const GetcostConvArgs g, const float* __restrict__ w7,
+                                                             const float* __restrict__ b7, int h, int w,
+                                                             float* __restrict__ out7, int gx, int gy, int n7) {
+    const int b = blockIdx.x;
+    if (b < n7) {
+        const int bz = b / (gx * gy), r = b - bz * gx * gy;
+        effi_c1k7_relu_tile<COUT>(g.inv_depth, w7, b7, h, w, out7, r % gx, r / gx, bz);
+    } else {
+        getcost_conv1x1_block<NQ>(g, b - n7);
     }
 }
 
@@ -401,10 +430,9 @@ extern "C" int effi_getcost_conv1x1_f32(const float* inv_depth, const float* dis
     if (cout % 8) return EFFI_ERR_UNSUPPORTED;
     const dim3 grid(effi_cdiv((long)h * w, TPB));
     hipStream_t st = effi_s(stream);
-#define EFFI_GC(NQ)                                                                                                        \
-    hipLaunchKernelGGL(getcost_conv1x1_kernel<NQ>, grid, dim3(TPB), 0, st, inv_depth, disp_range, n_range, input_is_depth, \
-                       interval, cur_vol, cds, cps, Dcur, reg_vol, rds, rps, Dreg, dmin, dmax, range_ps, h * w, weight,    \
-                       bias, cout, relu, out)
+    const GetcostConvArgs g{inv_depth, disp_range, n_range, input_is_depth, interval, cur_vol, cds, cps, Dcur, reg_vol, rds, rps,
+                            Dreg, dmin, dmax, range_ps, h * w, weight, bias, cout, relu, out};
+#define EFFI_GC(NQ) hipLaunchKernelGGL(getcost_conv1x1_kernel<NQ>, grid, dim3(TPB), 0, st, g)
     switch (nq) {
         case 2: EFFI_GC(2); break;
         case 3: EFFI_GC(3); break;
@@ -412,6 +440,32 @@ extern "C" int effi_getcost_conv1x1_f32(const float* inv_depth, const float* dis
         default: return EFFI_ERR_UNSUPPORTED;
     }
 #undef EFFI_GC
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_encoder_inputs_f32(const float* inv_depth, const float* disp_range, int n_range, const float* interval,
+                                       const float* cur_vol, long cds, long cps, int Dcur, const float* reg_vol, long rds,
+                                       long rps, int Dreg, const float* dmin, const float* dmax, long range_ps, int nq, int h,
+                                       int w, const float* weight_c1, const float* bias_c1, const float* weight_d1,
+                                       const float* bias_d1, int cout, float* out_c1, float* out_d1, effi_stream_t stream) {
+    if (!inv_depth || !interval || !cur_vol || !reg_vol || !dmin || !dmax || !weight_c1 || !bias_c1 || !weight_d1 || !bias_d1 ||
+        !out_c1 || !out_d1 || !disp_range || n_range < 2)
+        return EFFI_ERR_BADARG;
+    if (Dcur < 2 || Dreg < 2 || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    if (nq != 3 || (cout != 16 && cout != 32 && cout != 48)) return EFFI_ERR_UNSUPPORTED;
+    const int gx = effi_cdiv(w, 32), gy = effi_cdiv(h, 8), n7 = gx * gy * (cout / 16);
+    const dim3 grid(n7 + effi_cdiv((long)h * w, TPB));
+    hipStream_t st = effi_s(stream);
+    const GetcostConvArgs g{inv_depth, disp_range, n_range, 0, interval, cur_vol, cds, cps, Dcur, reg_vol, rds, rps,
+                            Dreg, dmin, dmax, range_ps, h * w, weight_c1, bias_c1, cout, 1, out_c1};
+#define EFFI_EI(CO) hipLaunchKernelGGL((encoder_inputs_kernel<3, CO>), grid, dim3(TPB), 0, st, g, weight_d1, bias_d1, h, w, out_d1, gx, gy, n7)
+    switch (cout) {
+        case 16: EFFI_EI(16); break;
+        case 32: EFFI_EI(32); break;
+        default: EFFI_EI(48); break;
+    }
+#undef EFFI_EI
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
 }

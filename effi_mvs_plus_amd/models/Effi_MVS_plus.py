@@ -175,7 +175,15 @@ class GetCost(nn.Module):
             return ops.getcost_conv1x1(inv_depth, disp_range[b], interval, cur[b * n:(b + 1) * n], reg[b * n:(b + 1) * n],
                                        lo, hi, CostNum, h, w, weight, bias, cout, relu=True, out=out)
 
+        def lookup_encoder_inputs(inv_depth, wc1, bc1, wd1, bd1, cout, out_c1=None, out_d1=None):
+            """lookup_conv1x1 and the encoder's convd1 (7x7, +ReLU) of the same map in one launch."""
+            h, w = inv_depth.shape[-2:]
+            n = h * w
+            return ops.encoder_inputs(inv_depth, disp_range[b], interval, cur[b * n:(b + 1) * n], reg[b * n:(b + 1) * n],
+                                      lo, hi, CostNum, h, w, wc1, bc1, wd1, bd1, cout, out_c1, out_d1)
+
         lookup.conv1x1 = lookup_conv1x1 if CostNum in (2, 3, 4) else None
+        lookup.encoder_inputs = lookup_encoder_inputs if CostNum == 3 else None
         return lookup
 
     def forward(self, depth_values, pro, features, proj_matrices, depth_interval, depth_max, depth_min, view_weights,
@@ -326,7 +334,13 @@ class Effi_MVS_plus(nn.Module):
                 return ops.getcost_conv1x1(inv_depth, disp_range, itv, cur_c, reg_c, lo_c, hi_c, self.CostNum, h, w,
                                            weight, bias, cout, relu=True, out=out)
 
+            def lookup_encoder_inputs(inv_depth, wc1, bc1, wd1, bd1, cout, out_c1=None, out_d1=None, cur_c=cur_c, reg_c=reg_c,
+                                      lo_c=lo_c, hi_c=hi_c, itv=itv, h=h, w=w):
+                return ops.encoder_inputs(inv_depth, disp_range, itv, cur_c, reg_c, lo_c, hi_c, self.CostNum, h, w,
+                                          wc1, bc1, wd1, bd1, cout, out_c1, out_d1)
+
             lookup.conv1x1 = lookup_conv1x1 if self.CostNum in (2, 3, 4) else None
+            lookup.encoder_inputs = lookup_encoder_inputs if self.CostNum == 3 else None
             _, masks, invs, depths = self.update_block[s].run_fused(hidden, lookup, inv_cur, inp, self.seq_len[s],
                                                                      disp_range)
             preds.extend(d[0] for d in depths)

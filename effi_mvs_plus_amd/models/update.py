@@ -121,29 +121,41 @@ class ProjectionInput(nn.Module):
             lambda: (self.convc1.weight.reshape(self.convc1.out_channels, -1).t().contiguous().float(),
                      self.convc1.bias.contiguous().float()))
 
-    def run(self, disp, cost, context, bufs=None, cor1=None):
+    def conv7_packed(self):
+        return self._caches["d1"].get([self.convd1.weight, self.convd1.bias],
+                                      lambda: packing.pack_conv2d_c1k7(self.convd1.weight, self.convd1.bias))
+
+    def run(self, disp, cost, context, bufs=None, cor1=None, inputs=None):
         """disp [1,h,w], cost [2*nq,h,w], context [cd,h,w] -> [hidden,h,w].  ``bufs``: optional dict of
         scratch tensors reused across GRU iterations; ``cor1``: relu(convc1(cost)), or a callable returning it, when the
-        lookup kernel produces it (then ``cost`` is not needed)."""
+        lookup kernel produces it (then ``cost`` is not needed); ``inputs``: callable returning (relu(convc1(cost)),
+        relu(convd1(disp))) when one launch produces both (``ops.encoder_inputs``)."""
         hd = self.convc1.out_channels
         if self.convd1.in_channels != 1:
             raise NotImplementedError("ProjectionInput: depth_num must be 1 on the HIP path")
         g = (lambda k: bufs.get(k)) if bufs is not None else (lambda k: None)
-        # the depth branch (7x7 -> 3x3) does not depend on the cost branch: it goes to the side stream
-        with ops.Branch() as br:
-            w7, b7 = self._caches["d1"].get([self.convd1.weight, self.convd1.bias],
-                                            lambda: packing.pack_conv2d_c1k7(self.convd1.weight, self.convd1.bias))
-            dfm = ops.conv2d_c1k7_relu(disp, w7, b7, hd, out=g("dfm1"))
-            w, b = _pack(self._caches["d2"], self.convd2)
-            dfm = ops.conv2d([dfm], w, b, hd, 3, act=ops.ACT_RELU, out0=g("dfm2"))
-        if callable(cor1):                     # produced by the lookup kernel, enqueued after the fork so both chains overlap
-            cor1 = cor1()
-        elif cor1 is None:
-            w, b = _pack(self._caches["c1"], self.convc1)
-            cor1 = ops.conv2d([cost], w, b, hd, 1, act=ops.ACT_RELU, out0=g("cor1"))
-        w, b = _pack(self._caches["c2"], self.convc2)
-        cor = ops.conv2d([cor1], w, b, hd, 3, act=ops.ACT_RELU, out0=g("cor2"))
-        br.join(dfm)
+        wd2, bd2 = _pack(self._caches["d2"], self.convd2)
+        wc2, bc2 = _pack(self._caches["c2"], self.convc2)
+        if (inputs is not None and ops.get_precision() == "split" and wd2.wx is not None and wc2.wx is not None
+                and disp.shape[-1] % 4 == 0 and hd <= 64):
+            # the cost chain (lookup + 1x1 -> 3x3) and the depth chain (7x7 -> 3x3) are independent: each level of the two
+            # chains is ONE launch whose workgroups are shared between them (no second stream, no fork / join bubbles)
+            cor1, dfm = inputs()
+            cor, dfm = ops.conv2d_k3_bf16x3_pair([cor1], wc2.wx, bc2, [dfm], wd2.wx, bd2, hd, act=ops.ACT_RELU,
+                                                 out_a=g("cor2"), out_b=g("dfm2"))
+        else:
+            # the depth branch (7x7 -> 3x3) does not depend on the cost branch: it goes to the side stream
+            with ops.Branch() as br:
+                w7, b7 = self.conv7_packed()
+                dfm = ops.conv2d_c1k7_relu(disp, w7, b7, hd, out=g("dfm1"))
+                dfm = ops.conv2d([dfm], wd2, bd2, hd, 3, act=ops.ACT_RELU, out0=g("dfm2"))
+            if callable(cor1):                     # produced by the lookup kernel, enqueued after the fork so both chains overlap
+                cor1 = cor1()
+            elif cor1 is None:
+                w, b = _pack(self._caches["c1"], self.convc1)
+                cor1 = ops.conv2d([cost], w, b, hd, 1, act=ops.ACT_RELU, out0=g("cor1"))
+            cor = ops.conv2d([cor1], wc2, bc2, hd, 3, act=ops.ACT_RELU, out0=g("cor2"))
+            br.join(dfm)
         w, b = _pack(self._caches["d"], self.convd)
         cmix, cd = self.convd.out_channels, context.shape[0]
         if (ops.get_precision() == "split" and w.wx is not None and cor.shape[-1] % 4 == 0 and hd % 8 == 0 and hd % 16 == 0
@@ -213,11 +225,16 @@ class BasicUpdateBlock(nn.Module):
         h_bufs = [mk(hd), mk(hd)]
         inv_list, mask_list, depth_list = [], [], []
         fuse_c1 = getattr(lookup, "conv1x1", None) is not None and hd % 8 == 0
+        fuse_in = fuse_c1 and getattr(lookup, "encoder_inputs", None) is not None and hd in (16, 32, 48)
         for i in range(seq_len):
             if fuse_c1:      # lookup + convc1 + ReLU in one kernel: the cost map never reaches HBM
                 wc1, bc1 = self.encoder.convc1_raw()
+                both = None
+                if fuse_in:
+                    w7, b7 = self.encoder.conv7_packed()
+                    both = lambda d=inv_depth: lookup.encoder_inputs(d, wc1, bc1, w7, b7, hd, bufs["cor1"], bufs["dfm1"])
                 x = self.encoder.run(inv_depth, None, context, bufs,
-                                     cor1=lambda d=inv_depth: lookup.conv1x1(d, wc1, bc1, hd, bufs["cor1"]))
+                                     cor1=lambda d=inv_depth: lookup.conv1x1(d, wc1, bc1, hd, bufs["cor1"]), inputs=both)
             else:
                 cost_buf = lookup(inv_depth, cost_buf)
                 x = self.encoder.run(inv_depth, cost_buf, context, bufs)

@@ -518,6 +518,52 @@ def getcost_conv1x1(x, disp_range, interval, cur_vol, reg_vol, dmin, dmax, nq, h
     return out
 
 
+def encoder_inputs(x, disp_range, interval, cur_vol, reg_vol, dmin, dmax, nq, h, w, weight_c1, bias_c1, weight_d1, bias_d1, cout,
+                   out_c1=None, out_d1=None):
+    """``getcost_conv1x1`` (+ReLU) and ``conv2d_c1k7_relu`` of the same normalised inverse-depth map in one launch ->
+    (relu(convc1(cost)) [cout,h,w], relu(convd1(x)) [cout,h,w]).  nq == 3, cout in {16, 32, 48}."""
+    _t(x, "inv_depth"), _t(interval, "interval"), _t(disp_range, "disp_range")
+    for t_ in (weight_c1, bias_c1, weight_d1, bias_d1):
+        _t(t_, "encoder weights")
+    cur_vol, cds, cps, Dc = _vol_strides(cur_vol, h, w)
+    reg_vol, rds, rps, Dr = _vol_strides(reg_vol, h, w)
+    dmin_t, gps = _range_ptr(dmin, h, w)
+    dmax_t, gps2 = _range_ptr(dmax, h, w)
+    if gps != gps2:
+        raise ValueError("depth_min / depth_max must both be global or both per-pixel")
+    if out_c1 is None:
+        out_c1 = torch.empty(cout, h, w, device=x.device, dtype=torch.float32)
+    if out_d1 is None:
+        out_d1 = torch.empty(cout, h, w, device=x.device, dtype=torch.float32)
+    work = lambda: {"flops": 2.0 * h * w * (2 * nq + 49) * cout, "bytes": 4.0 * h * w * (2 * cout + 1 + Dc + Dr)}
+    check(_call("encoder_inputs", work, _lib.lib().effi_encoder_inputs_f32, _p(x), _p(disp_range), disp_range.numel(),
+                _p(interval), _p(cur_vol), cds, cps, Dc, _p(reg_vol), rds, rps, Dr, _p(dmin_t), _p(dmax_t), gps, nq, h, w,
+                _p(weight_c1), _p(bias_c1), _p(weight_d1), _p(bias_d1), cout, _p(out_c1), _p(out_d1), _stream()),
+          "effi_encoder_inputs_f32")
+    return out_c1, out_d1
+
+
+def conv2d_k3_bf16x3_pair(srcs_a, wpack_a, bias_a, srcs_b, wpack_b, bias_b, cout, act=ACT_NONE, out_a=None, out_b=None):
+    """Two independent split-precision 3x3 convolutions of the same shape in one launch (``conv2d_k3_bf16x3`` twice)."""
+    for s in list(srcs_a) + list(srcs_b):
+        _t(s, "conv2d input")
+    h, w = srcs_a[0].shape[-2:]
+    if tuple(srcs_b[0].shape[-2:]) != (h, w):
+        raise ValueError("conv2d_k3_bf16x3_pair: the two convolutions must share the map size")
+    dev = srcs_a[0].device
+    if out_a is None:
+        out_a = torch.empty(cout, h, w, device=dev, dtype=torch.float32)
+    if out_b is None:
+        out_b = torch.empty(cout, h, w, device=dev, dtype=torch.float32)
+    cin = sum(s.shape[0] for s in srcs_a) + sum(s.shape[0] for s in srcs_b)
+    work = lambda: {"flops": 2.0 * h * w * cin * cout * 9, "bytes": 4.0 * h * w * (cin + 2 * cout)}
+    check(_call(f"conv2d_k3x3_pair_nt{(cout + 15) // 16}", work, _lib.lib().effi_conv2d_k3_bf16x3_pair_f32, _ptr_array(srcs_a),
+                _int_array([s.shape[0] for s in srcs_a]), len(srcs_a), _p(wpack_a), _p(bias_a), _p(out_a), _ptr_array(srcs_b),
+                _int_array([s.shape[0] for s in srcs_b]), len(srcs_b), _p(wpack_b), _p(bias_b), _p(out_b), cout, h, w, act,
+                _stream()), "effi_conv2d_k3_bf16x3_pair_f32")
+    return out_a, out_b
+
+
 def conv2d(srcs, wpack, bias, cout, ks, epilogue=EPI_PLAIN, act=ACT_NONE, aux0=None, aux1=None, disp_range=None,
            out0=None, out1=None):
     for s in srcs:

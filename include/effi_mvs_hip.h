@@ -131,6 +131,13 @@ int effi_conv2d_k3_k1_bf16x3_f32(const float* const* srcs, const int* src_channe
                                  const float* bias, int cout1, int relu1, const float* extra, int c_extra,
                                  const void* w2pack_bf16, const float* bias2, int cout2, int relu, int h, int w, float* out,
                                  effi_stream_t stream);
+/* Two independent 3x3 convolutions of the same shape (cout <= 64, h, w, activation; EPI_PLAIN) in ONE launch, each with
+ * its own sources / weights / bias / output as in effi_conv2d_k3_bf16x3_f32: convc2 and convd2 of the encoder
+ * (models/update.py:87,91), which do not depend on each other. */
+int effi_conv2d_k3_bf16x3_pair_f32(const float* const* srcs_a, const int* src_channels_a, int n_src_a, const void* wpack_a,
+                                   const float* bias_a, float* out_a, const float* const* srcs_b,
+                                   const int* src_channels_b, int n_src_b, const void* wpack_b, const float* bias_b,
+                                   float* out_b, int cout, int h, int w, int act, effi_stream_t stream);
 /* Same operator (stride 1, cout <= 32, w % 4 == 0) in split precision: products as hi*hi + hi*lo + lo*hi on the bf16
  * matrix cores with fp32 accumulation (see effi_conv2d_k3_bf16x3_f32).  Input = channel concatenation of n_src planar
  * tensors [Ci][D][h][w] (models/module.py:513); wpack_bf16 = split-bf16 packing of the weight viewed as
@@ -201,6 +208,17 @@ int effi_getcost_conv1x1_f32(const float* inv_depth, const float* disp_range, in
                              const float* dmin, const float* dmax, long range_pstride, int nq,
                              int h, int w, const float* weight, const float* bias, int cout, int relu,
                              float* out, effi_stream_t stream);
+
+/* Both inputs of the update block's encoder for one GRU iteration in ONE launch (models/update.py:86,90): out_c1 =
+ * relu(convc1(GetCost(inv_depth))) exactly as effi_getcost_conv1x1_f32 (normalised inverse depth in, nq == 3), and out_d1 =
+ * relu(convd1(inv_depth)) exactly as effi_conv2d_c1k7_relu_f32 (weight_d1 [49][cout], cout in {16,32,48}); the two share the
+ * grid, so neither a second stream nor its fork / join is needed to overlap them. */
+int effi_encoder_inputs_f32(const float* inv_depth, const float* disp_range, int n_range, const float* interval,
+                            const float* cur_vol, long cur_dstride, long cur_pstride, int Dcur,
+                            const float* reg_vol, long reg_dstride, long reg_pstride, int Dreg,
+                            const float* dmin, const float* dmax, long range_pstride, int nq, int h, int w,
+                            const float* weight_c1, const float* bias_c1, const float* weight_d1, const float* bias_d1,
+                            int cout, float* out_c1, float* out_d1, effi_stream_t stream);
 
 /* ---- K9: 2-D convolutions of the update block on the fp32 MFMA path (v_mfma_f32_16x16x4_f32).
  * models/update.py:14-15,36-38,73-81,109-112.  ks in {1,3}, padding ks/2, stride 1.

@@ -342,6 +342,16 @@ def test_update_block_parts(model, O, stage, precision):
     want_cor1 = F.relu(F.conv2d(g["cost"], sd[f"update_block.{stage - 1}.encoder.convc1.weight"],
                                 sd[f"update_block.{stage - 1}.encoder.convc1.bias"]))[0]
     check_close(f"GetCost+convc1 st{stage} (golden)", cor1, want_cor1, rtol=1e-4, atol=2e-5, frac_ok=0.999)
+    # ... and the one-launch form that also produces relu(convd1(inv)): the same arithmetic as the two separate kernels
+    from effi_mvs_plus_amd import ops as _ops
+    hd_ = blk.encoder.convc1.out_channels
+    w7, b7 = blk.encoder.conv7_packed()
+    both_c, both_d = lookup.encoder_inputs(inv0[0], wc1, bc1, w7, b7, hd_)
+    assert torch.equal(both_c, cor1)
+    assert torch.equal(both_d, _ops.conv2d_c1k7_relu(inv0[0], w7, b7, hd_))
+    want_d1 = F.relu(F.conv2d(g["inv0"], sd[f"update_block.{stage - 1}.encoder.convd1.weight"],
+                              sd[f"update_block.{stage - 1}.encoder.convd1.bias"], padding=3))[0]
+    check_close(f"convd1 st{stage} (torch)", both_d, want_d1, rtol=1e-4, atol=2e-5)
     enc = blk.encoder(inv0, t(g["cost"], DEV), ctx)
     ct = lambda want, layers=1: conv_tol(precision, want, 1e-4, 2e-5, layers)  # noqa: E731
     check_close(f"ProjectionInput st{stage} (golden)", enc, g["enc"], **ct(g["enc"], 3))
@@ -464,6 +474,23 @@ def test_conv3x3_then_1x1_fused(h, w, cins, cout1, c_extra, cout2, relu1):
                               relu=not relu1, relu1=relu1)
     check_close(f"3x3+1x1 {cins}->{cout1}(+{c_extra})->{cout2} {h}x{w}", got, want.float(), rtol=0.0,
                 atol=6e-5 * float(want.abs().max()))
+
+
+@pytest.mark.parametrize("h,w", [(21, 28), (130, 256), (148, 200), (256, 512), (72, 520)])
+@pytest.mark.parametrize("cin_a,cin_b,cout", [(16, 16, 16), (32, 32, 32), (48, 48, 48), (24, 8, 20), (64, 64, 64)])
+def test_conv2d_pair_matches_two_single_launches(h, w, cin_a, cin_b, cout):
+    """effi_conv2d_k3_bf16x3_pair_f32: two convolutions sharing one grid give the bits of the two single launches."""
+    from effi_mvs_plus_amd import ops, packing
+    g = torch.Generator().manual_seed(cout * 100 + h)
+    xa, xb = t(torch.randn(cin_a, h, w, generator=g), DEV), t(torch.randn(cin_b, h, w, generator=g), DEV)
+    packs = []
+    for cin in (cin_a, cin_b):
+        wt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+        packs.append(packing.pack_conv2d_bf16x3(wt.to(DEV), (0.1 * torch.randn(cout, generator=g)).to(DEV)))
+    (wa, ba), (wb, bb) = packs
+    ya, yb = ops.conv2d_k3_bf16x3_pair([xa], wa, ba, [xb], wb, bb, cout, act=ops.ACT_RELU)
+    assert torch.equal(ya, ops.conv2d_k3_bf16x3([xa], wa, ba, cout, act=ops.ACT_RELU))
+    assert torch.equal(yb, ops.conv2d_k3_bf16x3([xb], wb, bb, cout, act=ops.ACT_RELU))
 
 
 def test_conv2d_split_bf16_refuses_unaligned_sources():

@@ -17,7 +17,7 @@ for name, cins, cout, dims in shapes:
     m = Conv3d(sum(cins), cout, padding=1).eval().to(dev)
     xs = [torch.randn(c, *dims, generator=g).to(dev) for c in cins]
     line = f"{name:18s}"
-    for mode in ("split", "fp32"):
+    for mode in (("split",) if os.environ.get("EFFI_BENCH_SPLIT_ONLY") else ("split", "fp32")):
         ops.set_precision(mode)
         for _ in range(3):
             m.run(xs)
@@ -33,3 +33,24 @@ for name, cins, cout, dims in shapes:
         gb = 4.0 * vox * (sum(cins) + cout) / 1e9
         line += f"  {mode}: {us:7.1f} us ({gb / us * 1e6:6.0f} GB/s algorithmic)"
     print(line)
+
+# transposed convolutions of the stage-1 U-Net (stride 2, with the skip tensor added after the ReLU)
+from effi_mvs_plus_amd.models.module import Deconv3d  # noqa: E402
+ops.set_precision("split")
+for name, cin, cout, dims in [("st1 deconv 32->16", 32, 16, (12, 37, 50)), ("st1 deconv 16->8", 16, 8, (24, 74, 100))]:
+    m = Deconv3d(cin, cout, stride=2, padding=1, output_padding=1).eval().to(dev)
+    x = torch.randn(cin, *dims, generator=g).to(dev)
+    skip = torch.randn(cout, 2 * dims[0], 2 * dims[1], 2 * dims[2], generator=g).to(dev)
+    for _ in range(3):
+        m.run(x, skip)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        m.run(x, skip)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    vox = dims[0] * dims[1] * dims[2]
+    gb = 4.0 * vox * (cin + 16 * cout) / 1e9
+    print(f"{name:18s}  split: {us:7.1f} us ({gb / us * 1e6:6.0f} GB/s algorithmic)")
