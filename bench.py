@@ -64,6 +64,7 @@ def main():
                          "multi-rank plumbing on a box with fewer GPUs than ranks; ranks then share devices)")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -366,6 +367,27 @@ def main():
             result["fusion_filter"]["cpu_reference_ops"] = {"ms_per_ref_view": tq * 1e3, "size": f"{wq}x{hq} (a quarter of the pixels)",
                                                             "cores": torch.get_num_threads(), "kind": "port"}
         del dmaps
+
+    # ---- secondary (rank 0, N = 1): scope row n4, the producer of the path's inputs -- decoded 8-bit images resident in HBM ->
+    # [N,3,H,W] fp32 planes (/255, bilinear resize as scale_mvs_input does it, HWC -> CHW; datasets/general_eval.py:83-117,189)
+    if rank == 0 and world == 1 and not args.no_whole_forward:
+        src_h = H + 16                      # DTU: 1200 -> 1184 rows (general_eval.py:104-109); same 16-row difference elsewhere
+        raws = [torch.randint(0, 256, (src_h, W, 3), dtype=torch.uint8, device=dev) for _ in range(N)]
+        planes = torch.empty(N, 3, H, W, device=dev)
+        prep_ms = timed(lambda: [ops.image_prepare(raws[v], H, W, out=planes[v]) for v in range(N)], n=20)
+        pbytes = N * (3.0 * src_h * W + 12.0 * H * W)
+        result["input_prepare"] = {"views_per_s": 1e3 / prep_ms, "ms_per_ref_view": prep_ms, "images": N,
+                                   "algorithmic_GBps": pbytes / prep_ms / 1e6,
+                                   "note": f"{N} decoded {W}x{src_h} uint8 images in HBM -> [N,3,{H},{W}] fp32, one kernel per image"}
+        if not args.no_cpu_baseline:
+            from oracle import effi_io_oracle as Oio
+            raw_c = raws[0].cpu().numpy()
+            t0 = time.perf_counter()
+            Oio.resize_linear(raw_c.astype(np.float32) / 255., W, H).transpose(2, 0, 1).copy()
+            t1 = time.perf_counter() - t0
+            result["input_prepare"]["cpu_reference_ops"] = {"ms_per_ref_view": t1 * N * 1e3, "cores": 1, "kind": "port",
+                                                            "sample": "one image timed, scaled to N (numpy restatement of /255 + cv2.resize + transpose)"}
+        del raws, planes
 
     # ---- baselines (rank 0, N = 1 only): bounded samples of the same workload ------------------------
     if rank == 0 and world == 1:

@@ -85,18 +85,24 @@ __device__ __forceinline__ void effi_c1k7_relu_tile(const float* __restrict__ in
     }
     __syncthreads();
     const float* __restrict__ wg = wgt + c0;
-    float acc[CG];
+    // channel pairs as 2-vectors: the 784 FMAs of a thread become 392 packed ones (v_pk_fma_f32, weights as SGPR pairs)
+    typedef float effi_f32x2 __attribute__((ext_vector_type(2)));
+    effi_f32x2 acc[CG / 2];
 #pragma unroll
-    for (int c = 0; c < CG; ++c) acc[c] = bias[c0 + c];
+    for (int c = 0; c < CG / 2; ++c) acc[c] = effi_f32x2{bias[c0 + 2 * c], bias[c0 + 2 * c + 1]};
 #pragma unroll
     for (int k = 0; k < 49; ++k) {
         const float v = tile[(ty + k / 7) * IWX + tx + k % 7];
+        const effi_f32x2 vv = {v, v};
 #pragma unroll
-        for (int c = 0; c < CG; ++c) acc[c] = fmaf(v, wg[k * COUT + c], acc[c]);
+        for (int c = 0; c < CG / 2; ++c) {
+            const effi_f32x2 wv = {wg[k * COUT + 2 * c], wg[k * COUT + 2 * c + 1]};
+            acc[c] = __builtin_elementwise_fma(vv, wv, acc[c]);
+        }
     }
     const int x = x0 + tx, y = y0 + ty;
     if (x >= w || y >= h) return;
     const long hw = (long)h * w, pix = (long)y * w + x;
 #pragma unroll
-    for (int c = 0; c < CG; ++c) out[(c0 + c) * hw + pix] = fmaxf(acc[c], 0.0f);
+    for (int c = 0; c < CG; ++c) out[(c0 + c) * hw + pix] = fmaxf(acc[c / 2][c & 1], 0.0f);
 }

@@ -426,6 +426,34 @@ def fusion_dynamic_filter(ref_depth, src_depths, ref_cam, src_cams, ref_conf=Non
     return out
 
 
+def image_prepare(img_u8, dst_h, dst_w, out=None):
+    """Scope row n4: decoded image [h,w,3] (or [h,w]) uint8 on the device -> [3,dst_h,dst_w] fp32 = cv2-style bilinear resize of
+    img / 255, channel-first (datasets/general_eval.py:83-117,189)."""
+    if not isinstance(img_u8, torch.Tensor) or img_u8.dtype != torch.uint8 or not img_u8.is_contiguous():
+        raise TypeError("image_prepare: contiguous uint8 tensor [h,w,c] expected")
+    if img_u8.dim() == 2:
+        img_u8 = img_u8.unsqueeze(-1)
+    if not img_u8.is_cuda:
+        raise _lib.EffiLibraryError("effi_image_prepare_u8_f32 needs a tensor on the GPU (there is no CPU fallback)")
+    h, w, c = img_u8.shape
+    if out is None:
+        out = torch.empty(c, dst_h, dst_w, device=img_u8.device, dtype=torch.float32)
+    work = lambda: {"flops": 0.0, "bytes": 1.0 * h * w * c + 4.0 * c * dst_h * dst_w}
+    check(_call("image_prepare", work, _lib.lib().effi_image_prepare_u8_f32, C.c_void_p(img_u8.data_ptr()), h, w, c, dst_h, dst_w,
+                _p(out), _stream()), "effi_image_prepare_u8_f32")
+    return out
+
+
+def resize_planar(x, dst_h, dst_w, out=None):
+    """[C,h,w] fp32 -> [C,dst_h,dst_w], the bilinear resize of ``image_prepare`` (datasets/general_eval.py:160-166)."""
+    _t(x, "image")
+    c, h, w = x.shape
+    if out is None:
+        out = torch.empty(c, dst_h, dst_w, device=x.device, dtype=torch.float32)
+    check(_lib.lib().effi_resize_linear_f32(_p(x), c, h, w, dst_h, dst_w, _p(out), _stream()), "effi_resize_linear_f32")
+    return out
+
+
 def softmax_regress_conf(logits, depth):
     """logits [D,h,w]; depth [D] / [D,h,w] -> (depth [h,w], confidence [h,w])."""
     D, h, w = logits.shape

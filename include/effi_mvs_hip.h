@@ -292,6 +292,17 @@ int effi_fusion_dynamic_filter_f32(const float* ref_depth, const float* src_dept
                                    unsigned char* out_prob_mask, unsigned char* out_mask, float* out_points,
                                    float* out_reproj_xyd, effi_stream_t stream);
 
+/* ---- scope row n4 (input pipeline): decoded 8-bit image -> network input planes -------------------------------------
+ * datasets/general_eval.py:83-88 (read_img: / 255.), :94-117 and :160-166 (cv2.resize, INTER_LINEAR), :189 (HWC -> CHW);
+ * datasets/tank.py:101-107.  img_hwc: [src_h][src_w][channels] uint8 (channels 1 or 3); out_chw: [channels][dst_h][dst_w]
+ * fp32 = resize_linear(img / 255) with OpenCV's pixel-centre convention (horizontal pass, then vertical, fp32). */
+int effi_image_prepare_u8_f32(const unsigned char* img_hwc, int src_h, int src_w, int channels, int dst_h, int dst_w,
+                              float* out_chw, effi_stream_t stream);
+/* The same resize for an image that is already fp32 planar [channels][src_h][src_w] (second resize to the scene's standard
+ * size, datasets/general_eval.py:160-166). */
+int effi_resize_linear_f32(const float* in_chw, int channels, int src_h, int src_w, int dst_h, int dst_w, float* out_chw,
+                           effi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
