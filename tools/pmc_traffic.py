@@ -24,6 +24,11 @@ def key_of(name):
     m = re.match(r"conv2d_k3_bf16x3_kernel<(\d+), (\d+), (\d+), (true|false)", n)
     if m:
         return (f"conv2d_k3x3_nt{m.group(1)}_epi{m.group(3)}" if m.group(4) == "false" else f"conv3d_x3_nt{m.group(1)}"), 2.0
+    m = re.match(r"conv2d_k3_bf16x3_pair_kernel<(\d+)", n)
+    if m:
+        return f"conv2d_k3x3_pair_nt{m.group(1)}", 2.0
+    if n.startswith("encoder_inputs_kernel"):
+        return "encoder_inputs", 1.0
     m = re.match(r"conv3d_roll_bf16x3_kernel<(\d+), (\d+)", n)
     if m:
         return f"conv3d_roll_oct{m.group(1)}_nt{m.group(2)}", 2.0
