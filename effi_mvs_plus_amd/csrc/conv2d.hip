@@ -848,7 +848,7 @@ __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_pair_kernel(const Conv2d
 //     the slot bases rotate with z and are re-selected once per plane (NKS selects), row offsets are immediates.
 // ------------------------------------------------------------------------------------------------
 template <int NOCT, int NT, int MR>
-__global__ __launch_bounds__(256) void conv3d_roll_bf16x3_kernel(const Conv2dArgs a, int tiles_x, int ntiles, int zt) {
+__device__ __forceinline__ void conv3d_roll_bf16x3_body(const Conv2dArgs a, int tiles_x, int ntiles, int zt) {
     constexpr int TR = 4 * MR, AR = TR + 2, AW = 24, AQ = 6, XOFF = 3, XLEFT = 4;
     constexpr int APIX = AR * AW, NQ = APIX / 4, NITEMS = NQ * NOCT;
     constexpr int NIT = 27 * NOCT, NKS = (NIT + 3) / 4;
@@ -984,6 +984,28 @@ __global__ __launch_bounds__(256) void conv3d_roll_bf16x3_kernel(const Conv2dArg
         plane(B0{}, z);
         if (z + 1 < z1) plane(B1{}, z + 1);
     }
+}
+
+template <int NOCT, int NT, int MR>
+__global__ __launch_bounds__(256) void conv3d_roll_bf16x3_kernel(const Conv2dArgs a, int tiles_x, int ntiles, int zt) {
+    conv3d_roll_bf16x3_body<NOCT, NT, MR>(a, tiles_x, ntiles, zt);
+}
+
+// Two independent convolutions of the same shape in one launch (blockIdx.z picks the argument set): conv1 of the two
+// cross-scale blocks of a stage.
+template <int NOCT, int NT, int MR>
+__global__ __launch_bounds__(256) void conv3d_roll_bf16x3_pair_kernel(const Conv2dArgs a, const Conv2dArgs b, int tiles_x, int ntiles,
+                                                                      int zt) {
+    // the two calls differ in sources, weights, bias and output only: ONE inlined body behind scalar selects
+    Conv2dArgs c = a;
+    if (blockIdx.z) {
+#pragma unroll
+        for (int i = 0; i < EFFI_MAX_SRC; ++i) c.src[i] = b.src[i];
+        c.wpack = b.wpack;
+        c.bias = b.bias;
+        c.out0 = b.out0;
+    }
+    conv3d_roll_bf16x3_body<NOCT, NT, MR>(c, tiles_x, ntiles, zt);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1856,7 +1878,7 @@ extern "C" int effi_conv3d_k3s1_bf16x3_f32(const float* const* srcs, const int* 
 }
 
 template <int NOCT, int NT>
-static int launch_roll(const Conv2dArgs& a, hipStream_t st) {
+static int launch_roll(const Conv2dArgs& a, hipStream_t st, const Conv2dArgs* pair = nullptr) {
     // Rows per wave (MR) and planes per workgroup (ZT) from a small cost model fitted to sweeps at the cfg3 shapes
     // (tools/sweep_roll.sh): the chip holds 256 * occ workgroups at a time (occ from the LDS image / register count of the
     // instantiation), a launch takes ceil(workgroups / that) rounds, and a workgroup costs (ZT + 3) plane steps (3 ~ filling
@@ -1870,7 +1892,7 @@ static int launch_roll(const Conv2dArgs& a, hipStream_t st) {
         const long tiles_m = (long)cols * effi_cdiv(a.h, 4 * m), slots = 256L * occ;
         for (int nz = 1; nz <= D; ++nz) {
             const int z = effi_cdiv(D, nz);
-            const long wgs = tiles_m * effi_cdiv(D, z);
+            const long wgs = tiles_m * effi_cdiv(D, z) * (pair ? 2 : 1);
             const double cost = (double)effi_cdiv(wgs, slots) * (z + 3) * (m == 4 ? 1.3 : 1.0);
             if (cost < best - 1e-9) { best = cost; mr = m; zt = z; }
         }
@@ -1880,18 +1902,21 @@ static int launch_roll(const Conv2dArgs& a, hipStream_t st) {
     if (fm) mr = atoi(fm);
     if (fz) zt = atoi(fz);
     const long tiles = (long)cols * effi_cdiv(a.h, 4 * mr);
-    const dim3 grid((unsigned)tiles, (unsigned)effi_cdiv(D, zt));
-    if (mr == 4) hipLaunchKernelGGL((conv3d_roll_bf16x3_kernel<NOCT, NT, 4>), grid, dim3(256), 0, st, a, cols, (int)tiles, zt);
-    else hipLaunchKernelGGL((conv3d_roll_bf16x3_kernel<NOCT, NT, 2>), grid, dim3(256), 0, st, a, cols, (int)tiles, zt);
+    const dim3 grid((unsigned)tiles, (unsigned)effi_cdiv(D, zt), pair ? 2 : 1);
+    if (pair) {
+        if (mr == 4) hipLaunchKernelGGL((conv3d_roll_bf16x3_pair_kernel<NOCT, NT, 4>), grid, dim3(256), 0, st, a, *pair, cols, (int)tiles, zt);
+        else hipLaunchKernelGGL((conv3d_roll_bf16x3_pair_kernel<NOCT, NT, 2>), grid, dim3(256), 0, st, a, *pair, cols, (int)tiles, zt);
+    } else {
+        if (mr == 4) hipLaunchKernelGGL((conv3d_roll_bf16x3_kernel<NOCT, NT, 4>), grid, dim3(256), 0, st, a, cols, (int)tiles, zt);
+        else hipLaunchKernelGGL((conv3d_roll_bf16x3_kernel<NOCT, NT, 2>), grid, dim3(256), 0, st, a, cols, (int)tiles, zt);
+    }
     return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
 
-extern "C" int effi_conv3d_k3s1_roll_bf16x3_f32(const float* const* srcs, const int* src_channels, int n_src,
-                                                const void* wpack_bf16, const float* bias, int cout, int D, int h, int w,
-                                                int relu, float* out, effi_stream_t stream) {
+static int fill_roll_args(Conv2dArgs& a, const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
+                          const float* bias, int cout, int D, int h, int w, int relu, float* out) {
     if (!srcs || !src_channels || n_src < 1 || n_src > 2 || !wpack_bf16 || !bias || !out) return EFFI_ERR_BADARG;
     if (cout < 1 || D < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
-    Conv2dArgs a;
     a.cin = 0;
     for (int i = 0; i < EFFI_MAX_SRC; ++i) {
         a.src[i] = (i < n_src) ? srcs[i] : nullptr;
@@ -1916,11 +1941,34 @@ extern "C" int effi_conv3d_k3s1_roll_bf16x3_f32(const float* const* srcs, const 
     a.out0 = out;
     a.out1 = nullptr;
     a.cstride = a.ostride = (long)D * h * w;
-    a.zcount = D;
+    a.zcount = a.zin = D;
+    return EFFI_OK;
+}
+
+extern "C" int effi_conv3d_k3s1_roll_bf16x3_f32(const float* const* srcs, const int* src_channels, int n_src,
+                                                const void* wpack_bf16, const float* bias, int cout, int D, int h, int w,
+                                                int relu, float* out, effi_stream_t stream) {
+    Conv2dArgs a;
+    const int rc = fill_roll_args(a, srcs, src_channels, n_src, wpack_bf16, bias, cout, D, h, w, relu, out);
+    if (rc != EFFI_OK) return rc;
     hipStream_t st = effi_s(stream);
     const int nt = (cout + 15) / 16;
     if (a.cin == 8) return nt == 1 ? launch_roll<1, 1>(a, st) : launch_roll<1, 2>(a, st);
     return nt == 1 ? launch_roll<2, 1>(a, st) : launch_roll<2, 2>(a, st);
+}
+
+extern "C" int effi_conv3d_k3s1_roll_bf16x3_pair_f32(const float* const* srcs_a, const void* wpack_a, const float* bias_a,
+                                                     float* out_a, const float* const* srcs_b, const void* wpack_b,
+                                                     const float* bias_b, float* out_b, const int* src_channels, int n_src,
+                                                     int cout, int D, int h, int w, int relu, effi_stream_t stream) {
+    Conv2dArgs a, b;
+    int rc = fill_roll_args(a, srcs_a, src_channels, n_src, wpack_a, bias_a, cout, D, h, w, relu, out_a);
+    if (rc != EFFI_OK) return rc;
+    rc = fill_roll_args(b, srcs_b, src_channels, n_src, wpack_b, bias_b, cout, D, h, w, relu, out_b);
+    if (rc != EFFI_OK) return rc;
+    if (cout > 16) return EFFI_ERR_UNSUPPORTED;
+    hipStream_t st = effi_s(stream);
+    return a.cin == 8 ? launch_roll<1, 1>(a, st, &b) : launch_roll<2, 1>(a, st, &b);
 }
 
 extern "C" int effi_deconv3d_k3s2_bf16x3_f32(const float* in, int cin, const void* wpack_bf16, const float* bias, int cout, int D,

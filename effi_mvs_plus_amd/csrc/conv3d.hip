@@ -34,12 +34,13 @@ __device__ __forceinline__ const float* src_channel(const SrcSet& s, int c, long
 // DENSE: cout == COUT_T (every layer still on this kernel: cout 8 or 1), so the weight row stride is a compile-time constant
 // and all 27*COUT_T weights of a channel are scalar loads at immediate offsets from one base (measured before: as many scalar
 // ALU instructions as vector ones, spent on per-tap address arithmetic with the runtime stride).
-template <int COUT_T, int SZ, int SXY, int ZPT, bool DENSE = false>
-__global__ __launch_bounds__(256) void conv3d_k3_kernel(SrcSet src, int cin, const float* __restrict__ wgt,
-                                                        const float* __restrict__ bias, int cout,
-                                                        int D, int h, int w, int Do, int ho, int wo,
-                                                        int relu, const float* __restrict__ skip,
-                                                        float* __restrict__ out) {
+// (a __device__ body so that two independent convolutions can share one grid: conv3d_k3_pair_kernel below)
+template <int COUT_T, int SZ, int SXY, int ZPT, bool DENSE>
+__device__ __forceinline__ void conv3d_k3_body(SrcSet src, int cin, const float* __restrict__ wgt,
+                                               const float* __restrict__ bias, int cout,
+                                               int D, int h, int w, int Do, int ho, int wo,
+                                               int relu, const float* __restrict__ skip,
+                                               float* __restrict__ out) {
     constexpr int CC = (SXY == 1) ? 4 : ((SZ == 1) ? 1 : 2);
     constexpr int IZ = (ZPT - 1) * SZ + 3, IY = (TY - 1) * SXY + 3, IX = (TX - 1) * SXY + 3;
     constexpr int PLANE = IZ * IY * IX;
@@ -167,6 +168,39 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(SrcSet src, int cin, con
     }
 }
 
+template <int COUT_T, int SZ, int SXY, int ZPT, bool DENSE = false>
+__global__ __launch_bounds__(256) void conv3d_k3_kernel(SrcSet src, int cin, const float* __restrict__ wgt,
+                                                        const float* __restrict__ bias, int cout,
+                                                        int D, int h, int w, int Do, int ho, int wo,
+                                                        int relu, const float* __restrict__ skip,
+                                                        float* __restrict__ out) {
+    conv3d_k3_body<COUT_T, SZ, SXY, ZPT, DENSE>(src, cin, wgt, bias, cout, D, h, w, Do, ho, wo, relu, skip, out);
+}
+
+// Two independent convolutions of the same shape in one launch: blockIdx.y picks the argument set (the two cross-scale blocks
+// CSP_R / CSP_C of a stage, models/Effi_MVS_plus.py:520-531, which would otherwise be forked onto two streams).
+struct Conv3dCall {
+    SrcSet src;
+    const float* wgt;
+    const float* bias;
+    const float* skip;
+    float* out;
+};
+template <int COUT_T, int SZ, int SXY, int ZPT>
+__global__ __launch_bounds__(256) void conv3d_k3_pair_kernel(Conv3dCall a, Conv3dCall b, int cin, int cout, int D, int h, int w,
+                                                             int Do, int ho, int wo, int relu) {
+    // ONE inlined body behind scalar selects of the arguments (two inlined copies cost up to 3x the registers)
+    const bool second = blockIdx.y != 0;
+    SrcSet src;
+#pragma unroll
+    for (int i = 0; i < EFFI_MAX_SRC; ++i) {
+        src.p[i] = second ? b.src.p[i] : a.src.p[i];
+        src.ch[i] = second ? b.src.ch[i] : a.src.ch[i];
+    }
+    conv3d_k3_body<COUT_T, SZ, SXY, ZPT, true>(src, cin, second ? b.wgt : a.wgt, second ? b.bias : a.bias, cout, D, h, w, Do, ho, wo,
+                                               relu, second ? b.skip : a.skip, second ? b.out : a.out);
+}
+
 // ------------------------------------------------------------------------------------------------
 // transposed convolution, stride (SZ, 2, 2), padding 1, output_padding (SZ-1, 1, 1).
 // One thread per INPUT position: it produces the 2x2 (x SZ) output block that position owns, so every
@@ -176,11 +210,11 @@ __global__ __launch_bounds__(256) void conv3d_k3_kernel(SrcSet src, int cin, con
 // stride 1 along z:        out[z]    = sum_kd in[z + 1 - kd] * w[kd]
 // ------------------------------------------------------------------------------------------------
 template <int COUT_T, int SZ>
-__global__ __launch_bounds__(256) void deconv3d_k3_kernel(const float* __restrict__ in, int cin,
-                                                          const float* __restrict__ wgt,
-                                                          const float* __restrict__ bias, int cout,
-                                                          int D, int h, int w, int relu,
-                                                          const float* __restrict__ skip, float* __restrict__ out) {
+__device__ __forceinline__ void deconv3d_k3_body(const float* __restrict__ in, int cin,
+                                                 const float* __restrict__ wgt,
+                                                 const float* __restrict__ bias, int cout,
+                                                 int D, int h, int w, int relu,
+                                                 const float* __restrict__ skip, float* __restrict__ out) {
     constexpr int ZPT = (SZ == 2) ? 1 : 4;            // input z positions per thread
     constexpr int OZ = (SZ == 2) ? 2 : ZPT;           // output z positions per thread
     constexpr int CC = 4;
@@ -327,6 +361,30 @@ __global__ __launch_bounds__(256) void deconv3d_k3_kernel(const float* __restric
     }
 }
 
+template <int COUT_T, int SZ>
+__global__ __launch_bounds__(256) void deconv3d_k3_kernel(const float* __restrict__ in, int cin,
+                                                          const float* __restrict__ wgt,
+                                                          const float* __restrict__ bias, int cout,
+                                                          int D, int h, int w, int relu,
+                                                          const float* __restrict__ skip, float* __restrict__ out) {
+    deconv3d_k3_body<COUT_T, SZ>(in, cin, wgt, bias, cout, D, h, w, relu, skip, out);
+}
+
+struct Deconv3dCall {
+    const float* in;
+    const float* wgt;
+    const float* bias;
+    const float* skip;
+    float* out;
+};
+template <int COUT_T, int SZ>
+__global__ __launch_bounds__(256) void deconv3d_k3_pair_kernel(Deconv3dCall a, Deconv3dCall b, int cin, int cout, int D, int h,
+                                                               int w, int relu) {
+    const bool second = blockIdx.y != 0;
+    deconv3d_k3_body<COUT_T, SZ>(second ? b.in : a.in, cin, second ? b.wgt : a.wgt, second ? b.bias : a.bias, cout, D, h, w, relu,
+                                 second ? b.skip : a.skip, second ? b.out : a.out);
+}
+
 template <int COUT_T, int SZ, int SXY, int ZPT>
 int launch_conv_z(const SrcSet& s, int cin, const float* wgt, const float* bias, int cout, int D, int h, int w,
                   int relu, const float* skip, float* out, hipStream_t st) {
@@ -399,6 +457,49 @@ extern "C" int effi_deconv3d_k3_f32(const float* in, int cin, const float* weigh
     } else {
         return EFFI_ERR_UNSUPPORTED;
     }
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+// ---- pair launches (see conv3d_k3_pair_kernel) ------------------------------------------------------------------------
+namespace {
+template <int SXY, int ZPT>
+int launch_conv_pair(const Conv3dCall& a, const Conv3dCall& b, int cin, int D, int h, int w, int relu, hipStream_t st) {
+    const int ho = (h - 1) / SXY + 1, wo = (w - 1) / SXY + 1;
+    const dim3 grid(effi_cdiv(wo, TX) * effi_cdiv(ho, TY) * effi_cdiv(D, ZPT), 2);
+    hipLaunchKernelGGL((conv3d_k3_pair_kernel<8, 1, SXY, ZPT>), grid, dim3(256), 0, st, a, b, cin, 8, D, h, w, D, ho, wo, relu);
+    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+}
+}  // namespace
+
+extern "C" int effi_conv3d_k3_pair_f32(const float* in_a, const float* weight_a, const float* bias_a, float* out_a,
+                                       const float* in_b, const float* weight_b, const float* bias_b, float* out_b, int cin,
+                                       int cout, int D, int h, int w, int sxy, int relu, effi_stream_t stream) {
+    if (!in_a || !weight_a || !out_a || !in_b || !weight_b || !out_b || cin < 1 || D < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    if (cout != 8 || (sxy != 1 && sxy != 2)) return EFFI_ERR_UNSUPPORTED;
+    Conv3dCall a, b;
+    for (int i = 0; i < EFFI_MAX_SRC; ++i) {
+        a.src.p[i] = (i == 0) ? in_a : nullptr;
+        b.src.p[i] = (i == 0) ? in_b : nullptr;
+        a.src.ch[i] = b.src.ch[i] = (i == 0) ? cin : 0;
+    }
+    a.wgt = weight_a; a.bias = bias_a; a.skip = nullptr; a.out = out_a;
+    b.wgt = weight_b; b.bias = bias_b; b.skip = nullptr; b.out = out_b;
+    hipStream_t st = effi_s(stream);
+    const int ho = (h - 1) / sxy + 1, wo = (w - 1) / sxy + 1;
+    const bool big = 2L * effi_cdiv(wo, TX) * effi_cdiv(ho, TY) * effi_cdiv(D, 4) >= 384;     // as launch_conv, for both grids
+    if (sxy == 1) return big ? launch_conv_pair<1, 4>(a, b, cin, D, h, w, relu, st) : launch_conv_pair<1, 1>(a, b, cin, D, h, w, relu, st);
+    return big ? launch_conv_pair<2, 4>(a, b, cin, D, h, w, relu, st) : launch_conv_pair<2, 1>(a, b, cin, D, h, w, relu, st);
+}
+
+extern "C" int effi_deconv3d_k3_pair_f32(const float* in_a, const float* weight_a, const float* bias_a, float* out_a,
+                                         const float* in_b, const float* weight_b, const float* bias_b, float* out_b, int cin,
+                                         int cout, int D, int h, int w, int sz, int relu, effi_stream_t stream) {
+    if (!in_a || !weight_a || !out_a || !in_b || !weight_b || !out_b || cin < 1 || D < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    if (sz != 1 || cout != 1) return EFFI_ERR_UNSUPPORTED;
+    const Deconv3dCall a{in_a, weight_a, bias_a, nullptr, out_a}, b{in_b, weight_b, bias_b, nullptr, out_b};
+    const dim3 grid(effi_cdiv(w, TX) * effi_cdiv(h, TY) * effi_cdiv(D, 4), 2);
+    hipLaunchKernelGGL((deconv3d_k3_pair_kernel<1, 1>), grid, dim3(256), 0, effi_s(stream), a, b, cin, cout, D, h, w, relu);
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
 }

@@ -206,12 +206,18 @@ __device__ __forceinline__ float lookup1d(const float* __restrict__ vol, long ds
     return r;
 }
 
+// blockIdx.y = 1 (pair launch, effi_vol_lookup1d_pair_f32): the same queries into a second volume of the same shape
 __global__ void vol_lookup1d_kernel(const float* __restrict__ vol, long vds, long vps, int Dp,
                                     const float* __restrict__ query, long qds, long qys, long qxs, int nq,
                                     const float* __restrict__ dmin, const float* __restrict__ dmax, long rps,
-                                    int h, int w, float* __restrict__ out) {
+                                    int h, int w, float* __restrict__ out, const float* __restrict__ vol_b,
+                                    float* __restrict__ out_b) {
     const int p = blockIdx.x * TPB + threadIdx.x;
     if (p >= h * w) return;
+    if (blockIdx.y) {
+        vol = vol_b;
+        out = out_b;
+    }
     const int y = p / w, x = p - y * w;
     const float lo = dmin[p * rps], hi = dmax[p * rps];
     const float* v = vol + p * vps;
@@ -453,7 +459,17 @@ extern "C" int effi_vol_lookup1d_f32(const float* vol, long vds, long vps, int D
                                      int h, int w, float* out, effi_stream_t stream) {
     if (!vol || !query || !dmin || !dmax || !out || Dp < 2 || nq < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
     hipLaunchKernelGGL(vol_lookup1d_kernel, dim3(effi_cdiv((long)h * w, TPB)), dim3(TPB), 0, effi_s(stream), vol, vds,
-                       vps, Dp, query, qds, qys, qxs, nq, dmin, dmax, rps, h, w, out);
+                       vps, Dp, query, qds, qys, qxs, nq, dmin, dmax, rps, h, w, out, nullptr, nullptr);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_vol_lookup1d_pair_f32(const float* vol_a, const float* vol_b, long vds, long vps, int Dp, const float* query,
+                                          long qds, long qys, long qxs, int nq, const float* dmin, const float* dmax, long rps,
+                                          int h, int w, float* out_a, float* out_b, effi_stream_t stream) {
+    if (!vol_a || !vol_b || !query || !dmin || !dmax || !out_a || !out_b || Dp < 2 || nq < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    hipLaunchKernelGGL(vol_lookup1d_kernel, dim3(effi_cdiv((long)h * w, TPB), 2), dim3(TPB), 0, effi_s(stream), vol_a, vds,
+                       vps, Dp, query, qds, qys, qxs, nq, dmin, dmax, rps, h, w, out_a, vol_b, out_b);
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
 }

@@ -306,14 +306,21 @@ class Effi_MVS_plus(nn.Module):
                 D = self.depth_stage_nums[s]
                 sim, samples = ops.warpcorr_dyn(nhwc[0], nhwc[1:], rt, preds[-1], misc[s:s + 1], weights, D)
                 x = sim.unsqueeze(0)
-                # the two cross-scale blocks are independent chains of 5 kernels: CSP_C goes to the side stream
-                with ops.Branch() as br:
-                    prior_c = ops.vol_lookup1d(cur_vol, samples, lo_prev, hi_prev, h // 2, w // 2)
-                    cur_new = self.CSP_C[s - 1].run(x, prior_c.unsqueeze(0))[0][0]
-                prior = ops.vol_lookup1d(reg_vol, samples, lo_prev, hi_prev, h // 2, w // 2)
-                reg_vol = self.CSP_R[s - 1].run(x, prior.unsqueeze(0))[0][0]
-                br.join(cur_new)
-                cur_vol = cur_new
+                # the two cross-scale blocks are independent chains of 5 kernels on volumes of the same shape
+                csp_r, csp_c = self.CSP_R[s - 1], self.CSP_C[s - 1]
+                if cur_vol.shape == reg_vol.shape and cur_vol.dim() == 3 and cost_up_small.pairable(csp_r, csp_c, x, w // 2):
+                    # ... so each layer of both is ONE launch (no second stream, no fork / join bubbles)
+                    prior, prior_c = ops.vol_lookup1d_pair(reg_vol, cur_vol, samples, lo_prev, hi_prev, h // 2, w // 2)
+                    (reg_new, _), (cur_new, _) = cost_up_small.run_pair(csp_r, csp_c, x, prior.unsqueeze(0), prior_c.unsqueeze(0))
+                    reg_vol, cur_vol = reg_new[0], cur_new[0]
+                else:
+                    with ops.Branch() as br:           # general shapes: CSP_C goes to the side stream
+                        prior_c = ops.vol_lookup1d(cur_vol, samples, lo_prev, hi_prev, h // 2, w // 2)
+                        cur_new = csp_c.run(x, prior_c.unsqueeze(0))[0][0]
+                    prior = ops.vol_lookup1d(reg_vol, samples, lo_prev, hi_prev, h // 2, w // 2)
+                    reg_vol = csp_r.run(x, prior.unsqueeze(0))[0][0]
+                    br.join(cur_new)
+                    cur_vol = cur_new
                 lo_cur, hi_cur = samples[D - 1], samples[0]      # depth_min2 / depth_max2 (:508-509)
             if want_intermediates:
                 inter["view_weights"] = weights

@@ -355,6 +355,38 @@ class cost_up_small(nn.Module):
         c1 = self.conv1.run([a, b])
         return self.conv2.run(c1), c1
 
+    def _roll_packed(self):
+        c = self.conv1
+        t = [c.conv.weight, c.conv.bias] + ([c.bn.weight, c.bn.bias, c.bn.running_mean, c.bn.running_var] if c.bn is not None else [])
+        return c._cache_roll.get(t, lambda: packing.pack_conv3d_roll_bf16x3(c.conv, c.bn))
+
+    @staticmethod
+    def pairable(a, b, x, prior_w):
+        """Two blocks can share their launches when they have the stock shape (1 -> 8 -> 8 -> 1 channels, stride (1,2,2)), the
+        same input volume shape and the split-precision rolling conv applies to conv1."""
+        def stock(m):
+            return (m.conv0.conv.in_channels == 1 and m.conv0.out_channels == 8 and _triple(m.conv0.conv.stride) == (1, 2, 2)
+                    and m.conv_cost.conv.in_channels == 1 and m.conv_cost.out_channels == 8
+                    and _triple(m.conv_cost.conv.stride) == (1, 1, 1) and m.conv1.out_channels == 8
+                    and _triple(m.conv1.conv.stride) == (1, 1, 1) and m.conv2.out_channels == 1
+                    and _triple(m.conv2.conv.stride) == (1, 2, 2) and m.conv0.relu and m.conv_cost.relu and m.conv1.relu
+                    and m.conv2.relu and not m.training)
+        return stock(a) and stock(b) and ops.get_precision() == "split" and x.shape[0] == 1 and prior_w % 4 == 0
+
+    @staticmethod
+    def run_pair(a, b, x, prior_a, prior_b):
+        """``a.run(x, prior_a)`` and ``b.run(x, prior_b)`` with every layer of the two blocks in ONE launch (the blocks are
+        independent: CSP_R[s] and CSP_C[s] of a stage, reference models/Effi_MVS_plus.py:520-531) -> ((out_a, c1_a), (out_b, c1_b))."""
+        (w0a, b0a), (w0b, b0b) = a.conv0._packed(), b.conv0._packed()
+        fa, fb = ops.conv3d_k3_pair(x, w0a, b0a, x, w0b, b0b, 8, sxy=2, relu=True)
+        (wca, bca), (wcb, bcb) = a.conv_cost._packed(), b.conv_cost._packed()
+        ga, gb = ops.conv3d_k3_pair(prior_a, wca, bca, prior_b, wcb, bcb, 8, sxy=1, relu=True)
+        (w1a, b1a), (w1b, b1b) = a._roll_packed(), b._roll_packed()
+        c1a, c1b = ops.conv3d_k3s1_roll_pair([fa, ga], w1a, b1a, [fb, gb], w1b, b1b, 8, relu=True)
+        (w2a, b2a), (w2b, b2b) = a.conv2._packed(), b.conv2._packed()
+        oa, ob = ops.deconv3d_k3_pair(c1a, w2a, b2a, c1b, w2b, b2b, 1, sz=1, relu=True)
+        return (oa, c1a), (ob, c1b)
+
     def forward(self, x, IGEV_cost):
         outs = [self.run(x[i].contiguous(), IGEV_cost[i].contiguous()) for i in range(x.shape[0])]
         return _stack([o[0] for o in outs]), _stack([o[1] for o in outs])

@@ -509,6 +509,78 @@ def vol_lookup1d(vol, query, dmin, dmax, h, w):
     return out
 
 
+def vol_lookup1d_pair(vol_a, vol_b, query, dmin, dmax, h, w):
+    """``vol_lookup1d`` into two planar volumes of the same shape with the same queries, one launch -> (out_a, out_b)."""
+    vol_a, vds, vps, Dp = _vol_strides(vol_a, h, w)
+    vol_b, vds_b, vps_b, Dp_b = _vol_strides(vol_b, h, w)
+    if (vds, vps, Dp) != (vds_b, vps_b, Dp_b):
+        raise ValueError("vol_lookup1d_pair: the two volumes must share shape and layout")
+    _t(query, "query")
+    nq, qh, qw = query.shape
+    if (qh, qw) == (h, w):
+        qys, qxs = qw, 1
+    elif (qh // 2, qw // 2) == (h, w):
+        qys, qxs = 2 * qw, 2
+    else:
+        raise ValueError("query resolution must equal the volume's or be twice it")
+    dmin_t, rps = _range_ptr(dmin, h, w)
+    dmax_t, rps2 = _range_ptr(dmax, h, w)
+    if rps != rps2:
+        raise ValueError("depth_min / depth_max must both be global or both per-pixel")
+    out_a = torch.empty(nq, h, w, device=query.device, dtype=torch.float32)
+    out_b = torch.empty_like(out_a)
+    check(_lib.lib().effi_vol_lookup1d_pair_f32(_p(vol_a), _p(vol_b), vds, vps, Dp, _p(query), qh * qw, qys, qxs, nq, _p(dmin_t),
+                                                 _p(dmax_t), rps, h, w, _p(out_a), _p(out_b), _stream()), "effi_vol_lookup1d_pair_f32")
+    return out_a, out_b
+
+
+def conv3d_k3_pair(x_a, weight_a, bias_a, x_b, weight_b, bias_b, cout, sxy=1, relu=True):
+    """``conv3d_k3`` of two single-source convolutions of the same shape (cout 8, stride (1,sxy,sxy)) in one launch."""
+    _t(x_a, "conv3d input"), _t(x_b, "conv3d input")
+    if x_a.shape != x_b.shape:
+        raise ValueError("conv3d_k3_pair: the two inputs must share their shape")
+    cin, D, h, w = x_a.shape
+    ho, wo = (h - 1) // sxy + 1, (w - 1) // sxy + 1
+    out_a = torch.empty(cout, D, ho, wo, device=x_a.device, dtype=torch.float32)
+    out_b = torch.empty_like(out_a)
+    work = lambda: {"flops": 2.0 * 2 * 27 * cin * cout * D * ho * wo, "bytes": 2 * 4.0 * (cin * D * h * w + cout * D * ho * wo)}
+    check(_call(f"conv3d_pair_c8_s1{sxy}", work, _lib.lib().effi_conv3d_k3_pair_f32, _p(x_a), _p(weight_a), _p(bias_a), _p(out_a),
+                _p(x_b), _p(weight_b), _p(bias_b), _p(out_b), cin, cout, D, h, w, sxy, int(relu), _stream()), "effi_conv3d_k3_pair_f32")
+    return out_a, out_b
+
+
+def conv3d_k3s1_roll_pair(srcs_a, wpack_a, bias_a, srcs_b, wpack_b, bias_b, cout, relu=True):
+    """``conv3d_k3s1_roll`` of two convolutions with the same source split and shape in one launch."""
+    for s in list(srcs_a) + list(srcs_b):
+        _t(s, "conv3d input")
+    if [tuple(s.shape) for s in srcs_a] != [tuple(s.shape) for s in srcs_b]:
+        raise ValueError("conv3d_k3s1_roll_pair: the two source lists must share their shapes")
+    _, D, h, w = srcs_a[0].shape
+    cin = sum(s.shape[0] for s in srcs_a)
+    out_a = torch.empty(cout, D, h, w, device=srcs_a[0].device, dtype=torch.float32)
+    out_b = torch.empty_like(out_a)
+    work = lambda: {"flops": 2 * 2.0 * 27 * cin * cout * D * h * w, "bytes": 2 * 4.0 * (cin + cout) * D * h * w}
+    check(_call(f"conv3d_roll_pair_oct{cin // 8}", work, _lib.lib().effi_conv3d_k3s1_roll_bf16x3_pair_f32, _ptr_array(srcs_a),
+                _p(wpack_a), _p(bias_a), _p(out_a), _ptr_array(srcs_b), _p(wpack_b), _p(bias_b), _p(out_b),
+                _int_array([s.shape[0] for s in srcs_a]), len(srcs_a), cout, D, h, w, int(relu), _stream()),
+          "effi_conv3d_k3s1_roll_bf16x3_pair_f32")
+    return out_a, out_b
+
+
+def deconv3d_k3_pair(x_a, weight_a, bias_a, x_b, weight_b, bias_b, cout, sz=1, relu=True):
+    """``deconv3d_k3`` (stride (1,2,2), cout 1) of two inputs of the same shape in one launch."""
+    _t(x_a, "deconv3d input"), _t(x_b, "deconv3d input")
+    if x_a.shape != x_b.shape:
+        raise ValueError("deconv3d_k3_pair: the two inputs must share their shape")
+    cin, D, h, w = x_a.shape
+    out_a = torch.empty(cout, sz * D, 2 * h, 2 * w, device=x_a.device, dtype=torch.float32)
+    out_b = torch.empty_like(out_a)
+    work = lambda: {"flops": 2 * 2.0 * 27 * cin * cout * D * h * w, "bytes": 2 * 4.0 * (cin * D * h * w + cout * sz * D * 4 * h * w)}
+    check(_call("deconv3d_pair_c1_s1", work, _lib.lib().effi_deconv3d_k3_pair_f32, _p(x_a), _p(weight_a), _p(bias_a), _p(out_a),
+                _p(x_b), _p(weight_b), _p(bias_b), _p(out_b), cin, cout, D, h, w, sz, int(relu), _stream()), "effi_deconv3d_k3_pair_f32")
+    return out_a, out_b
+
+
 def getcost(x, disp_range, interval, cur_vol, reg_vol, dmin, dmax, nq, h, w, input_is_depth=False, out=None):
     _t(x, "inv_depth"), _t(interval, "interval")
     cur_vol, cds, cps, Dc = _vol_strides(cur_vol, h, w)

@@ -292,6 +292,30 @@ int effi_fusion_dynamic_filter_f32(const float* ref_depth, const float* src_dept
                                    unsigned char* out_prob_mask, unsigned char* out_mask, float* out_points,
                                    float* out_reproj_xyd, effi_stream_t stream);
 
+/* ---- pair launches for the two cross-scale blocks of a stage (CSP_R[s] / CSP_C[s], models/Effi_MVS_plus.py:520-531): the two
+ * blocks are independent chains of the same five layers on volumes of the same shape.  Each entry below runs the SAME layer of
+ * both blocks in one launch (a grid dimension picks the block), with the arithmetic of the single-block entry it is named after;
+ * results are bitwise those of two single launches.  (On two streams the chains overlap as well, but each fork / join of
+ * streams inside a captured graph costs ~5 / ~11 us of idle GPU.) */
+/* effi_vol_lookup1d_f32 into two volumes of the same shape with the same queries and ranges. */
+int effi_vol_lookup1d_pair_f32(const float* vol_a, const float* vol_b, long vol_dstride, long vol_pstride, int Dp,
+                               const float* query, long q_dstride, long q_ystride, long q_xstride, int nq, const float* dmin,
+                               const float* dmax, long range_pstride, int h, int w, float* out_a, float* out_b,
+                               effi_stream_t stream);
+/* effi_conv3d_k3_f32 twice: one source tensor of cin channels each, cout == 8, stride (1, sxy, sxy), sxy in {1, 2}, no skip. */
+int effi_conv3d_k3_pair_f32(const float* in_a, const float* weight_a, const float* bias_a, float* out_a, const float* in_b,
+                            const float* weight_b, const float* bias_b, float* out_b, int cin, int cout, int D, int h, int w,
+                            int sxy, int relu, effi_stream_t stream);
+/* effi_conv3d_k3s1_roll_bf16x3_f32 twice (same source channel split, cout <= 16). */
+int effi_conv3d_k3s1_roll_bf16x3_pair_f32(const float* const* srcs_a, const void* wpack_a, const float* bias_a, float* out_a,
+                                          const float* const* srcs_b, const void* wpack_b, const float* bias_b, float* out_b,
+                                          const int* src_channels, int n_src, int cout, int D, int h, int w, int relu,
+                                          effi_stream_t stream);
+/* effi_deconv3d_k3_f32 twice: stride (1,2,2), cout == 1, no skip. */
+int effi_deconv3d_k3_pair_f32(const float* in_a, const float* weight_a, const float* bias_a, float* out_a, const float* in_b,
+                              const float* weight_b, const float* bias_b, float* out_b, int cin, int cout, int D, int h, int w,
+                              int sz, int relu, effi_stream_t stream);
+
 /* ---- scope row n4 (input pipeline): decoded 8-bit image -> network input planes -------------------------------------
  * datasets/general_eval.py:83-88 (read_img: / 255.), :94-117 and :160-166 (cv2.resize, INTER_LINEAR), :189 (HWC -> CHW);
  * datasets/tank.py:101-107.  img_hwc: [src_h][src_w][channels] uint8 (channels 1 or 3); out_chw: [channels][dst_h][dst_w]

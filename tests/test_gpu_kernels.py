@@ -249,6 +249,44 @@ def test_costregnet_and_cost_up_small(model, O):
     assert pinned(o2, g["conv2"]) and pinned(o1, g["conv1"])
 
 
+@pytest.mark.parametrize("dims", [(8, 36, 48), (8, 74, 100), (5, 20, 24)])
+def test_cost_up_small_pair_equals_two_single_runs(dims):
+    """CSP_R / CSP_C of a stage with every layer of the two blocks in one launch (effi_*_pair_f32) give the bits of the two
+    separate runs, and so does the paired lookup."""
+    import contextlib
+    import io
+    from effi_mvs_plus_amd import ops
+    from effi_mvs_plus_amd.models.module import cost_up_small
+    D, h, w = dims
+    g = torch.Generator().manual_seed(D * 100 + h)
+    blocks = []
+    for seed in (3, 4):
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = cost_up_small(in_channels=1, base_channels=8).eval()
+        m.load_state_dict(synth.randomize_state_dict(m.state_dict(), seed=seed))
+        blocks.append(m.to(DEV))
+    a, b = blocks
+    x = torch.randn(1, D, 2 * h, 2 * w, generator=g).to(DEV)
+    pa, pb = torch.randn(1, D, h, w, generator=g).to(DEV), torch.randn(1, D, h, w, generator=g).to(DEV)
+    before = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        assert cost_up_small.pairable(a, b, x, w) == (w % 4 == 0)
+        if w % 4 == 0:
+            (oa, ca), (ob, cb) = cost_up_small.run_pair(a, b, x, pa, pb)
+            ra, rb = a.run(x, pa), b.run(x, pb)
+            assert torch.equal(oa, ra[0]) and torch.equal(ca, ra[1]) and torch.equal(ob, rb[0]) and torch.equal(cb, rb[1])
+    finally:
+        ops.set_precision(before)
+    # paired lookup: same queries into two volumes
+    Dp = 11
+    va, vb = torch.rand(Dp, h, w, generator=g).to(DEV), torch.rand(Dp, h, w, generator=g).to(DEV)
+    q = (0.002 + 0.001 * torch.rand(D, 2 * h, 2 * w, generator=g)).to(DEV)
+    lo, hi = torch.tensor([1 / 0.0035]).to(DEV), torch.tensor([1 / 0.0015]).to(DEV)
+    la, lb = ops.vol_lookup1d_pair(va, vb, q, lo, hi, h, w)
+    assert torch.equal(la, ops.vol_lookup1d(va, q, lo, hi, h, w)) and torch.equal(lb, ops.vol_lookup1d(vb, q, lo, hi, h, w))
+
+
 def test_softmax_regress_conf(O):
     from effi_mvs_plus_amd import ops
     g = torch.Generator().manual_seed(9)
