@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
                     help="graph (default): the step copies its inputs into the static buffers of a captured hipGraph of the hot path "
                          "and replays it (one launch); eager: ~150 launches enqueued from Python (host-bound at this kernel speed)")
+    ap.add_argument("--pipelined", type=int, default=3,
+                    help="secondary measurement: throughput with this many independent views in flight (0/1 = skip)")
     ap.add_argument("--in-flight", type=int, default=1,
                     help="graph launch only: reference views in flight at once, each on its own stream and input slot (throughput "
                          "metric: while one view is in its low-resolution stages, which cannot fill 256 CUs, the other uses them); "
@@ -252,7 +254,8 @@ def main():
             "dtype": DTYPE[precision], "data": "synthetic",
             "config": {"workload": f"{args.workload}: DTU-shaped {W}x{H}, N={N} views (S={N - 1} sources), 3-stage cascade "
                                    f"ndepths={nd}, GRU iters 3,3,3, seeded-random weights, features of the stock FPN resident in HBM",
-                       "launch": ("hipGraph replay of the captured hot path (two streams) on double-buffered static input slots that hold the "
+                       "launch": ("hipGraph replay of the captured hot path (" + ("two streams" if ops.get_branches() else "one stream, linear graph")
+                                  + ") on double-buffered static input slots that hold the "
                                   f"synthetic views; each step replays one slot and clones the outputs it keeps, inside the timed region; "
                                   f"{max(1, args.in_flight)} independent view(s) in flight, one stream each"
                                   if graphed is not None else "eager: every kernel enqueued from Python"),
@@ -299,6 +302,49 @@ def main():
                                      "final_depth_diff_between_modes": {"mean_norm": float(diff.mean()),
                                                                         "p99_norm": float(diff.flatten().kthvalue(int(0.99 * diff.numel())).values),
                                                                         "max_norm": float(diff.max())}}
+
+    # ---- secondary (rank 0, N = 1): throughput with several independent views in flight (their graphs on separate streams, the
+    # second stream inside each graph enabled): bubbles of one view are filled by kernels of the others.  Not the headline: a
+    # view's latency rises to ~in_flight x ms_per_view.
+    if rank == 0 and world == 1 and graphed is not None and args.pipelined > 1 and not args.no_whole_forward:
+        from effi_mvs_plus_amd.graph import HotPathGraph
+        br0 = ops.get_branches()
+        ops.set_branches(True)
+        try:
+            pg = HotPathGraph(net, *inputs[0], slots=args.pipelined)
+            for i in range(args.pipelined):
+                pg.load(i, *inputs[i % n_scenes])
+            plan = [torch.cuda.Stream() for _ in range(args.pipelined)]
+            nst = max(args.steps, 3 * args.pipelined)
+
+            def run_pipelined(n):
+                cur = torch.cuda.current_stream()
+                for st_ in plan:
+                    st_.wait_stream(cur)
+                keep = []
+                for i in range(n):
+                    with torch.cuda.stream(plan[i % len(plan)]):
+                        o = pg.replay(i % args.pipelined)
+                        keep.append((o["depth"][-1].clone(), o["photometric_confidence"].clone()))
+                for st_ in plan:
+                    cur.wait_stream(st_)
+                return keep
+
+            with torch.no_grad():
+                run_pipelined(args.pipelined)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                run_pipelined(nst)
+                torch.cuda.synchronize()
+                tp = (time.perf_counter() - t0) / nst
+            result["pipelined"] = {"views_in_flight": args.pipelined, "value": 1.0 / tp, "unit": "views/s", "ms_per_view": tp * 1e3,
+                                   "steps": nst, "note": "one captured graph (two streams) per input slot, replayed on "
+                                                         f"{args.pipelined} streams round-robin; outputs cloned per step as in the headline run"}
+            del pg
+        except Exception as exc:
+            result["pipelined"] = {"error": f"{type(exc).__name__}: {exc}"}
+        ops.set_branches(br0)
+        torch.cuda.empty_cache()
 
     # ---- secondary (rank 0, N = 1, outside the timed region): the whole forward as the reference's drivers time it
     # (test_dtu_dypcd.py:437-442: images -> 13 depth maps), with the feature pyramid on the HIP kernels (scope row n1)

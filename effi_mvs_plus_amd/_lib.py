@@ -33,7 +33,7 @@ SIGNATURES = {
     "effi_conv3d_k3s2_mfma_f32": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "effi_conv3d_k3s1_mfma_f32": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "effi_deconv3d_k3_f32": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
-    "effi_softmax_regress_conf_f32": [_vp, _vp, _l, _l, _i, _i, _vp, _vp, _vp],
+    "effi_softmax_regress_conf_f32": [_vp, _vp, _l, _l, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "effi_vol_lookup1d_f32": [_vp, _l, _l, _i, _vp, _l, _l, _l, _i, _vp, _vp, _l, _i, _i, _vp, _vp],
     "effi_getcost_conv1x1_f32": [_vp, _vp, _i, _i, _vp, _vp, _l, _l, _i, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _i,
                                  _i, _vp, _vp],
@@ -54,7 +54,9 @@ SIGNATURES = {
     "effi_conv2d_k3_bf16x3_f32": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "effi_conv2d_k5s2_f32": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "effi_conv2d_c1k7_relu_f32": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
-    "effi_convex_upsample2x_f32": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "effi_convex_upsample2x_f32": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "effi_compose_rel_proj_stages_f32": [_vp, _i, _i, _vp, _vp],
+    "effi_split_tanh_relu_stages_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "effi_split_tanh_relu_f32": [_vp, _i, _i, _i, _vp, _vp, _vp],
     "effi_depth_to_inv_f32": [_vp, _vp, _i, _i, _vp, _vp],
     "effi_stage1_hypotheses_f32": [_vp, _i, _i, _vp, _vp, _vp],

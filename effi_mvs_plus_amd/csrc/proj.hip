@@ -77,6 +77,22 @@ __global__ void compose_rel_proj_kernel(const float* __restrict__ pairs, int n_v
     write_rt(S, Rinv, rt + v * 12);
 }
 
+// all stages of the cascade in one launch: blockIdx.x = stage
+struct PairList { const float* p[4]; };
+__global__ void compose_rel_proj_stages_kernel(PairList pl, int n_views, float* __restrict__ rt_all) {
+    const int v = threadIdx.x;
+    if (v >= n_views - 1) return;
+    const float* pairs = pl.p[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+        if ((int)blockIdx.x == j) pairs = pl.p[j];
+    double R[4][4], Rinv[4][4], S[4][4];
+    compose_k_rt(pairs, R);
+    invert4x4(R, Rinv);
+    compose_k_rt(pairs + (long)(v + 1) * 32, S);
+    write_rt(S, Rinv, rt_all + ((long)blockIdx.x * (n_views - 1) + v) * 12);
+}
+
 __global__ void rel_proj_kernel(const float* __restrict__ src, const float* __restrict__ ref, float* __restrict__ rt) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     double R[4][4], Rinv[4][4], S[4][4];
@@ -91,6 +107,19 @@ __global__ void rel_proj_kernel(const float* __restrict__ src, const float* __re
 extern "C" int effi_compose_rel_proj_f32(const float* pairs, int n_views, float* rt_out, effi_stream_t stream) {
     if (!pairs || !rt_out || n_views < 2 || n_views > EFFI_MAX_VIEWS + 1) return EFFI_ERR_BADARG;
     hipLaunchKernelGGL(compose_rel_proj_kernel, dim3(1), dim3(64), 0, effi_s(stream), pairs, n_views, rt_out);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_compose_rel_proj_stages_f32(const float* const* pairs, int n_stages, int n_views, float* rt_out,
+                                                effi_stream_t stream) {
+    if (!pairs || !rt_out || n_stages < 1 || n_stages > 4 || n_views < 2 || n_views > EFFI_MAX_VIEWS + 1) return EFFI_ERR_BADARG;
+    PairList pl;
+    for (int k = 0; k < 4; ++k) {
+        pl.p[k] = pairs[k < n_stages ? k : 0];
+        if (!pl.p[k]) return EFFI_ERR_BADARG;
+    }
+    hipLaunchKernelGGL(compose_rel_proj_stages_kernel, dim3(n_stages), dim3(64), 0, effi_s(stream), pl, n_views, rt_out);
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
 }

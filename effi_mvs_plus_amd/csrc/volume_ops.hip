@@ -3,6 +3,7 @@
 // All are HBM-bound streaming kernels: one thread per pixel, lanes along x (coalesced), 256-thread
 // blocks.  Compiled with -ffp-contract=off so that the element-wise formulas round exactly like the
 // reference's separate torch ops; fused multiply-adds are written explicitly where wanted.
+#include <cstdint>
 #include "common.hpp"
 
 namespace {
@@ -39,6 +40,55 @@ __global__ void split_tanh_relu_kernel(const float* __restrict__ ctx, int hd, in
         const float v = ctx[i];
         if (i < (long)hd * hw) hidden[i] = tanhf(v);
         else inp[i - (long)hd * hw] = fmaxf(v, 0.0f);
+    }
+}
+
+// hw % 4 == 0: four values per thread (float4 loads / stores; a quad never straddles the hidden / input boundary)
+__global__ __launch_bounds__(TPB) void split_tanh_relu4_kernel(const float4* __restrict__ ctx, long nh4, long n4, float4* __restrict__ hidden,
+                                                               float4* __restrict__ inp) {
+    const long i = (long)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = ctx[i];
+    if (i < nh4) hidden[i] = make_float4(tanhf(v.x), tanhf(v.y), tanhf(v.z), tanhf(v.w));
+    else inp[i - nh4] = make_float4(fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f), fmaxf(v.z, 0.0f), fmaxf(v.w, 0.0f));
+}
+
+// depth_to_disp(depth, depth_min_, depth_max_) (models/Effi_MVS_plus.py:151-164) with the global range of the hypotheses
+__device__ __forceinline__ float effi_depth_to_inv(float depth, float lo, float hi) {
+    const float max_depth = 1.0f / lo, min_depth = 1.0f / hi;
+    const float min_disp = 1.0f / max_depth, max_disp = 1.0f / min_depth;
+    const float den = (max_disp - min_disp) + 1e-10f;
+    const float s_ = 1.0f / depth;
+    return (s_ - min_disp) / den;
+}
+
+// the same for up to 4 context maps (all stages of the cascade) in ONE launch: blocks [first[k], first[k+1]) work on map k
+struct SplitStages {
+    const float* ctx[4];
+    float* hidden[4];
+    float* inp[4];
+    long nh[4], n[4];          // elements of the hidden part / of the whole map
+    int first[5];              // first block of each map
+};
+__global__ __launch_bounds__(TPB) void split_tanh_relu_stages_kernel(SplitStages a) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) k += ((int)blockIdx.x >= a.first[j]) ? 1 : 0;
+    const float* __restrict__ ctx = a.ctx[0];
+    float* __restrict__ hidden = a.hidden[0];
+    float* __restrict__ inp = a.inp[0];
+    long nh = a.nh[0], n = a.n[0];
+    int b0 = a.first[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+        if (k == j) { ctx = a.ctx[j]; hidden = a.hidden[j]; inp = a.inp[j]; nh = a.nh[j]; n = a.n[j]; b0 = a.first[j]; }
+    const long i = 4 * ((long)(blockIdx.x - b0) * TPB + threadIdx.x);          // 4 consecutive values per thread
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (i + e >= n) break;
+        const float v = ctx[i + e];
+        if (i + e < nh) hidden[i + e] = tanhf(v);
+        else inp[i + e - nh] = fmaxf(v, 0.0f);
     }
 }
 
@@ -117,7 +167,8 @@ __global__ void view_aggregate_kernel(const float* __restrict__ sim_views, const
 // ------------------------------------------------------------------------------------------------
 __global__ void softmax_regress_conf_kernel(const float* __restrict__ logits, const float* __restrict__ depth,
                                             long dds, long dps, int D, int hw,
-                                            float* __restrict__ out_depth, float* __restrict__ out_conf) {
+                                            float* __restrict__ out_depth, float* __restrict__ out_conf,
+                                            const float* __restrict__ disp_range, int n_range, float* __restrict__ out_dinv) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;     // launched with 64-thread blocks
     if (p >= hw) return;
     float m = -INFINITY;
@@ -139,6 +190,7 @@ __global__ void softmax_regress_conf_kernel(const float* __restrict__ logits, co
     }
     out_depth[p] = dep;
     out_conf[p] = 4.0f * (s4 / 4.0f);
+    if (out_dinv) out_dinv[p] = effi_depth_to_inv(dep, disp_range[0], disp_range[n_range - 1]);   // models/Effi_MVS_plus.py:538
 }
 
 // Same arithmetic, same order, for the depth counts the cascade uses: the D logits of a pixel are loaded ONCE into registers
@@ -147,7 +199,8 @@ __global__ void softmax_regress_conf_kernel(const float* __restrict__ logits, co
 template <int DT>
 __global__ __launch_bounds__(64) void softmax_regress_conf_reg_kernel(const float* __restrict__ logits, const float* __restrict__ depth,
                                                                       long dds, long dps, int hw, float* __restrict__ out_depth,
-                                                                      float* __restrict__ out_conf) {
+                                                                      float* __restrict__ out_conf, const float* __restrict__ disp_range,
+                                                                      int n_range, float* __restrict__ out_dinv) {
     const int p = blockIdx.x * 64 + threadIdx.x;
     if (p >= hw) return;
     float e[DT], dv[DT];
@@ -181,6 +234,7 @@ __global__ __launch_bounds__(64) void softmax_regress_conf_reg_kernel(const floa
     }
     out_depth[p] = dep;
     out_conf[p] = 4.0f * (s4 / 4.0f);
+    if (out_dinv) out_dinv[p] = effi_depth_to_inv(dep, disp_range[0], disp_range[n_range - 1]);   // models/Effi_MVS_plus.py:538
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -330,7 +384,8 @@ __global__ __launch_bounds__(TPB) void encoder_inputs_kernel(const GetcostConvAr
 // ------------------------------------------------------------------------------------------------
 __global__ void convex_upsample2x_kernel(const float* __restrict__ inv, const float* __restrict__ mask,
                                          const float* __restrict__ disp_range, int n_range, int h, int w,
-                                         float* __restrict__ out_inv, float* __restrict__ out_depth) {
+                                         float* __restrict__ out_inv, float* __restrict__ out_depth,
+                                         float* __restrict__ out_dinv) {
     const int p = blockIdx.x * TPB + threadIdx.x;
     if (p >= h * w) return;
     const int y = p / w, x = p - y * w;
@@ -363,7 +418,11 @@ __global__ void convex_upsample2x_kernel(const float* __restrict__ inv, const fl
         for (int k = 0; k < 9; ++k) acc = acc + (mv[k] / sum) * nb[k];
         const long o = (long)(2 * y + (r >> 1)) * W2 + 2 * x + (r & 1);
         if (out_inv) out_inv[o] = acc;
-        if (out_depth) out_depth[o] = effi_inv_to_depth(acc, lo, hi);
+        if (out_depth) {
+            const float dep = effi_inv_to_depth(acc, lo, hi);
+            out_depth[o] = dep;
+            if (out_dinv) out_dinv[o] = effi_depth_to_inv(dep, lo, hi);     // what the next stage starts from (:538)
+        }
     }
 }
 
@@ -390,8 +449,34 @@ extern "C" int effi_split_tanh_relu_f32(const float* ctx, int hd, int cd, int hw
                                         effi_stream_t stream) {
     if (!ctx || !hidden || !inp || hd < 1 || cd < 1 || hw < 1) return EFFI_ERR_BADARG;
     const long n = (long)(hd + cd) * hw;
-    hipLaunchKernelGGL(split_tanh_relu_kernel, dim3(min(effi_cdiv(n, TPB), 4096)), dim3(TPB), 0, effi_s(stream),
-                       ctx, hd, cd, hw, hidden, inp);
+    if ((hw & 3) == 0 && ((reinterpret_cast<uintptr_t>(ctx) | reinterpret_cast<uintptr_t>(hidden) | reinterpret_cast<uintptr_t>(inp)) & 15) == 0)
+        hipLaunchKernelGGL(split_tanh_relu4_kernel, dim3(effi_cdiv(n / 4, TPB)), dim3(TPB), 0, effi_s(stream),
+                           reinterpret_cast<const float4*>(ctx), (long)hd * hw / 4, n / 4, reinterpret_cast<float4*>(hidden),
+                           reinterpret_cast<float4*>(inp));
+    else
+        hipLaunchKernelGGL(split_tanh_relu_kernel, dim3(min(effi_cdiv(n, TPB), 4096)), dim3(TPB), 0, effi_s(stream),
+                           ctx, hd, cd, hw, hidden, inp);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_split_tanh_relu_stages_f32(const float* const* ctx, const int* hd, const int* cd, const int* hw,
+                                               float* const* hidden, float* const* inp, int n_stages, effi_stream_t stream) {
+    if (!ctx || !hd || !cd || !hw || !hidden || !inp || n_stages < 1 || n_stages > 4) return EFFI_ERR_BADARG;
+    SplitStages a;
+    int blocks = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int j = k < n_stages ? k : 0;
+        if (!ctx[j] || !hidden[j] || !inp[j] || hd[j] < 1 || cd[j] < 1 || hw[j] < 1) return EFFI_ERR_BADARG;
+        a.ctx[k] = ctx[j]; a.hidden[k] = hidden[j]; a.inp[k] = inp[j];
+        a.nh[k] = (long)hd[j] * hw[j];
+        a.n[k] = (long)(hd[j] + cd[j]) * hw[j];
+        a.first[k] = blocks;
+        if (k < n_stages) blocks += effi_cdiv(a.n[k], 4L * TPB);
+    }
+    for (int k = n_stages; k < 4; ++k) a.first[k] = blocks;      // unused maps own no blocks
+    a.first[4] = blocks;
+    hipLaunchKernelGGL(split_tanh_relu_stages_kernel, dim3(blocks), dim3(TPB), 0, effi_s(stream), a);
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
 }
@@ -434,11 +519,15 @@ extern "C" int effi_view_aggregate_f32(const float* sim_views, const float* weig
 }
 
 extern "C" int effi_softmax_regress_conf_f32(const float* logits, const float* depth, long dds, long dps, int D,
-                                             int hw, float* out_depth, float* out_conf, effi_stream_t stream) {
+                                             int hw, float* out_depth, float* out_conf, const float* disp_range, int n_range,
+                                             float* out_depth_inv, effi_stream_t stream) {
     if (!logits || !depth || !out_depth || !out_conf || D < 1 || hw < 1) return EFFI_ERR_BADARG;
+    if (out_depth_inv && (!disp_range || n_range < 2)) return EFFI_ERR_BADARG;
     const dim3 grid(effi_cdiv(hw, 64));
     hipStream_t st = effi_s(stream);
-#define EFFI_SM(DT) hipLaunchKernelGGL(softmax_regress_conf_reg_kernel<DT>, grid, dim3(64), 0, st, logits, depth, dds, dps, hw, out_depth, out_conf)
+#define EFFI_SM(DT)                                                                                                      \
+    hipLaunchKernelGGL(softmax_regress_conf_reg_kernel<DT>, grid, dim3(64), 0, st, logits, depth, dds, dps, hw, out_depth, \
+                       out_conf, disp_range, n_range, out_depth_inv)
     switch (D) {
         case 8: EFFI_SM(8); break;
         case 16: EFFI_SM(16); break;
@@ -447,7 +536,8 @@ extern "C" int effi_softmax_regress_conf_f32(const float* logits, const float* d
         case 64: EFFI_SM(64); break;
         case 96: EFFI_SM(96); break;
         default:
-            hipLaunchKernelGGL(softmax_regress_conf_kernel, grid, dim3(64), 0, st, logits, depth, dds, dps, D, hw, out_depth, out_conf);
+            hipLaunchKernelGGL(softmax_regress_conf_kernel, grid, dim3(64), 0, st, logits, depth, dds, dps, D, hw, out_depth, out_conf,
+                               disp_range, n_range, out_depth_inv);
     }
 #undef EFFI_SM
     EFFI_LAUNCH_CHECK();
@@ -542,11 +632,12 @@ extern "C" int effi_encoder_inputs_f32(const float* inv_depth, const float* disp
 
 extern "C" int effi_convex_upsample2x_f32(const float* inv_depth, const float* mask, const float* disp_range,
                                           int n_range, int h, int w, float* out_inv, float* out_depth,
-                                          effi_stream_t stream) {
+                                          float* out_depth_inv, effi_stream_t stream) {
     if (!inv_depth || !mask || (!out_inv && !out_depth) || h < 1 || w < 1) return EFFI_ERR_BADARG;
     if (out_depth && (!disp_range || n_range < 2)) return EFFI_ERR_BADARG;
+    if (out_depth_inv && !out_depth) return EFFI_ERR_BADARG;
     hipLaunchKernelGGL(convex_upsample2x_kernel, dim3(effi_cdiv((long)h * w, TPB)), dim3(TPB), 0, effi_s(stream),
-                       inv_depth, mask, disp_range, n_range, h, w, out_inv, out_depth);
+                       inv_depth, mask, disp_range, n_range, h, w, out_inv, out_depth, out_depth_inv);
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
 }

@@ -273,23 +273,33 @@ class Effi_MVS_plus(nn.Module):
         weights = reg_vol = cur_vol = None
         lo_prev, hi_prev = g_min, g_max          # depth range the PREVIOUS stage's volumes are sampled on
 
-        def geometry(s):     # per-stage inputs that depend on nothing but the features / cameras
-            key = "stage{}".format(s + 1)
-            maps = [f[key] for f in feats]
-            return ops.to_nhwc(maps), ops.compose_rel_proj(pairs[key]), maps[0].shape
+        keys = ["stage{}".format(s + 1) for s in range(self.num_stage)]
+        # per-stage inputs that depend on nothing but the features / cameras / context pyramid: relative projections of all
+        # stages in one launch, tanh / relu halves of all context maps (hidden state and context input of the update blocks)
+        # in one launch
+        if self.num_stage <= 4:
+            rts = ops.compose_rel_proj_stages([pairs[k].contiguous() for k in keys])
+        else:
+            rts = [ops.compose_rel_proj(pairs[k]) for k in keys]
 
-        def states(s):       # hidden state / context input of the update block: tanh / relu halves of the context pyramid
-            return ops.split_tanh_relu(ctx["stage{}".format(s + 1)].contiguous(), self.hdim_stage[s], self.cdim_stage[s])
+        def geometry(s):
+            maps = [f[keys[s]] for f in feats]
+            return ops.to_nhwc(maps), rts[s], maps[0].shape
+
+        def all_states():
+            cs = [ctx[k].contiguous() for k in keys]
+            if self.num_stage <= 4:
+                return dict(enumerate(ops.split_tanh_relu_stages(cs, self.hdim_stage[:self.num_stage], self.cdim_stage[:self.num_stage])))
+            return {s: ops.split_tanh_relu(cs[s], self.hdim_stage[s], self.cdim_stage[s]) for s in range(self.num_stage)}
 
         geo = {0: geometry(0)}
-        st = {}
-        with ops.Branch() as prep_branch:        # what the stage-1 cost volume does not need: side stream, beside it
-            st[0] = states(0)
+        with ops.Branch() as prep_branch:        # what the stage-1 cost volume does not need (side stream when branches are on)
+            st = all_states()
             for s in range(1, self.num_stage):
                 geo[s] = geometry(s)
-                st[s] = states(s)
         prep_joined = False
         tail_branch = None
+        inv_next = None                          # normalised inverse depth the next update block starts from
         for s in range(self.num_stage):
             nhwc, rt, (_, h, w) = geo[s]
             if s == 0:
@@ -297,7 +307,7 @@ class Effi_MVS_plus(nn.Module):
                 weights = self.PixelwiseNet.run(entropy)
                 cur_vol = ops.view_aggregate(sim_views, weights)
                 reg_vol = self.cost_regularization.run(cur_vol.unsqueeze(0))[0][0]
-                depth, c = ops.softmax_regress_conf(reg_vol, hyp)
+                depth, c, inv_next = ops.softmax_regress_conf(reg_vol, hyp, disp_range)     # + depth_to_inv of it (:538)
                 with ops.Branch() as tail_branch:      # the confidence map is only an output: off the critical path
                     conf = ops.upsample_nearest(c.unsqueeze(0), 4)[0]
                 preds.append(depth)
@@ -330,7 +340,7 @@ class Effi_MVS_plus(nn.Module):
                 prep_branch.join(*[t_ for k in st for t_ in st[k]], *[t_ for k in range(1, self.num_stage) for t_ in (list(geo[k][0]) + [geo[k][1]])])
                 prep_joined = True
             hidden, inp = st[s]
-            inv_cur = ops.depth_to_inv(preds[-1], disp_range).unsqueeze(0)
+            inv_cur = (inv_next if inv_next is not None else ops.depth_to_inv(preds[-1], disp_range)).unsqueeze(0)
             cur_c, reg_c, lo_c, hi_c, itv = cur_vol, reg_vol, lo_cur, hi_cur, misc[s:s + 1]
 
             def lookup(inv_depth, out=None, cur_c=cur_c, reg_c=reg_c, lo_c=lo_c, hi_c=hi_c, itv=itv, h=h, w=w):
@@ -351,7 +361,8 @@ class Effi_MVS_plus(nn.Module):
             _, masks, invs, depths = self.update_block[s].run_fused(hidden, lookup, inv_cur, inp, self.seq_len[s],
                                                                      disp_range)
             preds.extend(d[0] for d in depths)
-            preds.append(ops.convex_upsample2x(invs[-1], masks[-1], disp_range, want_inv=False)[1])
+            _, up_depth, inv_next = ops.convex_upsample2x(invs[-1], masks[-1], disp_range, want_inv=False, want_depth_inv=True)
+            preds.append(up_depth)
             lo_prev, hi_prev = lo_cur, hi_cur
         if tail_branch is not None:
             tail_branch.join(conf)

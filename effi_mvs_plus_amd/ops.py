@@ -98,10 +98,14 @@ def _p(x):
     return C.c_void_p(x.data_ptr()) if x is not None else C.c_void_p(0)
 
 
-# Independent kernel chains (the two encoder branches of the update block, the two cross-scale blocks, the mask head) are
-# enqueued on a second HIP stream so that layers which do not fill the 256 CUs on their own overlap.  Results are identical
-# (no atomics; every kernel still sees its producers through stream events).  EFFI_MVS_BRANCHES=0 keeps one stream.
-_BRANCHES = os.environ.get("EFFI_MVS_BRANCHES", "1") != "0"
+# Independent kernel chains (the mask head, the preparation of the stages' GRU inputs, the pyramid passes of the odd views) CAN
+# be enqueued on a second HIP stream (``Branch``).  Off by default: inside a captured graph every cross-stream edge costs ~5 us
+# (fork) / ~11 us (join) of idle GPU, and a graph with ANY such edge replays ~3 % slower than the linear graph of the same
+# kernels (measured at 1600x1184: 2.64 -> 2.57 ms; at 800x576: 1.40 -> 1.31 ms) -- the chains that do overlap well share ONE
+# grid instead (effi_encoder_inputs_f32, effi_*_pair_f32).  A second stream pays off when several views are in flight at once
+# (bench.py --in-flight 3: 2.31 ms per view with branches, 2.43 without).  EFFI_MVS_BRANCHES=1 / set_branches(True) turn it on;
+# results are identical either way (no atomics; every kernel sees its producers through stream events).
+_BRANCHES = os.environ.get("EFFI_MVS_BRANCHES", "0") != "0"
 _SIDE_STREAMS = {}
 
 
@@ -175,6 +179,19 @@ def compose_rel_proj(pairs: torch.Tensor) -> torch.Tensor:
     rt = torch.empty(n - 1, 12, device=pairs.device, dtype=torch.float32)
     check(_lib.lib().effi_compose_rel_proj_f32(_p(pairs), n, _p(rt), _stream()), "effi_compose_rel_proj_f32")
     return rt
+
+
+def compose_rel_proj_stages(pairs_list):
+    """``compose_rel_proj`` of up to 4 stages' [N,2,4,4] tensors in one launch -> list of rt [N-1,12] (views of one buffer)."""
+    for p_ in pairs_list:
+        _t(p_, "pairs")
+    n = pairs_list[0].shape[0]
+    if len(pairs_list) > 4 or any(p_.shape[0] != n for p_ in pairs_list):
+        raise ValueError("compose_rel_proj_stages: up to 4 stages with the same number of views")
+    rt = torch.empty(len(pairs_list), n - 1, 12, device=pairs_list[0].device, dtype=torch.float32)
+    check(_lib.lib().effi_compose_rel_proj_stages_f32(_ptr_array(pairs_list), len(pairs_list), n, _p(rt), _stream()),
+          "effi_compose_rel_proj_stages_f32")
+    return [rt[k] for k in range(len(pairs_list))]
 
 
 def rel_proj(src_proj: torch.Tensor, ref_proj: torch.Tensor) -> torch.Tensor:
@@ -454,16 +471,21 @@ def resize_planar(x, dst_h, dst_w, out=None):
     return out
 
 
-def softmax_regress_conf(logits, depth):
-    """logits [D,h,w]; depth [D] / [D,h,w] -> (depth [h,w], confidence [h,w])."""
+def softmax_regress_conf(logits, depth, disp_range=None):
+    """logits [D,h,w]; depth [D] / [D,h,w] -> (depth [h,w], confidence [h,w]) and, with ``disp_range``, also the regressed
+    depth as normalised inverse depth (``depth_to_inv`` of it, written by the same kernel)."""
     D, h, w = logits.shape
     _t(logits, "logits"), _t(depth, "depth", contiguous=False)
     depth, dds, dps = _depth_strides(depth, D, h, w)
     od = torch.empty(h, w, device=logits.device, dtype=torch.float32)
     oc = torch.empty(h, w, device=logits.device, dtype=torch.float32)
-    check(_lib.lib().effi_softmax_regress_conf_f32(_p(logits), _p(depth), dds, dps, D, h * w, _p(od), _p(oc), _stream()),
-          "effi_softmax_regress_conf_f32")
-    return od, oc
+    oi, n_range = None, 0
+    if disp_range is not None:
+        _t(disp_range, "disp_range")
+        oi, n_range = torch.empty(h, w, device=logits.device, dtype=torch.float32), disp_range.numel()
+    check(_lib.lib().effi_softmax_regress_conf_f32(_p(logits), _p(depth), dds, dps, D, h * w, _p(od), _p(oc), _p(disp_range), n_range,
+                                                    _p(oi), _stream()), "effi_softmax_regress_conf_f32")
+    return (od, oc) if disp_range is None else (od, oc, oi)
 
 
 def _vol_strides(vol, h, w):
@@ -767,8 +789,9 @@ def conv2d_c1k7_relu(x, weight, bias, cout, out=None):
     return out
 
 
-def convex_upsample2x(inv_depth, mask, disp_range=None, want_inv=True):
-    """-> (inv [2h,2w] or None, depth [2h,2w] or None); depth needs ``disp_range``."""
+def convex_upsample2x(inv_depth, mask, disp_range=None, want_inv=True, want_depth_inv=False):
+    """-> (inv [2h,2w] or None, depth [2h,2w] or None); depth needs ``disp_range``.  ``want_depth_inv``: a third result,
+    ``depth_to_inv(depth)`` (what the next stage starts from), written by the same kernel."""
     _t(inv_depth, "inv_depth"), _t(mask, "mask")
     h, w = inv_depth.shape[-2:]
     if mask.shape[0] != 36:
@@ -780,9 +803,10 @@ def convex_upsample2x(inv_depth, mask, disp_range=None, want_inv=True):
         _t(disp_range, "disp_range")
         n_range = disp_range.numel()
         out_depth = torch.empty(2 * h, 2 * w, device=mask.device, dtype=torch.float32)
+    out_dinv = torch.empty(2 * h, 2 * w, device=mask.device, dtype=torch.float32) if (want_depth_inv and out_depth is not None) else None
     check(_lib.lib().effi_convex_upsample2x_f32(_p(inv_depth), _p(mask), _p(disp_range), n_range, h, w,
-                                                 _p(out_inv), _p(out_depth), _stream()), "effi_convex_upsample2x_f32")
-    return out_inv, out_depth
+                                                 _p(out_inv), _p(out_depth), _p(out_dinv), _stream()), "effi_convex_upsample2x_f32")
+    return (out_inv, out_depth, out_dinv) if want_depth_inv else (out_inv, out_depth)
 
 
 def split_tanh_relu(ctx, hd, cd):
@@ -793,6 +817,23 @@ def split_tanh_relu(ctx, hd, cd):
     check(_lib.lib().effi_split_tanh_relu_f32(_p(ctx), hd, cd, h * w, _p(hid), _p(inp), _stream()),
           "effi_split_tanh_relu_f32")
     return hid, inp
+
+
+def split_tanh_relu_stages(ctxs, hds, cds):
+    """``split_tanh_relu`` of up to 4 context maps (the stages of the cascade) in one launch -> [(hidden, inp), ...]."""
+    outs, hws = [], []
+    for c_, hd, cd in zip(ctxs, hds, cds):
+        _t(c_, "context")
+        _, h, w = c_.shape
+        hws.append(h * w)
+        outs.append((torch.empty(hd, h, w, device=c_.device, dtype=torch.float32),
+                     torch.empty(cd, h, w, device=c_.device, dtype=torch.float32)))
+    if len(ctxs) > 4:
+        raise ValueError("split_tanh_relu_stages: up to 4 stages")
+    check(_lib.lib().effi_split_tanh_relu_stages_f32(_ptr_array(ctxs), _int_array(list(hds)), _int_array(list(cds)), _int_array(hws),
+                                                      _ptr_array([o[0] for o in outs]), _ptr_array([o[1] for o in outs]), len(ctxs),
+                                                      _stream()), "effi_split_tanh_relu_stages_f32")
+    return outs
 
 
 def depth_to_inv(depth, disp_range):

@@ -55,6 +55,10 @@ const char* effi_error_string(int code);
 int effi_compose_rel_proj_f32(const float* pairs, int n_views, float* rt_out, effi_stream_t stream);
 /* Same for matrices that are already composed (the argument form of homo_warping_new,
  * models/module.py:303-316).  src_proj, ref_proj: [4][4]; rt_out: [12]. */
+/* effi_compose_rel_proj_f32 for all stages of the cascade in one launch: pairs = HOST array of n_stages (<= 4) device
+ * pointers, rt_out [n_stages][n_views-1][12]. */
+int effi_compose_rel_proj_stages_f32(const float* const* pairs, int n_stages, int n_views, float* rt_out,
+                                     effi_stream_t stream);
 int effi_rel_proj_f32(const float* src_proj, const float* ref_proj, float* rt_out, effi_stream_t stream);
 
 /* ---- layout: planar [C][HW] -> nhwc [HW][C] for n tensors (feature maps arrive NCHW from the FPN,
@@ -167,10 +171,12 @@ int effi_deconv3d_k3s2_bf16x3_f32(const float* in, int cin, const void* wpack_bf
 
 /* ---- K7: softmax over D, soft-argmin depth, 4-window confidence.
  * models/Effi_MVS_plus.py:79-88, models/module.py:518-524.
- * logits [D][hw]; depth hypotheses as in effi_homo_warp_f32; out_depth [hw]; out_conf [hw]. */
+ * logits [D][hw]; depth hypotheses as in effi_homo_warp_f32; out_depth [hw]; out_conf [hw].
+ * out_depth_inv (or NULL; then disp_range may be NULL): depth_to_disp(out_depth) on the global hypothesis range
+ * disp_range[0] .. disp_range[n_range-1] -- the normalised inverse depth the stage's update block starts from (:538). */
 int effi_softmax_regress_conf_f32(const float* logits, const float* depth, long depth_dstride,
                                   long depth_pstride, int D, int hw, float* out_depth, float* out_conf,
-                                  effi_stream_t stream);
+                                  const float* disp_range, int n_range, float* out_depth_inv, effi_stream_t stream);
 
 /* ---- K8: 1-D volume lookup (pro_bilinear_sampler), models/Effi_MVS_plus.py:102-134,151-164.
  * vol: value k of pixel p at vol[k*vol_dstride + p*vol_pstride], Dp entries per pixel, (h,w) pixels.
@@ -254,16 +260,20 @@ int effi_conv2d_c1k7_relu_f32(const float* in, const float* weight, const float*
 
 /* ---- K10: convex upsampling x2 (upsample_depth, models/Effi_MVS_plus.py:167-178) fused with
  * scale_inv_depth (:138-148).  inv_depth [h][w]; mask [36][h][w] (already scaled by 0.25);
- * out_inv [2h][2w] (or NULL); out_depth [2h][2w] (or NULL, then disp_range may be NULL too). */
+ * out_inv [2h][2w] (or NULL); out_depth [2h][2w] (or NULL, then disp_range may be NULL too);
+ * out_depth_inv [2h][2w] (or NULL; needs out_depth): depth_to_disp(out_depth), what the NEXT stage starts from (:538). */
 int effi_convex_upsample2x_f32(const float* inv_depth, const float* mask, const float* disp_range,
                                int n_range, int h, int w, float* out_inv, float* out_depth,
-                               effi_stream_t stream);
+                               float* out_depth_inv, effi_stream_t stream);
 
 /* ---- small fused element-wise steps of the stage loop --------------------------------------------
  * models/Effi_MVS_plus.py:445-450: hidden = tanh(ctx[:hd]), inp = relu(ctx[hd:hd+cd]); ctx [hd+cd][hw]. */
 int effi_split_tanh_relu_f32(const float* ctx, int hd, int cd, int hw, float* hidden, float* inp,
                              effi_stream_t stream);
 /* models/Effi_MVS_plus.py:538 (depth_to_disp with the global range): inv = (1/d - lo)/((hi-lo)+1e-10). */
+/* effi_split_tanh_relu_f32 for all stages of the cascade in one launch: HOST arrays of n_stages (<= 4) device pointers / sizes. */
+int effi_split_tanh_relu_stages_f32(const float* const* ctx, const int* hd, const int* cd, const int* hw,
+                                    float* const* hidden, float* const* inp, int n_stages, effi_stream_t stream);
 int effi_depth_to_inv_f32(const float* depth, const float* disp_range, int n_range, int n, float* inv,
                           effi_stream_t stream);
 /* models/Effi_MVS_plus.py:464-474: D uniform hypotheses in inverse depth between disp_range[0] and

@@ -591,6 +591,17 @@ def test_update_convs_at_tile_configs(O, h, w, hd, cd, precision):
     check_close(f"head depth hd={hd} {h}x{w}", depth, want_depth[0], rtol=1e-4, atol=2e-2)
 
 
+@pytest.mark.parametrize("h,w", [(16, 20), (9, 7), (148, 200)])
+def test_split_tanh_relu(h, w):
+    """tanh / relu halves of the context pyramid (models/Effi_MVS_plus.py:445-450): vectorised (h*w % 4 == 0) and scalar form."""
+    from effi_mvs_plus_amd import ops
+    g = torch.Generator().manual_seed(h)
+    ctx = torch.randn(20, h, w, generator=g) * 2
+    hid, inp = ops.split_tanh_relu(t(ctx, DEV), 16, 4)
+    check_close("tanh half", hid, torch.tanh(ctx[:16]), rtol=1e-5, atol=1e-6)
+    assert torch.equal(inp.cpu(), torch.relu(ctx[16:]))
+
+
 def test_cpu_tensor_fails_loudly():
     from effi_mvs_plus_amd import ops
     from effi_mvs_plus_amd._lib import EffiLibraryError
