@@ -53,7 +53,7 @@ def main():
                     help="arithmetic of the 3x3 MFMA convolutions (default: the library default, EFFI_MVS_PRECISION or 'split')")
     ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
                     help="graph (default): the step copies its inputs into the static buffers of a captured hipGraph of the hot path "
-                         "and replays it (one launch); eager: ~150 launches enqueued from Python (host-bound at this kernel speed)")
+                         "and replays it (one launch); eager: ~100 launches enqueued from Python (about as long on the host as on the GPU)")
     ap.add_argument("--pipelined", type=int, default=3,
                     help="secondary measurement: throughput with this many independent views in flight (0/1 = skip)")
     ap.add_argument("--in-flight", type=int, default=1,
@@ -296,7 +296,7 @@ def main():
                 dt_eager = time.perf_counter() - t0
                 ops.set_profile(None)
             result["eager_launch"] = {"value": args.steps / dt_eager, "unit": "views/s", "ms_per_step": dt_eager / args.steps * 1e3,
-                                      "note": "same kernels enqueued from Python (~150 launches on two streams per view): host-bound"}
+                                      "note": "same kernels enqueued from Python (~100 launches per view): the host needs about as long as the GPU"}
         result["other_precision"] = {"mode": other, "dtype": DTYPE[other], "launch": "eager", "value": args.steps / dt_other, "unit": "views/s",
                                      "ms_per_step": dt_other / args.steps * 1e3,
                                      "final_depth_diff_between_modes": {"mean_norm": float(diff.mean()),

@@ -29,6 +29,14 @@ def key_of(name):
         return f"conv2d_k3x3_pair_nt{m.group(1)}", 2.0
     if n.startswith("encoder_inputs_kernel"):
         return "encoder_inputs", 1.0
+    m = re.match(r"conv3d_roll_bf16x3_pair_kernel<(\d+)", n)
+    if m:
+        return f"conv3d_roll_pair_oct{m.group(1)}", 2.0
+    m = re.match(r"conv3d_k3_pair_kernel<(\d+), (\d+), (\d+)", n)
+    if m:
+        return f"conv3d_pair_c{m.group(1)}_s{m.group(2)}{m.group(3)}", 1.0
+    if n.startswith("deconv3d_k3_pair_kernel"):
+        return "deconv3d_pair_c1_s1", 1.0
     m = re.match(r"conv3d_roll_bf16x3_kernel<(\d+), (\d+)", n)
     if m:
         return f"conv3d_roll_oct{m.group(1)}_nt{m.group(2)}", 2.0
