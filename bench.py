@@ -435,6 +435,48 @@ def main():
                                                             "sample": "one image timed, scaled to N (numpy restatement of /255 + cv2.resize + transpose)"}
         del raws, planes
 
+    # ---- secondary (rank 0, N = 1): scope row n2, first piece -- forward + backward of the stage-1 warp + correlation
+    # (effi_mvs_plus_amd.autograd.warp_correlate) against torch autograd through the reference's grid_sample formulation
+    if rank == 0 and world == 1 and not args.no_whole_forward:
+        from effi_mvs_plus_amd import autograd as A
+        from oracle import effi_oracle as Ob
+        f0, c0, p0, d0 = inputs[0]
+        st1 = [fv["stage1"][0].contiguous() for fv in f0]
+        C1, h1, w1 = st1[0].shape
+        D1 = int(nd.split(",")[0])
+        pairs1 = p0["stage1"][0].contiguous()
+        hyp1, _ = ops.stage1_hypotheses(d0[0].contiguous(), D1)
+        gsim = torch.randn(N - 1, D1, h1, w1, device=dev)
+
+        def hip_fb():
+            leaves = [x.detach().requires_grad_(True) for x in st1]
+            sim = A.warp_correlate(leaves[0], leaves[1:], pairs1, hyp1)
+            sim.backward(gsim)
+            return leaves[0].grad
+
+        def torch_fb():
+            leaves = [x.detach().unsqueeze(0).requires_grad_(True) for x in st1]
+            P = [Ob.compose_projection(pairs1[v:v + 1]) for v in range(N)]
+            dvals = hyp1.view(1, D1)
+            sims = []
+            for v in range(1, N):
+                wv = Ob.homo_warping_new(leaves[v], P[v], P[0], dvals).view(1, C1, D1, h1, w1)
+                sims.append((wv * leaves[0].unsqueeze(2)).mean(1)[0])
+            torch.stack(sims).backward(gsim)
+            return leaves[0].grad[0]
+
+        try:
+            hip_ms = timed(hip_fb, n=10)
+            ref_ms = timed(torch_fb, n=3)
+            gd = (hip_fb() - torch_fb()).abs().max().item() / max(torch_fb().abs().max().item(), 1e-30)
+            result["warp_correlate_fwd_bwd"] = {"ms": hip_ms, "ms_torch_rocm_autograd": ref_ms, "speedup": ref_ms / hip_ms,
+                                                "grad_ref_max_diff_rel_to_peak": gd,
+                                                "note": f"stage-1 shape: C={C1}, {w1}x{h1}, D={D1}, {N - 1} source views; forward + backward "
+                                                        "to reference and source features"}
+        except Exception as exc:
+            result["warp_correlate_fwd_bwd"] = {"error": f"{type(exc).__name__}: {exc}"}
+        torch.cuda.empty_cache()
+
     # ---- baselines (rank 0, N = 1 only): bounded samples of the same workload ------------------------
     if rank == 0 and world == 1:
         from oracle import effi_oracle as O

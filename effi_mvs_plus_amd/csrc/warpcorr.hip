@@ -286,6 +286,62 @@ __global__ __launch_bounds__(256) void homo_warp_kernel(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Scope row n2 (first piece): backward of the stage-1 warp + correlation,  sim[v][d][p] = mean_c ref[p][c] * warp_v(src_v)[c][d][p]
+// (models/module.py:303-344 + models/Effi_MVS_plus.py:38-40; the sampling grid carries no gradient, module.py:313).
+//   grad_ref[p][c]       = sum_{v,d} g * sum_t w_t * src_v[tap_t][c]            (plain store: a lane group owns its pixel)
+//   grad_src_v[tap_t][c] += g * w_t * ref[p][c]                                  (scatter: fp32 atomic adds)
+// with g = grad_sim[v][d][p] / C.  Same lane layout as the forward kernel (C/4 lanes per pixel, 4 channels per lane), taps
+// recomputed from the projection, so nothing but grad_sim is read beyond the forward's inputs.
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void warpcorr_views_bwd_kernel(const float* __restrict__ ref, EffiPtrList srcs, int S,
+                                                                 const float* __restrict__ rt_all,
+                                                                 const float* __restrict__ depth, long dds, long dps,
+                                                                 int h, int w, int D, const float* __restrict__ grad_sim,
+                                                                 float* __restrict__ grad_ref, EffiOutList grad_srcs) {
+    int x, y, sub;
+    if (!tile_pixel<C>(blockIdx.x, gridDim.x, h, w, x, y, sub)) return;
+    const int hw = h * w, pix = y * w + x, sub4 = 4 * sub;
+    const float4 r4 = *reinterpret_cast<const float4*>(ref + (long)pix * C + sub4);
+    const float fx = (float)x, fy = (float)y;
+    const float* dp = depth + (long)pix * dps;
+    float4 gr = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int v = 0; v < S; ++v) {
+        const float* __restrict__ src = pick_view(srcs, v);
+        float* gs = grad_srcs.p[0];
+#pragma unroll
+        for (int i = 1; i <= EFFI_MAX_VIEWS; ++i)
+            if (v == i) gs = grad_srcs.p[i];
+        const float* __restrict__ rt = rt_all + v * 12;
+        const float rx = rt[0] * fx + rt[1] * fy + rt[2];
+        const float ry = rt[3] * fx + rt[4] * fy + rt[5];
+        const float rz = rt[6] * fx + rt[7] * fy + rt[8];
+        for (int d = 0; d < D; ++d) {
+            const float dep = dp[d * dds];
+            Taps t;
+            make_taps(rx * dep + rt[9], ry * dep + rt[10], rz * dep + rt[11], w, h, C, t);
+            const float g = grad_sim[((long)v * D + d) * hw + pix] / (float)C;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (t.w[k] == 0.0f) continue;                        // out-of-bounds taps carry no gradient
+                const float4 sv = *reinterpret_cast<const float4*>(src + t.off[k] + sub4);
+                const float gw = g * t.w[k];
+                gr.x = fmaf(gw, sv.x, gr.x);
+                gr.y = fmaf(gw, sv.y, gr.y);
+                gr.z = fmaf(gw, sv.z, gr.z);
+                gr.w = fmaf(gw, sv.w, gr.w);
+                float* o = gs + t.off[k] + sub4;
+                unsafeAtomicAdd(o + 0, gw * r4.x);
+                unsafeAtomicAdd(o + 1, gw * r4.y);
+                unsafeAtomicAdd(o + 2, gw * r4.z);
+                unsafeAtomicAdd(o + 3, gw * r4.w);
+            }
+        }
+    }
+    *reinterpret_cast<float4*>(grad_ref + (long)pix * C + sub4) = gr;
+}
+
 template <int C> int grid_blocks(int h, int w) {
     using G = WarpGeom<C>;
     return ((w + G::TW - 1) / G::TW) * ((h + G::TH - 1) / G::TH);
@@ -328,6 +384,28 @@ extern "C" int effi_warpcorr_views_f32(const float* ref_nhwc, const float* const
         case 32: hipLaunchKernelGGL(warpcorr_views_kernel<32>, dim3(grid_blocks<32>(h, w), S), dim3(256), 0, s, ref_nhwc, l, rt, depth, dds, dps, h, w, D, sim_views, entropy); break;
         case 16: hipLaunchKernelGGL(warpcorr_views_kernel<16>, dim3(grid_blocks<16>(h, w), S), dim3(256), 0, s, ref_nhwc, l, rt, depth, dds, dps, h, w, D, sim_views, entropy); break;
         case 8:  hipLaunchKernelGGL(warpcorr_views_kernel<8>, dim3(grid_blocks<8>(h, w), S), dim3(256), 0, s, ref_nhwc, l, rt, depth, dds, dps, h, w, D, sim_views, entropy); break;
+        default: return EFFI_ERR_UNSUPPORTED;
+    }
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_warpcorr_views_bwd_f32(const float* ref_nhwc, const float* const* src_nhwc, int S, const float* rt,
+                                           const float* depth, long dds, long dps, int C, int h, int w, int D,
+                                           const float* grad_sim, float* grad_ref_nhwc, float* const* grad_src_nhwc,
+                                           effi_stream_t stream) {
+    EffiPtrList l;
+    if (!fill_views(src_nhwc, S, l) || !ref_nhwc || !rt || !depth || !grad_sim || !grad_ref_nhwc || !grad_src_nhwc) return EFFI_ERR_BADARG;
+    if (h < 2 || w < 2 || D < 1) return EFFI_ERR_BADARG;
+    EffiOutList g;
+    for (int i = 0; i <= EFFI_MAX_VIEWS; ++i) g.p[i] = (i < S) ? grad_src_nhwc[i] : nullptr;
+    for (int i = 0; i < S; ++i)
+        if (!g.p[i]) return EFFI_ERR_BADARG;
+    hipStream_t s = effi_s(stream);
+    switch (C) {
+        case 32: hipLaunchKernelGGL(warpcorr_views_bwd_kernel<32>, dim3(grid_blocks<32>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, depth, dds, dps, h, w, D, grad_sim, grad_ref_nhwc, g); break;
+        case 16: hipLaunchKernelGGL(warpcorr_views_bwd_kernel<16>, dim3(grid_blocks<16>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, depth, dds, dps, h, w, D, grad_sim, grad_ref_nhwc, g); break;
+        case 8:  hipLaunchKernelGGL(warpcorr_views_bwd_kernel<8>, dim3(grid_blocks<8>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, depth, dds, dps, h, w, D, grad_sim, grad_ref_nhwc, g); break;
         default: return EFFI_ERR_UNSUPPORTED;
     }
     EFFI_LAUNCH_CHECK();

@@ -267,6 +267,23 @@ def warpcorr_views(ref_nhwc, srcs_nhwc, rt, depth, D):
     return sim, ent
 
 
+def warpcorr_views_bwd(ref_nhwc, srcs_nhwc, rt, depth, D, grad_sim):
+    """Backward of ``warpcorr_views``' similarity output (scope row n2): grad_sim [S,D,h,w] -> (grad_ref [h,w,C], [grad_src_v [h,w,C]])."""
+    h, w, Cc = ref_nhwc.shape
+    S = len(srcs_nhwc)
+    _t(ref_nhwc, "ref_nhwc"), _t(rt, "rt"), _t(depth, "depth", contiguous=False), _t(grad_sim, "grad_sim")
+    for s_ in srcs_nhwc:
+        _t(s_, "src_nhwc")
+    if tuple(grad_sim.shape) != (S, D, h, w):
+        raise ValueError(f"grad_sim {tuple(grad_sim.shape)} does not match (S, D, h, w) = {(S, D, h, w)}")
+    depth, dds, dps = _depth_strides(depth, D, h, w)
+    g_ref = torch.empty_like(ref_nhwc)
+    g_src = [torch.zeros_like(s_) for s_ in srcs_nhwc]
+    check(_lib.lib().effi_warpcorr_views_bwd_f32(_p(ref_nhwc), _ptr_array(srcs_nhwc), S, _p(rt), _p(depth), dds, dps, Cc, h, w, D,
+                                                  _p(grad_sim), _p(g_ref), _ptr_array(g_src), _stream()), "effi_warpcorr_views_bwd_f32")
+    return g_ref, g_src
+
+
 def pixelwise_net(entropy, params):
     n, h, w = entropy.shape
     _t(entropy, "entropy"), _t(params, "params")

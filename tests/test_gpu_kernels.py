@@ -125,6 +125,38 @@ def test_warpcorr_views(O, C, h, w, D, N):
     check_close(f"warpcorr_views entropy C={C} D={D}", ent, want_ent, rtol=1e-4, atol=2e-4, frac_ok=0.998)
 
 
+@pytest.mark.parametrize("C,h,w,D,N", [(32, 16, 20, 8, 4), (16, 18, 30, 5, 3), (8, 21, 27, 6, 3)])
+def test_warp_correlate_backward_matches_torch_autograd(O, C, h, w, D, N):
+    """Scope row n2, first piece: gradients of the stage-1 warp + correlation w.r.t. reference and source features from the HIP
+    backward kernel (scatter-add of the bilinear weights) against torch autograd through the oracle's grid_sample formulation."""
+    from effi_mvs_plus_amd import autograd as A
+    feats = synth.smooth_features(N, C, h, w, seed=200 + C)
+    pm = synth.synth_cameras(h * 8, w * 8, N)["stage1"]
+    g = torch.Generator().manual_seed(2)
+    samples = (425.0 + 510.0 * torch.rand(1, D, h, w, generator=g)) if C == 16 else \
+        torch.linspace(425.0, 935.0, D).view(1, D, 1, 1).expand(1, D, h, w)
+    G = torch.randn(N - 1, D, h, w, generator=g)
+    # oracle: autograd on the CPU
+    leaves = [f.clone().requires_grad_(True) for f in feats]
+    P = composed(pm)
+    sims = []
+    for v in range(1, N):
+        warped = O.homo_warping_new(leaves[v], P[v], P[0], samples).view(1, C, D, h, w)
+        sims.append((warped * leaves[0].unsqueeze(2)).mean(1)[0])
+    want_sim = torch.stack(sims)
+    (want_sim * G).sum().backward()
+    # HIP: forward + backward kernels behind torch.autograd.Function
+    dev_leaves = [f[0].to(DEV).requires_grad_(True) for f in feats]
+    dv = t(samples[0], DEV) if C == 16 else t(samples[0, :, 0, 0], DEV)
+    sim = A.warp_correlate(dev_leaves[0], dev_leaves[1:], t(pm[0], DEV), dv)
+    check_close("warp_correlate forward", sim, want_sim.detach(), rtol=1e-4, atol=2e-4, frac_ok=0.998)
+    (sim * t(G, DEV)).sum().backward()
+    for v in range(N):
+        want = leaves[v].grad[0]
+        check_close(f"warp_correlate grad view {v}", dev_leaves[v].grad, want, rtol=1e-3, atol=2e-4 * float(want.abs().max()) + 1e-6,
+                    frac_ok=0.998)
+
+
 def test_pixelwise_net(model, O):
     net, sd = model
     g = load_golden("g03_pixelwise.npz")
