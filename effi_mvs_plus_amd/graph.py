@@ -1,8 +1,9 @@
 """HIP-graph replay of the hot path (``Effi_MVS_plus.forward_hot``).
 
-One reference view is ~150 kernel launches on two streams; enqueued from Python they cost ~3 ms of host time, which
-is more than the GPU needs.  ``HotPathGraph`` captures the whole pass once (``torch.cuda.CUDAGraph``: a hipGraph with
-both streams' dependencies) for a fixed input geometry and replays it with one launch.  Inputs live in static device
+One reference view is ~100 kernel launches; enqueued from Python they cost about as much host time as the GPU needs.
+``HotPathGraph`` captures the whole pass once (``torch.cuda.CUDAGraph``: a hipGraph; linear when ``ops.get_branches()`` is off,
+the default, otherwise with both streams' dependencies) for a fixed input geometry and replays it with one launch -- a linear
+graph replays back to back with no gaps between kernels.  Inputs live in static device
 buffers, ``slots`` sets of them (double buffering: the producer of the next view's features fills one slot while the graph
 runs on the other; each slot has its own captured graph).  ``graph(features, cnet, proj, depth_values, slot=0)`` copies the
 caller's tensors into the slot (device to device) and replays; a producer that writes straight into ``graph.inputs[slot]``

@@ -336,7 +336,7 @@ class Effi_MVS_plus(nn.Module):
                 inter["view_weights"] = weights
                 inter["reg_volume{}".format(s + 1)] = reg_vol
                 inter["cur_volume{}".format(s + 1)] = cur_vol
-            if not prep_joined:                   # first use of the side stream's results: the stage-1 update block
+            if not prep_joined:                   # first use of the preparation's results: the stage-1 update block
                 prep_branch.join(*[t_ for k in st for t_ in st[k]], *[t_ for k in range(1, self.num_stage) for t_ in (list(geo[k][0]) + [geo[k][1]])])
                 prep_joined = True
             hidden, inp = st[s]
@@ -397,7 +397,7 @@ class Effi_MVS_plus(nn.Module):
         disp_max = depth_values[:, -1, None, None, None]
         self.scale_inv_depth = partial(disp_to_depth, min_depth=1. / disp_max, max_depth=1. / disp_min)
         self.scale_inv_depth.effi_disp_range = depth_values
-        # the N + 1 pyramid passes are independent: odd views and the context net go to the side stream (their coarse layers
+        # the N + 1 pyramid passes are independent: with branches on, odd views and the context net go to the side stream (their coarse layers
         # do not fill the chip on their own)
         n_views = imgs.size(1)
         features = [None] * n_views

@@ -144,7 +144,7 @@ class ProjectionInput(nn.Module):
             cor, dfm = ops.conv2d_k3_bf16x3_pair([cor1], wc2.wx, bc2, [dfm], wd2.wx, bd2, hd, act=ops.ACT_RELU,
                                                  out_a=g("cor2"), out_b=g("dfm2"))
         else:
-            # the depth branch (7x7 -> 3x3) does not depend on the cost branch: it goes to the side stream
+            # the depth branch (7x7 -> 3x3) does not depend on the cost branch: with branches on it goes to the side stream
             with ops.Branch() as br:
                 w7, b7 = self.conv7_packed()
                 dfm = ops.conv2d_c1k7_relu(disp, w7, b7, hd, out=g("dfm1"))
@@ -240,7 +240,7 @@ class BasicUpdateBlock(nn.Module):
                 x = self.encoder.run(inv_depth, cost_buf, context, bufs)
             net = self.depth_gru.run(net, [x], z_buf, rh_buf, out=h_bufs[i % 2])
             want_mask = self.UpMask and i == seq_len - 1
-            if want_mask:                      # the mask head only needs the new hidden state: side stream
+            if want_mask:                      # the mask head only needs the new hidden state (side stream when branches are on)
                 with ops.Branch() as br:
                     mask = self.run_mask(net)
             hid = self.depth_head.run_hidden(net, head_buf)
