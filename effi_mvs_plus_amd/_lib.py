@@ -51,6 +51,7 @@ SIGNATURES = {
     "effi_encoder_inputs_f32": [_vp, _vp, _i, _vp, _vp, _l, _l, _i, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp, _vp,
                                 _i, _vp, _vp, _vp],
     "effi_conv2d_k3_bf16x3_pair_f32": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "effi_conv2d_k3_k1_up2x_bf16x3_f32": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "effi_conv2d_k3_k1_bf16x3_f32": [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "effi_conv2d_k3_bf16x3_f32": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "effi_conv2d_k5s2_f32": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp],

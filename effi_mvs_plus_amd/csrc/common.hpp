@@ -67,6 +67,15 @@ __device__ __forceinline__ float effi_inv_to_depth(float inv, float lo, float hi
     return 1.0f / s;
 }
 
+// depth_to_disp(depth, depth_min_, depth_max_) (models/Effi_MVS_plus.py:151-164) with the global range of the hypotheses
+__device__ __forceinline__ float effi_depth_to_inv(float depth, float lo, float hi) {
+    const float max_depth = 1.0f / lo, min_depth = 1.0f / hi;
+    const float min_disp = 1.0f / max_depth, max_disp = 1.0f / min_depth;
+    const float den = (max_disp - min_disp) + 1e-10f;
+    const float s_ = 1.0f / depth;
+    return (s_ - min_disp) / den;
+}
+
 // 7x7 convolution of a single-channel map + ReLU, one (32 x 8 pixel, 16 channel) tile of it: shared by
 // conv2d_c1k7_relu_kernel (conv2d.hip) and encoder_inputs_kernel (volume_ops.hip).  Block of 256 threads.
 template <int COUT>

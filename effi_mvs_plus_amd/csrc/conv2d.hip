@@ -40,6 +40,7 @@ struct Conv2dArgs {
     int zin;                 // input planes (= zcount for stride 1; stride-2 3-D convs read a 2x deeper volume)
     int hin, win;            // input map size (= h, w for stride 1; stride-2 convs read a 2x larger map)
     const float* zeros;      // >= 64 B of zeros in device memory: where padding is read from (split-precision kernels)
+    const float* xptr0;      // EPI_K1UP: the hypotheses' inverse-depth range (first / last entry used), zin = its length
 };
 
 // One zero page per process (never freed): padding loads of the split-precision kernels read it instead of masking.
@@ -579,6 +580,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 //   * A fragments sit at lane_base + koff[s] + m*row with the row term as an immediate (no address swizzle: the stores are then
 //     4-way instead of 2-way conflicted, ~0.5k LDS cycles per tile, against ~150 address instructions per wave).
 #define EFFI_EPI_K1 6        // internal: the 3x3 result (+ extra channels) goes through a fused 1x1 convolution (see below)
+#define EFFI_EPI_K1UP 8      // internal: K1 producing the 36-channel convex-upsampling mask, consumed in registers (see below)
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -611,7 +613,7 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
     constexpr int NB4 = (NBF + 255) / 256;
     static_assert(NITEMS <= 256, "one staging item per thread");
     static_assert(EPI != EFFI_EPI_HEAD && EPI != EFFI_EPI_ADD_UP2, "epilogue not instantiated for the split-precision kernel");
-    static_assert(EPI != EFFI_EPI_K1 || !ZB, "the fused 1x1 epilogue is 2-D only");
+    static_assert((EPI != EFFI_EPI_K1 && EPI != EFFI_EPI_K1UP) || !ZB, "the fused 1x1 epilogue is 2-D only");
     __shared__ __attribute__((aligned(16))) unsigned short lds_ah[APIX * CCH];
     __shared__ __attribute__((aligned(16))) unsigned short lds_al[APIX * CCH];
     __shared__ __attribute__((aligned(16))) unsigned short lds_b[NB4 * 256 * 8];
@@ -734,7 +736,7 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
         }
     }
 
-    if (EPI == EFFI_EPI_K1) {
+    if (EPI == EFFI_EPI_K1 || EPI == EFFI_EPI_K1UP) {
         // Fused 1x1 convolution (convd -> convc of the encoder, models/update.py:78-80,93-96): the 3x3 result of a lane
         // -- channels 4*lk..4*lk+3 of pixel li, per N-tile -- is exactly the B fragment of v_mfma_f32_16x16x16_bf16 (K = 16
         // channels), so out2[co2][px] = sum_k W2[co2][k] * cat(conv3x3 + b1, extra)[k][px] needs no data movement: one K = 16 step
@@ -779,6 +781,74 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
                 xl[m][n] = __builtin_convertvector(vf - __builtin_convertvector(xh[m][n], f32x4), bf16x4);
             }
         }
+        if constexpr (EPI == EFFI_EPI_K1UP) {
+            // Mask head + convex upsampling (models/update.py:109-112,136-138 + upsample_depth, models/Effi_MVS_plus.py:167-178 +
+            // scale_inv_depth): the 36 mask values of a pixel never reach HBM.  Channel c = 16 t + 4 lk + r of the 1x1 result is mask
+            // entry (tap k = c / 4 = 4 t + lk, sub-pixel r = c % 4): a lane holds the taps k = lk, 4 + lk, 8 + lk of ITS pixel for all
+            // four sub-pixels, the softmax over the 9 taps and the weighted sum of the 3x3 inverse-depth neighbourhood are reductions
+            // over the four lanes li + 16 lk (two xor-shuffles each).  aux0 = inverse depth [h][w], out0 / out1 = depth /
+            // depth_to_disp(depth) [2h][2w], xptr0 / zin = the hypotheses' range.
+            f32x4 om[MR][3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                bf16x4 wh[NT + 1], wl[NT + 1];
+#pragma unroll
+                for (int n = 0; n <= NT; ++n) {
+                    const long f = ((long)(t * (NT + 1) + n) * 2) * 64 + lane;
+                    wh[n] = *reinterpret_cast<const bf16x4*>(w2 + f * 4);
+                    wl[n] = *reinterpret_cast<const bf16x4*>(w2 + (f + 64) * 4);
+                }
+                const int co = t * 16 + 4 * lk;
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int n = 0; n <= NT; ++n) {
+                        o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[n], xh[m][n], o, 0, 0, 0);
+                        o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wl[n], xh[m][n], o, 0, 0, 0);
+                        o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[n], xl[m][n], o, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) om[m][t][r] = o[r] + a.disp_range[co + r];
+                }
+            }
+            const float lo = a.xptr0[0], hi = a.xptr0[a.zin - 1];
+            const int W2 = 2 * w;
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                const int x = x0 + li + (WIDE ? 16 * m : 0);
+                const int y = y0 + (WIDE ? wv : wv * MR + m);
+                float nbv[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int k = 4 * t + lk;
+                    const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+                    const bool ok = (k < 9) & inside[m] & (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w);
+                    nbv[t] = ok ? a.aux0[ok ? (long)yy * w + xx : 0] : 0.0f;         // F.unfold zero padding
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v0 = om[m][0][r], v1 = om[m][1][r], v2 = (lk == 0) ? om[m][2][r] : -INFINITY;
+                    float mx = fmaxf(v0, fmaxf(v1, v2));
+                    mx = fmaxf(mx, __shfl_xor(mx, 16));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    const float e0 = expf(v0 - mx), e1 = expf(v1 - mx), e2 = (lk == 0) ? expf(v2 - mx) : 0.0f;
+                    float sm = (e0 + e1) + e2;
+                    sm = sm + __shfl_xor(sm, 16);
+                    sm = sm + __shfl_xor(sm, 32);
+                    float ac = ((e0 / sm) * nbv[0] + (e1 / sm) * nbv[1]) + (e2 / sm) * nbv[2];
+                    ac = ac + __shfl_xor(ac, 16);
+                    ac = ac + __shfl_xor(ac, 32);
+                    if (lk == 0 && inside[m]) {
+                        const long o = (long)(2 * y + (r >> 1)) * W2 + 2 * x + (r & 1);
+                        const float dep = effi_inv_to_depth(ac, lo, hi);
+                        a.out0[o] = dep;
+                        if (a.out1) a.out1[o] = effi_depth_to_inv(dep, lo, hi);
+                    }
+                }
+            }
+            return;
+        }
         for (int t = 0; t < nt2; ++t) {
             bf16x4 wh[NT + 1], wl[NT + 1];
 #pragma unroll
@@ -819,7 +889,8 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
         if (y >= h || x >= w) continue;
         const long pix = (long)y * w + x;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) conv_epilogue_store_t<(EPI == EFFI_EPI_K1 ? EFFI_EPI_PLAIN : EPI)>(a, acc[m][n], n * 16 + 4 * lk, pix, hw, zpl);
+        for (int n = 0; n < NT; ++n)
+            conv_epilogue_store_t<((EPI == EFFI_EPI_K1 || EPI == EFFI_EPI_K1UP) ? EFFI_EPI_PLAIN : EPI)>(a, acc[m][n], n * 16 + 4 * lk, pix, hw, zpl);
     }
 }
 
@@ -1833,6 +1904,53 @@ extern "C" int effi_conv2d_k3_k1_bf16x3_f32(const float* const* srcs, const int*
         case 3: return launch_bf16x3<3, EFFI_EPI_K1>(a, st);
         case 4: return launch_bf16x3<4, EFFI_EPI_K1>(a, st);
         case 6: return launch_bf16x3<6, EFFI_EPI_K1>(a, st);
+        default: return EFFI_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int effi_conv2d_k3_k1_up2x_bf16x3_f32(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
+                                                 const float* bias, int cout1, const void* w2pack_bf16, const float* bias2,
+                                                 const float* inv_depth, const float* disp_range, int n_range, int h, int w,
+                                                 float* out_depth, float* out_depth_inv, effi_stream_t stream) {
+    if (!srcs || !src_channels || n_src < 1 || n_src > EFFI_MAX_SRC || !wpack_bf16 || !bias || !w2pack_bf16 || !bias2 || !inv_depth ||
+        !disp_range || n_range < 2 || !out_depth)
+        return EFFI_ERR_BADARG;
+    if (cout1 < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    if ((w & 3) || cout1 > 96) return EFFI_ERR_UNSUPPORTED;
+    Conv2dArgs a;
+    a.cin = 0;
+    for (int i = 0; i < EFFI_MAX_SRC; ++i) {
+        a.src[i] = (i < n_src) ? srcs[i] : srcs[0];
+        a.ch[i] = (i < n_src) ? src_channels[i] : 0;
+        if (i < n_src && (!srcs[i] || src_channels[i] < 1)) return EFFI_ERR_BADARG;
+        if (i + 1 < n_src && (src_channels[i] & 7)) return EFFI_ERR_UNSUPPORTED;
+        a.cin += a.ch[i];
+    }
+    a.kgroups = 1;                          // ReLU between the 3x3 and the 1x1 convolution (models/update.py:110)
+    a.zeros = effi_zero_page();
+    if (!a.zeros) return EFFI_ERR_LAUNCH;
+    a.wpack = reinterpret_cast<const float*>(wpack_bf16);
+    a.bias = bias;
+    a.cout = cout1;
+    a.h = a.hin = h;
+    a.w = a.win = w;
+    a.act = EFFI_ACT_NONE;
+    a.hd = 0;
+    a.aux0 = inv_depth;
+    a.aux1 = reinterpret_cast<const float*>(w2pack_bf16);
+    a.disp_range = bias2;
+    a.n_range = 36;
+    a.out0 = out_depth;
+    a.out1 = out_depth_inv;
+    a.cstride = a.ostride = (long)h * w;
+    a.zcount = 0;
+    a.zin = n_range;
+    a.xptr0 = disp_range;
+    hipStream_t st = effi_s(stream);
+    switch ((cout1 + 15) / 16) {
+        case 2: return launch_bf16x3<2, EFFI_EPI_K1UP>(a, st);
+        case 4: return launch_bf16x3<4, EFFI_EPI_K1UP>(a, st);
+        case 6: return launch_bf16x3<6, EFFI_EPI_K1UP>(a, st);
         default: return EFFI_ERR_UNSUPPORTED;
     }
 }

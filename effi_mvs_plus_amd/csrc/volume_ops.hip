@@ -53,15 +53,6 @@ __global__ __launch_bounds__(TPB) void split_tanh_relu4_kernel(const float4* __r
     else inp[i - nh4] = make_float4(fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f), fmaxf(v.z, 0.0f), fmaxf(v.w, 0.0f));
 }
 
-// depth_to_disp(depth, depth_min_, depth_max_) (models/Effi_MVS_plus.py:151-164) with the global range of the hypotheses
-__device__ __forceinline__ float effi_depth_to_inv(float depth, float lo, float hi) {
-    const float max_depth = 1.0f / lo, min_depth = 1.0f / hi;
-    const float min_disp = 1.0f / max_depth, max_disp = 1.0f / min_depth;
-    const float den = (max_disp - min_disp) + 1e-10f;
-    const float s_ = 1.0f / depth;
-    return (s_ - min_disp) / den;
-}
-
 // the same for up to 4 context maps (all stages of the cascade) in ONE launch: blocks [first[k], first[k+1]) work on map k
 struct SplitStages {
     const float* ctx[4];

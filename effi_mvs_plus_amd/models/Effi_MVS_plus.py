@@ -359,9 +359,12 @@ class Effi_MVS_plus(nn.Module):
             lookup.conv1x1 = lookup_conv1x1 if self.CostNum in (2, 3, 4) else None
             lookup.encoder_inputs = lookup_encoder_inputs if self.CostNum == 3 else None
             _, masks, invs, depths = self.update_block[s].run_fused(hidden, lookup, inv_cur, inp, self.seq_len[s],
-                                                                     disp_range)
+                                                                     disp_range, fuse_upsample=not want_intermediates)
             preds.extend(d[0] for d in depths)
-            _, up_depth, inv_next = ops.convex_upsample2x(invs[-1], masks[-1], disp_range, want_inv=False, want_depth_inv=True)
+            if isinstance(masks[-1], tuple):      # mask head + upsampling ran as one kernel
+                up_depth, inv_next = masks[-1]
+            else:
+                _, up_depth, inv_next = ops.convex_upsample2x(invs[-1], masks[-1], disp_range, want_inv=False, want_depth_inv=True)
             preds.append(up_depth)
             lo_prev, hi_prev = lo_cur, hi_cur
         if tail_branch is not None:

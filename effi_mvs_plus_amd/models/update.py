@@ -206,10 +206,26 @@ class BasicUpdateBlock(nn.Module):
         w, b = _pack(self._m2, self.mask[2], scale=0.25)
         return ops.conv2d([hid], w, b, self.mask[2].out_channels, 1, act=ops.ACT_NONE)
 
+    def mask_upsample_fusable(self, net):
+        c1, c2 = self.mask[0].out_channels, self.mask[2].out_channels
+        return (ops.get_precision() == "split" and net.shape[-1] % 4 == 0 and c1 in (32, 64, 96) and c2 == 36
+                and self.mask[0].in_channels % 8 == 0)
+
+    def run_mask_upsample(self, net, inv_depth, disp_range):
+        """0.25 * mask(net) and the convex x2 upsampling of ``inv_depth`` with it in one kernel (the mask stays in registers)
+        -> (depth [2h,2w], depth_to_inv(depth) [2h,2w])."""
+        w, b = _pack(self._m0, self.mask[0])
+        c1 = self.mask[0].out_channels
+        w2, b2 = self._m2x.get([self.mask[2].weight, self.mask[2].bias],
+                               lambda: packing.pack_conv1x1_after(self.mask[2].weight, self.mask[2].bias, c1, 0, scale=0.25))
+        return ops.conv2d_k3_k1_up2x([net], w.wx, b, c1, w2, b2, inv_depth, disp_range)
+
     # -- fused path: the cost lookup is our GetCost and scale_inv_depth is the global-range rescale ------
-    def run_fused(self, net, lookup, inv_depth, context, seq_len, disp_range):
+    def run_fused(self, net, lookup, inv_depth, context, seq_len, disp_range, fuse_upsample=False):
         """Unbatched tensors; ``lookup(inv_depth, out)`` fills the [2*nq,h,w] cost for a normalised
-        inverse-depth map.  Returns (net, mask_list, inv_list, depth_list)."""
+        inverse-depth map.  Returns (net, mask_list, inv_list, depth_list).  ``fuse_upsample``: the last iteration's mask
+        head and the convex upsampling it feeds run as one kernel; mask_list[-1] is then the pair (upsampled depth,
+        depth_to_inv of it) instead of the mask."""
         hd = net.shape[0]
         h, w = net.shape[-2:]
         dev = net.device
@@ -240,12 +256,15 @@ class BasicUpdateBlock(nn.Module):
                 x = self.encoder.run(inv_depth, cost_buf, context, bufs)
             net = self.depth_gru.run(net, [x], z_buf, rh_buf, out=h_bufs[i % 2])
             want_mask = self.UpMask and i == seq_len - 1
-            if want_mask:                      # the mask head only needs the new hidden state (side stream when branches are on)
+            fused_up = want_mask and fuse_upsample and self.mask_upsample_fusable(net)
+            if want_mask and not fused_up:     # the mask head only needs the new hidden state (side stream when branches are on)
                 with ops.Branch() as br:
                     mask = self.run_mask(net)
             hid = self.depth_head.run_hidden(net, head_buf)
             inv_depth, depth = self.depth_head.run_update(hid, inv_depth, disp_range)
-            if want_mask:
+            if fused_up:                       # needs the NEW inverse depth: after the head
+                mask = self.run_mask_upsample(net, inv_depth, disp_range)
+            elif want_mask:
                 br.join(mask)
             inv_list.append(inv_depth)
             depth_list.append(depth)

@@ -784,6 +784,24 @@ def conv2d_k3_k1_x3(srcs, wpack, bias, cout1, extra, w2pack, bias2, cout2, relu=
     return out
 
 
+def conv2d_k3_k1_up2x(srcs, wpack, bias, cout1, w2pack, bias2, inv_depth, disp_range, want_depth_inv=True):
+    """Mask head (3x3 + ReLU + 1x1 to 36 channels) and the convex x2 upsampling it feeds in one kernel: inv_depth [1,h,w] or [h,w]
+    -> (depth [2h,2w], depth_to_inv(depth) [2h,2w] or None).  cout1 in {32, 64, 96}."""
+    for s_ in srcs:
+        _t(s_, "conv2d input")
+    _t(inv_depth, "inv_depth"), _t(disp_range, "disp_range")
+    h, w = srcs[0].shape[-2:]
+    dev = srcs[0].device
+    out_depth = torch.empty(2 * h, 2 * w, device=dev, dtype=torch.float32)
+    out_dinv = torch.empty(2 * h, 2 * w, device=dev, dtype=torch.float32) if want_depth_inv else None
+    cin = sum(s_.shape[0] for s_ in srcs)
+    work = lambda: {"flops": 2.0 * h * w * (cin * cout1 * 9 + cout1 * 36), "bytes": 4.0 * h * w * (cin + 1 + 8)}
+    check(_call(f"conv2d_k3k1up_nt{(cout1 + 15) // 16}", work, _lib.lib().effi_conv2d_k3_k1_up2x_bf16x3_f32, _ptr_array(srcs),
+                _int_array([s_.shape[0] for s_ in srcs]), len(srcs), _p(wpack), _p(bias), cout1, _p(w2pack), _p(bias2), _p(inv_depth),
+                _p(disp_range), disp_range.numel(), h, w, _p(out_depth), _p(out_dinv), _stream()), "effi_conv2d_k3_k1_up2x_bf16x3_f32")
+    return out_depth, out_dinv
+
+
 def conv2d_k5s2(x, wpack, bias, cout, act=ACT_RELU):
     """5x5 stride-2 pad-2 convolution (+bias, activation): x planar [cin,hin,win] -> [cout,ceil(hin/2),ceil(win/2)]."""
     _t(x, "conv input")

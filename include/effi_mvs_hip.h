@@ -142,6 +142,15 @@ int effi_conv2d_k3_bf16x3_pair_f32(const float* const* srcs_a, const int* src_ch
                                    const float* bias_a, float* out_a, const float* const* srcs_b,
                                    const int* src_channels_b, int n_src_b, const void* wpack_b, const float* bias_b,
                                    float* out_b, int cout, int h, int w, int act, effi_stream_t stream);
+/* Mask head + convex upsampling of the last GRU iteration in one kernel (models/update.py:109-112,136-138: 3x3 conv, ReLU, 1x1
+ * conv to 36 channels, x0.25 folded into w2pack / bias2; upsample_depth, models/Effi_MVS_plus.py:167-178; scale_inv_depth
+ * :138-148): the 36 mask values of a pixel stay in registers.  inv_depth [h][w]; out_depth [2h][2w]; out_depth_inv [2h][2w] or
+ * NULL = depth_to_disp(out_depth) (what the next stage starts from); cout1 in {32, 64, 96}; w % 4 == 0.  The softmax over the 9
+ * taps is summed across four lanes, i.e. in a different order than effi_convex_upsample2x_f32 sums it (last-bit differences). */
+int effi_conv2d_k3_k1_up2x_bf16x3_f32(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
+                                      const float* bias, int cout1, const void* w2pack_bf16, const float* bias2,
+                                      const float* inv_depth, const float* disp_range, int n_range, int h, int w,
+                                      float* out_depth, float* out_depth_inv, effi_stream_t stream);
 /* Same operator (stride 1, cout <= 32, w % 4 == 0) in split precision: products as hi*hi + hi*lo + lo*hi on the bf16
  * matrix cores with fp32 accumulation (see effi_conv2d_k3_bf16x3_f32).  Input = channel concatenation of n_src planar
  * tensors [Ci][D][h][w] (models/module.py:513); wpack_bf16 = split-bf16 packing of the weight viewed as

@@ -634,6 +634,36 @@ def test_split_tanh_relu(h, w):
     assert torch.equal(inp.cpu(), torch.relu(ctx[16:]))
 
 
+@pytest.mark.parametrize("h,w", [(36, 60), (148, 200), (72, 520)])
+@pytest.mark.parametrize("hd", [16, 32, 48])
+def test_mask_head_fused_with_convex_upsampling(h, w, hd):
+    """effi_conv2d_k3_k1_up2x_bf16x3_f32 (mask never written) against the mask-head kernel followed by effi_convex_upsample2x_f32:
+    same mask values, the 9-tap softmax summed in a different order -> last-bit differences only."""
+    import contextlib
+    import io
+    from effi_mvs_plus_amd import ops
+    from effi_mvs_plus_amd.models.update import BasicUpdateBlock
+    g = torch.Generator().manual_seed(hd * 10 + h)
+    with contextlib.redirect_stdout(io.StringIO()):
+        blk = BasicUpdateBlock(hidden_dim=hd, cost_dim=3, ratio=2, context_dim=hd // 4, UpMask=True, Inverse=True, cost_num=2).eval()
+    blk.load_state_dict(synth.randomize_state_dict(blk.state_dict(), seed=7))
+    blk = blk.to(DEV)
+    net = t(torch.tanh(torch.randn(hd, h, w, generator=g)), DEV)
+    inv = t(torch.rand(1, h, w, generator=g), DEV)
+    dv = t(torch.linspace(1 / 935.0, 1 / 425.0, 384), DEV)
+    before = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        assert blk.mask_upsample_fusable(net)
+        depth_f, dinv_f = blk.run_mask_upsample(net, inv, dv)
+        mask = blk.run_mask(net)
+        _, depth_c, dinv_c = ops.convex_upsample2x(inv, mask, dv, want_inv=False, want_depth_inv=True)
+    finally:
+        ops.set_precision(before)
+    check_close(f"fused mask+upsample depth hd={hd} {h}x{w}", depth_f, depth_c.cpu(), rtol=2e-6, atol=1e-3)
+    check_close(f"fused mask+upsample inverse depth hd={hd} {h}x{w}", dinv_f, dinv_c.cpu(), rtol=0.0, atol=2e-6)
+
+
 def test_cpu_tensor_fails_loudly():
     from effi_mvs_plus_amd import ops
     from effi_mvs_plus_amd._lib import EffiLibraryError
