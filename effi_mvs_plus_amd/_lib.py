@@ -45,6 +45,7 @@ SIGNATURES = {
     "effi_conv3d_k3_pair_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "effi_conv3d_k3s1_roll_bf16x3_pair_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "effi_deconv3d_k3_pair_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "effi_homo_warp_bwd_f32": [_vp, _vp, _l, _l, _i, _i, _i, _i, _vp, _vp, _vp],
     "effi_warpcorr_views_bwd_f32": [_vp, _vp, _i, _vp, _vp, _l, _l, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "effi_image_prepare_u8_f32": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
     "effi_resize_linear_f32": [_vp, _i, _i, _i, _i, _i, _vp, _vp],

@@ -31,6 +31,32 @@ class _WarpCorrelate(torch.autograd.Function):
         return (planar(g_ref), None, None) + tuple(planar(g) for g in g_src)
 
 
+class _HomoWarp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src_fea, src_proj, ref_proj, depth_values):
+        # src_fea planar [C,h,w]; src_proj / ref_proj [4,4] (already K.[R|t]); depth_values [D] or [D,h,w]
+        C_, h, w = src_fea.shape
+        D = depth_values.shape[0]
+        nhwc = ops.to_nhwc([src_fea.contiguous()])[0]
+        rt = ops.rel_proj(src_proj.contiguous(), ref_proj.contiguous())
+        ctx.save_for_backward(rt, depth_values)
+        ctx.dims = (D, h, w)
+        return ops.homo_warp(nhwc, rt, depth_values, D)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        rt, depth_values = ctx.saved_tensors
+        D, h, w = ctx.dims
+        g = ops.homo_warp_bwd(rt, depth_values, D, grad_out.contiguous(), h, w)
+        return g.permute(2, 0, 1).contiguous(), None, None, None
+
+
+def homo_warp(src_fea, src_proj, ref_proj, depth_values):
+    """Differentiable ``homo_warping_new`` for one sample (models/module.py:303-344): src_fea [C,h,w] -> warped [C,D,h,w]; the
+    gradient flows to ``src_fea`` (the grid is constant, module.py:313)."""
+    return _HomoWarp.apply(src_fea, src_proj, ref_proj, depth_values)
+
+
 def warp_correlate(ref_fea, src_feas, pairs, depth_values):
     """ref_fea [C,h,w], src_feas list of [C,h,w] (C in 8/16/32), pairs [N,2,4,4] (view 0 = reference), depth_values [D] or
     [D,h,w] -> similarity [S,D,h,w]; differentiable w.r.t. the feature maps."""

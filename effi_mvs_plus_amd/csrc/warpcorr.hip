@@ -342,6 +342,38 @@ __global__ __launch_bounds__(256) void warpcorr_views_bwd_kernel(const float* __
     *reinterpret_cast<float4*>(grad_ref + (long)pix * C + sub4) = gr;
 }
 
+// Backward of homo_warp_kernel w.r.t. the source features (scope row n2): grad_src[tap][c] += w_tap * grad_out[c][d][p]; the grid
+// is constant (models/module.py:313).  Same lane layout as the forward kernel; fp32 atomic adds.
+template <int C>
+__global__ __launch_bounds__(256) void homo_warp_bwd_kernel(const float* __restrict__ rt, const float* __restrict__ depth,
+                                                            long dds, long dps, int h, int w, int D,
+                                                            const float* __restrict__ grad_out, float* __restrict__ grad_src) {
+    int x, y, sub;
+    if (!tile_pixel<C>(blockIdx.x, gridDim.x, h, w, x, y, sub)) return;
+    const int hw = h * w, pix = y * w + x, sub4 = 4 * sub;
+    const float fx = (float)x, fy = (float)y;
+    const float rx = rt[0] * fx + rt[1] * fy + rt[2];
+    const float ry = rt[3] * fx + rt[4] * fy + rt[5];
+    const float rz = rt[6] * fx + rt[7] * fy + rt[8];
+    const float* dp = depth + (long)pix * dps;
+    for (int d = 0; d < D; ++d) {
+        const float dep = dp[d * dds];
+        Taps t;
+        make_taps(rx * dep + rt[9], ry * dep + rt[10], rz * dep + rt[11], w, h, C, t);
+        const float* g = grad_out + ((long)sub4 * D + d) * hw + pix;
+        const float g0 = g[0], g1 = g[(long)D * hw], g2 = g[2L * D * hw], g3 = g[3L * D * hw];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (t.w[k] == 0.0f) continue;
+            float* o = grad_src + t.off[k] + sub4;
+            unsafeAtomicAdd(o + 0, t.w[k] * g0);
+            unsafeAtomicAdd(o + 1, t.w[k] * g1);
+            unsafeAtomicAdd(o + 2, t.w[k] * g2);
+            unsafeAtomicAdd(o + 3, t.w[k] * g3);
+        }
+    }
+}
+
 template <int C> int grid_blocks(int h, int w) {
     using G = WarpGeom<C>;
     return ((w + G::TW - 1) / G::TW) * ((h + G::TH - 1) / G::TH);
@@ -367,6 +399,20 @@ extern "C" int effi_homo_warp_f32(const float* src_nhwc, const float* rt, const 
         case 32: hipLaunchKernelGGL(homo_warp_kernel<32>, dim3(grid_blocks<32>(h, w)), dim3(256), 0, s, src_nhwc, rt, depth, dds, dps, h, w, D, out); break;
         case 16: hipLaunchKernelGGL(homo_warp_kernel<16>, dim3(grid_blocks<16>(h, w)), dim3(256), 0, s, src_nhwc, rt, depth, dds, dps, h, w, D, out); break;
         case 8:  hipLaunchKernelGGL(homo_warp_kernel<8>, dim3(grid_blocks<8>(h, w)), dim3(256), 0, s, src_nhwc, rt, depth, dds, dps, h, w, D, out); break;
+        default: return EFFI_ERR_UNSUPPORTED;
+    }
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_homo_warp_bwd_f32(const float* rt, const float* depth, long dds, long dps, int C, int h, int w, int D,
+                                      const float* grad_out, float* grad_src_nhwc, effi_stream_t stream) {
+    if (!rt || !depth || !grad_out || !grad_src_nhwc || h < 2 || w < 2 || D < 1) return EFFI_ERR_BADARG;
+    hipStream_t s = effi_s(stream);
+    switch (C) {
+        case 32: hipLaunchKernelGGL(homo_warp_bwd_kernel<32>, dim3(grid_blocks<32>(h, w)), dim3(256), 0, s, rt, depth, dds, dps, h, w, D, grad_out, grad_src_nhwc); break;
+        case 16: hipLaunchKernelGGL(homo_warp_bwd_kernel<16>, dim3(grid_blocks<16>(h, w)), dim3(256), 0, s, rt, depth, dds, dps, h, w, D, grad_out, grad_src_nhwc); break;
+        case 8:  hipLaunchKernelGGL(homo_warp_bwd_kernel<8>, dim3(grid_blocks<8>(h, w)), dim3(256), 0, s, rt, depth, dds, dps, h, w, D, grad_out, grad_src_nhwc); break;
         default: return EFFI_ERR_UNSUPPORTED;
     }
     EFFI_LAUNCH_CHECK();

@@ -403,6 +403,13 @@ def homo_warping_new(src_fea, src_proj, ref_proj, depth_values):
     B, C_, H, W = src_fea.shape
     D = depth_values.shape[1]
     outs = []
+    if src_fea.requires_grad and torch.is_grad_enabled():
+        # differentiable form (scope row n2): forward and backward on the HIP kernels, gradient to src_fea only (the reference
+        # builds its grid under no_grad, module.py:313)
+        from .. import autograd as _ag
+        for b in range(B):
+            outs.append(_ag.homo_warp(src_fea[b], src_proj[b], ref_proj[b], depth_values[b]).reshape(C_, D * H, W))
+        return torch.stack(outs)
     for b in range(B):
         nhwc = ops.to_nhwc([src_fea[b]])[0]
         rt = ops.rel_proj(src_proj[b].contiguous(), ref_proj[b].contiguous())

@@ -247,6 +247,17 @@ def homo_warp(src_nhwc, rt, depth, D):
     return out
 
 
+def homo_warp_bwd(rt, depth, D, grad_out, h, w):
+    """Backward of ``homo_warp`` w.r.t. the source features: grad_out [C,D,h,w] -> grad_src [h,w,C] (scope row n2)."""
+    _t(rt, "rt"), _t(depth, "depth", contiguous=False), _t(grad_out, "grad_out")
+    Cc = grad_out.shape[0]
+    depth, dds, dps = _depth_strides(depth, D, h, w)
+    g_src = torch.zeros(h, w, Cc, device=grad_out.device, dtype=torch.float32)
+    check(_lib.lib().effi_homo_warp_bwd_f32(_p(rt), _p(depth), dds, dps, Cc, h, w, D, _p(grad_out), _p(g_src), _stream()),
+          "effi_homo_warp_bwd_f32")
+    return g_src
+
+
 def warpcorr_views(ref_nhwc, srcs_nhwc, rt, depth, D):
     """-> (sim_views [S,D,h,w], entropy [S,h,w])."""
     h, w, Cc = ref_nhwc.shape

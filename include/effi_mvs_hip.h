@@ -320,6 +320,10 @@ int effi_warpcorr_views_bwd_f32(const float* ref_nhwc, const float* const* src_n
                                 const float* depth, long depth_dstride, long depth_pstride, int C, int h, int w, int D,
                                 const float* grad_sim, float* grad_ref_nhwc, float* const* grad_src_nhwc,
                                 effi_stream_t stream);
+/* Backward of effi_homo_warp_f32 w.r.t. the source features (the "differentiable homography warping" of homo_warping_new,
+ * models/module.py:303-344): grad_out [C][D][h*w]; grad_src_nhwc [h][w][C] must be ZERO on entry (fp32 atomic scatter-add). */
+int effi_homo_warp_bwd_f32(const float* rt, const float* depth, long depth_dstride, long depth_pstride, int C, int h, int w,
+                           int D, const float* grad_out, float* grad_src_nhwc, effi_stream_t stream);
 
 /* ---- pair launches for the two cross-scale blocks of a stage (CSP_R[s] / CSP_C[s], models/Effi_MVS_plus.py:520-531): the two
  * blocks are independent chains of the same five layers on volumes of the same shape.  Each entry below runs the SAME layer of
