@@ -205,6 +205,25 @@ def main():
             ops.set_profile(None)
             ops.set_branches(br)
             torch.cuda.synchronize()
+    # ms per cost-volume stage (the second half of BASELINE.json's metric): HIP events at the stage boundaries of eager
+    # single-stream passes (stage k = its cost volume + regularisation / cross-scale blocks + its three GRU iterations + upsampling;
+    # stage 1 also carries the preparation of all stages)
+    stage_ms = None
+    if rank == 0:
+        with torch.no_grad():
+            br = ops.get_branches()
+            ops.set_branches(False)
+            acc_ms, n_pass = {}, 5
+            for i in range(n_pass):
+                marks = []
+                ops.set_marks(marks)
+                net.forward_hot(*inputs[i % n_scenes])
+                ops.set_marks(None)
+                torch.cuda.synchronize()
+                for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
+                    acc_ms[n1] = acc_ms.get(n1, 0.0) + e0.elapsed_time(e1)
+            ops.set_branches(br)
+            stage_ms = {k: v / n_pass for k, v in acc_ms.items()}
     if distributed:
         tmax = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -262,6 +281,7 @@ def main():
                        "parallelism": f"view-sharded x{world}, {'RCCL' if args.backend == 'nccl' else 'gloo (rehearsal)'} gather of "
                                       f"depth+confidence to rank 0 inside the timed region" if world > 1 else "single GPU"},
             "in_flight": (max(1, args.in_flight) if graphed is not None else 1),
+            "ms_per_cost_volume_stage": stage_ms,
             **({"graph_fallback": graph_fallback} if graph_fallback else {}),
             "roofline": roof,
             "kernel_breakdown_ms": {k: round(v["ms"], 4) for k, v in sorted(disc.items(), key=lambda kv: -kv[1]["ms"])},

@@ -266,6 +266,7 @@ class Effi_MVS_plus(nn.Module):
         """One sample, unbatched.  feats: per view {stageK: [C,h,w]}; ctx {stageK: [hd+cd,h,w]};
         pairs {stageK: [N,2,4,4]}; disp_range [384] ascending inverse depths."""
         D1 = self.depth_stage_nums[0]
+        ops.mark("begin")
         hyp, misc = ops.stage1_hypotheses(disp_range, D1)      # misc: 3 intervals, depth_min_, depth_max_
         g_min, g_max = misc[3:4], misc[4:5]
         preds, inter = [], {}
@@ -301,6 +302,8 @@ class Effi_MVS_plus(nn.Module):
         tail_branch = None
         inv_next = None                          # normalised inverse depth the next update block starts from
         for s in range(self.num_stage):
+            if s > 0:
+                ops.mark("stage{}".format(s))              # end of the previous stage
             nhwc, rt, (_, h, w) = geo[s]
             if s == 0:
                 sim_views, entropy = ops.warpcorr_views(nhwc[0], nhwc[1:], rt, hyp, D1)
@@ -367,6 +370,7 @@ class Effi_MVS_plus(nn.Module):
                 _, up_depth, inv_next = ops.convex_upsample2x(invs[-1], masks[-1], disp_range, want_inv=False, want_depth_inv=True)
             preds.append(up_depth)
             lo_prev, hi_prev = lo_cur, hi_cur
+        ops.mark("stage{}".format(self.num_stage))
         if tail_branch is not None:
             tail_branch.join(conf)
         out = {"depth": preds, "photometric_confidence": conf}

@@ -157,6 +157,23 @@ class Branch:
                     t_.record_stream(self.main)
 
 
+# Optional stage markers (bench.py's "ms per cost-volume stage"): forward_hot calls mark() at the stage boundaries; events are only
+# recorded while a list is installed (never during graph capture).
+_MARKS = None
+
+
+def set_marks(marks):
+    global _MARKS
+    _MARKS = marks
+
+
+def mark(name):
+    if _MARKS is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        _MARKS.append((name, ev))
+
+
 def _stream():
     # raw hipStream_t of torch's current stream on the current device (fast path: ~1 us instead of the
     # ~8 us of torch.cuda.current_stream().cuda_stream; this is called once per kernel launch)
