@@ -37,6 +37,25 @@ DTYPE = {"split": "f32 (3x3 MFMA convs: products as 3 bf16 partial products hi*h
          "fp32": "f32"}
 
 
+def self_launch(n, backend, ndev):
+    """One process per GPU on this node through torch.distributed.run (the same command line the driver uses); returns the
+    launcher's exit code.  Refuses (non-zero) when the RCCL path would need more devices than the node has."""
+    import socket
+    import subprocess
+    if backend == "nccl" and ndev < n:
+        print(f"[bench] --gpus {n} needs {n} GPUs for the RCCL path, this node has {ndev}; use --backend gloo to rehearse the "
+              "multi-rank plumbing on fewer devices", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,16 +83,24 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1: nccl (= RCCL over xGMI, the real path) or gloo (rehearsal of the "
                          "multi-rank plumbing on a box with fewer GPUs than ranks; ranks then share devices)")
+    ap.add_argument("--fusion-torch-baseline", action="store_true",
+                    help="also time the reference's fusion op sequence on the GPU (element-wise 3x3 algebra instead of the 19 M-batch "
+                         "GEMM that faulted in round 1); opt-in, never part of the default run")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # ``python bench.py --gpus N`` without an external launcher: start the N ranks ourselves, BEFORE anything in this
+        # process touches the GPU (device_count() does not initialise it), and pass their exit code on
+        sys.exit(self_launch(args.gpus, args.backend, torch.cuda.device_count()))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     distributed = world > 1
     ndev = torch.cuda.device_count()
@@ -268,7 +295,8 @@ def main():
         roof["share_of_kernel_time"] = disc[key]["ms"] / max(total_ms, 1e-9)
         result = {
             "metric": "ref-views/sec (cost-volume hot path: warp + cost volume + 3-D regularisation + cascaded GRU refinement)",
-            "value": views / dt, "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": views / dt, "unit": "views/s", "n_gpus": (dist.get_world_size() if distributed else 1),       # as the process group reports it
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE[precision], "data": "synthetic",
             "config": {"workload": f"{args.workload}: DTU-shaped {W}x{H}, N={N} views (S={N - 1} sources), 3-stage cascade "
@@ -287,20 +315,44 @@ def main():
             "kernel_breakdown_ms": {k: round(v["ms"], 4) for k, v in sorted(disc.items(), key=lambda kv: -kv[1]["ms"])},
         }
 
-    # ---- secondary (rank 0, N = 1, outside the timed region): the same K steps with the other conv arithmetic, and the
+    # ---- secondary (rank 0, N = 1, outside the timed region): the same K steps with the other conv arithmetic -- measured the
+    # same way as the headline (its own captured graph, K replays + output clones) and, for reference, eagerly -- and the
     # distance between the two modes' final depth maps (normalised by the depth range, as the parity tests do)
     if rank == 0 and world == 1 and not args.no_other_precision:
         other = "fp32" if precision == "split" else "split"
         with torch.no_grad():
             ref_out = step(0)["depth"][-1].clone()
             ops.set_precision(other)
-            alt_out = step(0)["depth"][-1].clone()
+            alt_out = step(0)["depth"][-1].clone()              # eager: step() replays only in the headline precision
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(args.steps):
                 step(i)
             torch.cuda.synchronize()
             dt_other = time.perf_counter() - t0
+            other_graph = None
+            if graphed is not None:
+                from effi_mvs_plus_amd.graph import HotPathGraph
+                try:
+                    og = HotPathGraph(net, *inputs[0], slots=n_scenes)          # captured while ``other`` is the precision
+                    for i in range(n_scenes):
+                        og.load(i, *inputs[i % n_scenes])
+                    for i in range(2):
+                        og.replay(i % n_scenes)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    keep = []
+                    for i in range(args.steps):
+                        o = og.replay(i % n_scenes)
+                        keep.append((o["depth"][-1].clone(), o["photometric_confidence"].clone()))
+                    torch.cuda.synchronize()
+                    dt_og = time.perf_counter() - t0
+                    same = bool(torch.equal(og.replay(0)["depth"][-1], alt_out))
+                    other_graph = {"value": args.steps / dt_og, "unit": "views/s", "ms_per_step": dt_og / args.steps * 1e3,
+                                   "replay_bitwise_equal_to_eager": same}
+                    del og, keep
+                except Exception as exc:
+                    other_graph = {"error": f"{type(exc).__name__}: {exc}"}
             ops.set_precision(precision)
         rng = synth.DEPTH_MAX_MM - synth.DEPTH_MIN_MM
         diff = (ref_out - alt_out).abs() / rng
@@ -317,11 +369,13 @@ def main():
                 ops.set_profile(None)
             result["eager_launch"] = {"value": args.steps / dt_eager, "unit": "views/s", "ms_per_step": dt_eager / args.steps * 1e3,
                                       "note": "same kernels enqueued from Python (~100 launches per view): the host needs about as long as the GPU"}
-        result["other_precision"] = {"mode": other, "dtype": DTYPE[other], "launch": "eager", "value": args.steps / dt_other, "unit": "views/s",
-                                     "ms_per_step": dt_other / args.steps * 1e3,
+        result["other_precision"] = {"mode": other, "dtype": DTYPE[other],
+                                     "graph_replay": other_graph,        # like-for-like with the headline line
+                                     "eager": {"value": args.steps / dt_other, "unit": "views/s", "ms_per_step": dt_other / args.steps * 1e3},
                                      "final_depth_diff_between_modes": {"mean_norm": float(diff.mean()),
                                                                         "p99_norm": float(diff.flatten().kthvalue(int(0.99 * diff.numel())).values),
                                                                         "max_norm": float(diff.max())}}
+        torch.cuda.empty_cache()
 
     # ---- secondary (rank 0, N = 1): throughput with several independent views in flight (their graphs on separate streams, the
     # second stream inside each graph enabled): bubbles of one view are filled by kernels of the others.  Not the headline: a
@@ -420,9 +474,18 @@ def main():
         result["fusion_filter"] = {"views_per_s": 1e3 / hip_ms, "ms_per_ref_view": hip_ms, "src_views": Vf,
                                    "algorithmic_GBps": fbytes / hip_ms / 1e6,
                                    "note": f"{W}x{H} depth maps, {Vf} source views, dh_view_num 2, one fused kernel per reference view"}
+        if args.fusion_torch_baseline:
+            # the reference's op sequence on this GPU with the per-pixel 3x3 / 4x4 products written element-wise (opt-in: its
+            # literal form issues ONE batched GEMM of 18.9 M (3x3)(3x1) products, inside which round 1's run aborted with a GPU
+            # memory access fault -- DESIGN.md section 6)
+            with torch.no_grad(), Of.elementwise_mm():
+                fa = (dmaps[0][None, None], dmaps[1:][None, :, None], fcams[0][None], fcams[1:][None], fconf[None], 0.3, 2, 4.0, 1.3)
+                tg = timed(lambda: Of.fusion_dynamic_filter(*fa), n=3)
+            result["fusion_filter"]["torch_rocm_composite"] = {"ms_per_ref_view": tg, "speedup_of_hip_path": tg / hip_ms,
+                                                               "note": "oracle restatement of misc/fusion.py on the GPU, element-wise matrix products"}
+            torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
-            # the reference's op sequence (oracle restatement of misc/fusion.py) on the host cores, quarter of the pixels.
-            # (Its PyTorch-ROCm form is not timed: the 19M-batch 3x3 matmul it issues at this size faults inside the BLAS library.)
+            # the reference's op sequence (oracle restatement of misc/fusion.py) on the host cores, quarter of the pixels
             hq, wq = H // 2, W // 2
             dq, cq = synth.synth_depth_maps(hq, wq, Vf + 1, seed=4)
             with torch.no_grad():
@@ -501,21 +564,34 @@ def main():
     if rank == 0 and world == 1:
         from oracle import effi_oracle as O
         f, c, p, d = inputs[0]
+        hip_ms = dt / args.steps * 1e3
         if args.torch_baseline_views > 0:
-            # reference-style composite path: the oracle's op-for-op torch sequence on this GPU
-            # (sync-free: it omits the reference's NaN probe and torch.unique assert, 34 host syncs per view)
+            # reference-style composite path: the oracle's op-for-op torch sequence on this GPU, (a) sync-free (without the
+            # reference's NaN probe and torch.unique assert) and (b) literal: with those 34 host synchronisations per view
+            # (models/module.py:331-332 x12, models/Effi_MVS_plus.py:109 x22) exactly where the reference has them
             sd_dev = {k: v.to(dev) for k, v in sd.items()}
-            with torch.no_grad():
+
+            def time_composite():
                 O.hot_path(sd_dev, f, c, p, d)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(args.torch_baseline_views):
                     O.hot_path(sd_dev, f, c, p, d)
                 torch.cuda.synchronize()
-                tb = (time.perf_counter() - t0) / args.torch_baseline_views
+                return (time.perf_counter() - t0) / args.torch_baseline_views
+
+            with torch.no_grad():
+                tb = time_composite()
+                with O.literal_syncs():
+                    tl = time_composite()
+                    n_syncs = O.SYNC_COUNT // (args.torch_baseline_views + 1)
             result["torch_rocm_composite"] = {"value": 1.0 / tb, "unit": "views/s", "ms_per_view": tb * 1e3,
-                                              "speedup_of_hip_path": (dt / args.steps) and tb / (dt / args.steps),
-                                              "sample": f"{args.torch_baseline_views} views, same inputs, stock PyTorch-ROCm ops"}
+                                              "speedup_of_hip_path": tb * 1e3 / hip_ms,
+                                              "sample": f"{args.torch_baseline_views} views, same inputs, stock PyTorch-ROCm ops, sync-free restatement"}
+            result["torch_rocm_literal_with_syncs"] = {"value": 1.0 / tl, "unit": "views/s", "ms_per_view": tl * 1e3,
+                                                       "host_syncs_per_view": n_syncs, "speedup_of_hip_path": tl * 1e3 / hip_ms,
+                                                       "sample": f"{args.torch_baseline_views} views, same inputs, stock PyTorch-ROCm ops with the "
+                                                                 "reference's NaN probe and torch.unique assert in place"}
             del sd_dev
             torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
@@ -526,12 +602,33 @@ def main():
             with torch.no_grad():
                 t0 = time.perf_counter()
                 for _ in range(args.cpu_views):
-                    O.hot_path(sd, fc, cc, pc, dc)
+                    want = O.hot_path(sd, fc, cc, pc, dc)
                 tc = (time.perf_counter() - t0) / args.cpu_views
             result["cpu_baseline"] = {"value": 1.0 / tc, "unit": "views/s", "cores": torch.get_num_threads(), "kind": "port",
                                       "sample": f"{args.cpu_views} reference views of the same workload ({args.workload}), hot path only, "
                                                 f"oracle/effi_oracle.py (bitwise equal to the reference's CPU PyTorch path), "
                                                 f"{tc:.2f} s per view"}
+            # parity of the timed workload at its own size: the HIP path's outputs for the same view against the oracle pass that
+            # was just timed (normalised by the depth range, the units of SURVEY.md section 8(d); gates: mean <= 1e-3, p99 <= 5e-3)
+            with torch.no_grad():
+                got = step(0)
+                torch.cuda.synchronize()
+            rng = synth.DEPTH_MAX_MM - synth.DEPTH_MIN_MM
+
+            def dist_(a, b, scale):
+                e = ((a.detach().cpu() - b).abs() / scale).flatten()
+                return {"mean_norm": float(e.mean()), "p99_norm": float(e.kthvalue(max(1, int(0.99 * e.numel()))).values),
+                        "max_norm": float(e.max())}
+
+            per = [dist_(a, b, rng) for a, b in zip(got["depth"], want["depth"])]
+            cf = dist_(got["photometric_confidence"], want["photometric_confidence"], 1.0)
+            result["parity_vs_oracle"] = {
+                "depth": per, "photometric_confidence": cf,
+                "worst_depth_mean_norm": max(x["mean_norm"] for x in per), "worst_depth_p99_norm": max(x["p99_norm"] for x in per),
+                "gate": {"mean_norm": 1e-3, "p99_norm": 5e-3, "confidence_mean_abs": 1e-3},
+                "pass": bool(max(x["mean_norm"] for x in per) <= 1e-3 and max(x["p99_norm"] for x in per) <= 5e-3 and cf["mean_norm"] <= 1e-3),
+                "note": f"{len(per)} depth maps + confidence of the timed workload ({args.workload}, view 0, precision {precision}) vs "
+                        "oracle/effi_oracle.py on the host; |d - d_ref| / (depth_max - depth_min)"}
     if rank == 0:
         print(json.dumps(result))
     if distributed:

@@ -18,6 +18,7 @@ _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 # name -> argtypes (restype is int for all but effi_error_string)
 SIGNATURES = {
     "effi_version": [],
+    "effi_set_workspace": [_i, _vp, _l],
     "effi_fusion_dynamic_filter_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _f, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp],
     "effi_compose_rel_proj_f32": [_vp, _i, _vp, _vp],
@@ -66,6 +67,9 @@ SIGNATURES = {
     "effi_upsample_nearest_f32": [_vp, _i, _i, _i, _i, _vp, _vp],
 }
 
+# entry points whose return type is not the int status code (bound explicitly in lib())
+NON_STATUS_SYMBOLS = ("effi_error_string", "effi_workspace_bytes", "effi_get_workspace")
+
 _lock = threading.Lock()
 _lib = None
 
@@ -94,6 +98,10 @@ def lib():
             fn.restype = _i
         handle.effi_error_string.argtypes = [_i]
         handle.effi_error_string.restype = C.c_char_p
+        handle.effi_workspace_bytes.argtypes = []
+        handle.effi_workspace_bytes.restype = _l
+        handle.effi_get_workspace.argtypes = [_i]
+        handle.effi_get_workspace.restype = _vp
         _lib = handle
     return _lib
 

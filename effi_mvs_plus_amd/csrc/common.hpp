@@ -5,8 +5,11 @@
 
 #define EFFI_LAUNCH_CHECK()                                   \
     do {                                                      \
-        if (hipGetLastError() != hipSuccess) return EFFI_ERR_LAUNCH; \
+        if (hipPeekAtLastError() != hipSuccess) return EFFI_ERR_LAUNCH; \
     } while (0)
+
+// zero page of the current device (caller-registered, api.hip); nullptr when none is registered
+const float* effi_zero_page();
 
 static inline hipStream_t effi_s(effi_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int effi_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

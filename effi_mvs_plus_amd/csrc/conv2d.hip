@@ -43,17 +43,6 @@ struct Conv2dArgs {
     const float* xptr0;      // EPI_K1UP: the hypotheses' inverse-depth range (first / last entry used), zin = its length
 };
 
-// One zero page per process (never freed): padding loads of the split-precision kernels read it instead of masking.
-static const float* effi_zero_page() {
-    static const float* page = [] {
-        void* p = nullptr;
-        if (hipMalloc(&p, 256) != hipSuccess) return (const float*)nullptr;
-        if (hipMemset(p, 0, 256) != hipSuccess) return (const float*)nullptr;
-        return (const float*)p;
-    }();
-    return page;
-}
-
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case EFFI_ACT_RELU: return fmaxf(v, 0.0f);
@@ -1415,7 +1404,7 @@ template <int KS, int NT, int MR, int EPI>
 int launch2d_v2(const Conv2dArgs& a, hipStream_t st) {
     const int tiles_x = effi_cdiv(a.w, 16), ntiles = tiles_x * effi_cdiv(a.h, 4 * MR);
     hipLaunchKernelGGL((conv2d_mfma_v2_kernel<KS, NT, MR, EPI, 8, false>), dim3(ntiles), dim3(256), 0, st, a, tiles_x, ntiles);
-    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+    return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
 
 template <int KS, int NT, int EPI>
@@ -1434,7 +1423,7 @@ int launch2d(const Conv2dArgs& a, hipStream_t st) {
     }
     dim3 grid(effi_cdiv(a.w, 16), effi_cdiv(a.h, 16));
     hipLaunchKernelGGL((conv2d_mfma_kernel<KS, NT, EPI>), grid, dim3(256), 0, st, a);
-    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+    return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
 
 template <int KS, int EPI>
@@ -1457,7 +1446,7 @@ static int launch3d_planes(const Conv2dArgs& a, hipStream_t st) {
     const int tiles_x = effi_cdiv(a.w, 16), ntiles = tiles_x * effi_cdiv(a.h, 4 * MR);
     hipLaunchKernelGGL((conv2d_mfma_v2_kernel<3, NT, MR, EFFI_EPI_PLAIN, 8, false, ALIGNED>), dim3(ntiles, a.zcount), dim3(256), 0, st,
                        a, tiles_x, ntiles);
-    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+    return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
 
 template <int NT>
@@ -1506,7 +1495,7 @@ static int launch3d_planes_s2(const Conv2dArgs& a, hipStream_t st) {
     const int tiles_x = effi_cdiv(a.w, 16), ntiles = tiles_x * effi_cdiv(a.h, 4 * MR);
     hipLaunchKernelGGL((conv2d_mfma_v2_kernel<3, NT, MR, EFFI_EPI_PLAIN, 8, false, ALIGNED, 2>), dim3(ntiles, a.zcount), dim3(256), 0,
                        st, a, tiles_x, ntiles);
-    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+    return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
 
 template <int NT>
@@ -1594,7 +1583,7 @@ extern "C" int effi_conv2d_f32(const float* const* srcs, const int* src_channels
             hipLaunchKernelGGL(conv2d_cout1_k3_kernel<EFFI_EPI_HEAD>, grid, dim3(256), 0, st, a, wraw);
         else
             hipLaunchKernelGGL(conv2d_cout1_k3_kernel<EFFI_EPI_PLAIN>, grid, dim3(256), 0, st, a, wraw);
-        return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+        return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
     }
     switch (epilogue) {
         case EFFI_EPI_PLAIN:
@@ -1632,7 +1621,7 @@ static int launch_k5s2(const Conv2dArgs& a, hipStream_t st) {
     const int tiles_x = effi_cdiv(a.w, 16), ntiles = tiles_x * effi_cdiv(a.h, 4 * MR);
     hipLaunchKernelGGL((conv2d_mfma_v2_kernel<5, NT, MR, EFFI_EPI_PLAIN, 4, false, ALIGNED, 2>), dim3(ntiles), dim3(256), 0, st, a,
                        tiles_x, ntiles);
-    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+    return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
 
 template <int NT>
@@ -1704,14 +1693,14 @@ static int launch_bf16x3(const Conv2dArgs& a, hipStream_t st) {
         if (mr == 4) hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 4, EPI, ZB, true>), grid, dim3(256), 0, st, a, tiles_x, ntiles);
         else if (mr == 2) hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 2, EPI, ZB, true>), grid, dim3(256), 0, st, a, tiles_x, ntiles);
         else hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 1, EPI, ZB, true>), grid, dim3(256), 0, st, a, tiles_x, ntiles);
-        return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+        return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
     }
     const int tiles_x = (int)cols, ntiles = tiles_x * effi_cdiv(a.h, 4 * mr);
     const dim3 grid(ntiles, (unsigned)planes);
     if (mr == 4) hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 4, EPI, ZB>), grid, dim3(256), 0, st, a, tiles_x, ntiles);
     else if (mr == 2) hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 2, EPI, ZB>), grid, dim3(256), 0, st, a, tiles_x, ntiles);
     else hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 1, EPI, ZB>), grid, dim3(256), 0, st, a, tiles_x, ntiles);
-    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+    return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
 
 template <int EPI>
@@ -1740,14 +1729,14 @@ static int launch_bf16x3_pair(const Conv2dArgs& a0, const Conv2dArgs& a1, hipStr
     if (mr == 4 && a0.w >= 512) {
         const int tiles_x = effi_cdiv(a0.w, 64), ntiles = tiles_x * effi_cdiv(a0.h, 4);
         hipLaunchKernelGGL((conv2d_k3_bf16x3_pair_kernel<NT, 4, true>), dim3(ntiles, 2), dim3(256), 0, st, a0, a1, tiles_x, ntiles);
-        return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+        return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
     }
     const int tiles_x = (int)cols, ntiles = tiles_x * effi_cdiv(a0.h, 4 * mr);
     const dim3 grid(ntiles, 2);
     if (mr == 4) hipLaunchKernelGGL((conv2d_k3_bf16x3_pair_kernel<NT, 4, false>), grid, dim3(256), 0, st, a0, a1, tiles_x, ntiles);
     else if (mr == 2) hipLaunchKernelGGL((conv2d_k3_bf16x3_pair_kernel<NT, 2, false>), grid, dim3(256), 0, st, a0, a1, tiles_x, ntiles);
     else hipLaunchKernelGGL((conv2d_k3_bf16x3_pair_kernel<NT, 1, false>), grid, dim3(256), 0, st, a0, a1, tiles_x, ntiles);
-    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+    return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
 
 static int fill_bf16x3_plain(Conv2dArgs& a, const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
@@ -1763,7 +1752,7 @@ static int fill_bf16x3_plain(Conv2dArgs& a, const float* const* srcs, const int*
     }
     a.kgroups = (a.cin + 3) / 4;
     a.zeros = effi_zero_page();
-    if (!a.zeros) return EFFI_ERR_LAUNCH;
+    if (!a.zeros) return EFFI_ERR_WORKSPACE;
     a.wpack = reinterpret_cast<const float*>(wpack_bf16);
     a.bias = bias;
     a.cout = cout;
@@ -1820,7 +1809,7 @@ extern "C" int effi_conv2d_k3_bf16x3_f32(const float* const* srcs, const int* sr
     }
     a.kgroups = (a.cin + 3) / 4;
     a.zeros = effi_zero_page();
-    if (!a.zeros) return EFFI_ERR_LAUNCH;
+    if (!a.zeros) return EFFI_ERR_WORKSPACE;
     a.wpack = reinterpret_cast<const float*>(wpack_bf16);
     a.bias = bias;
     a.cout = cout;
@@ -1881,7 +1870,7 @@ extern "C" int effi_conv2d_k3_k1_bf16x3_f32(const float* const* srcs, const int*
     }
     a.kgroups = relu1 ? 1 : 0;
     a.zeros = effi_zero_page();
-    if (!a.zeros) return EFFI_ERR_LAUNCH;
+    if (!a.zeros) return EFFI_ERR_WORKSPACE;
     a.wpack = reinterpret_cast<const float*>(wpack_bf16);
     a.bias = bias;
     a.cout = cout1;
@@ -1928,7 +1917,7 @@ extern "C" int effi_conv2d_k3_k1_up2x_bf16x3_f32(const float* const* srcs, const
     }
     a.kgroups = 1;                          // ReLU between the 3x3 and the 1x1 convolution (models/update.py:110)
     a.zeros = effi_zero_page();
-    if (!a.zeros) return EFFI_ERR_LAUNCH;
+    if (!a.zeros) return EFFI_ERR_WORKSPACE;
     a.wpack = reinterpret_cast<const float*>(wpack_bf16);
     a.bias = bias;
     a.cout = cout1;
@@ -1973,7 +1962,7 @@ extern "C" int effi_conv3d_k3s1_bf16x3_f32(const float* const* srcs, const int* 
     if (a.cin & 7) return EFFI_ERR_UNSUPPORTED;            // an octet of (plane, channel) lies in one plane
     a.kgroups = 0;
     a.zeros = effi_zero_page();
-    if (!a.zeros) return EFFI_ERR_LAUNCH;
+    if (!a.zeros) return EFFI_ERR_WORKSPACE;
     a.wpack = reinterpret_cast<const float*>(wpack_bf16);
     a.bias = bias;
     a.cout = cout;
@@ -2028,7 +2017,7 @@ static int launch_roll(const Conv2dArgs& a, hipStream_t st, const Conv2dArgs* pa
         if (mr == 4) hipLaunchKernelGGL((conv3d_roll_bf16x3_kernel<NOCT, NT, 4>), grid, dim3(256), 0, st, a, cols, (int)tiles, zt);
         else hipLaunchKernelGGL((conv3d_roll_bf16x3_kernel<NOCT, NT, 2>), grid, dim3(256), 0, st, a, cols, (int)tiles, zt);
     }
-    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+    return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
 
 static int fill_roll_args(Conv2dArgs& a, const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
@@ -2046,7 +2035,7 @@ static int fill_roll_args(Conv2dArgs& a, const float* const* srcs, const int* sr
     if (n_src == 1) a.src[1] = a.src[0];
     a.kgroups = 0;
     a.zeros = effi_zero_page();
-    if (!a.zeros) return EFFI_ERR_LAUNCH;
+    if (!a.zeros) return EFFI_ERR_WORKSPACE;
     a.wpack = reinterpret_cast<const float*>(wpack_bf16);
     a.bias = bias;
     a.cout = cout;
@@ -2099,7 +2088,7 @@ extern "C" int effi_deconv3d_k3s2_bf16x3_f32(const float* in, int cin, const voi
     a.bias = bias;
     a.skip = skip;
     a.zeros = effi_zero_page();
-    if (!a.zeros) return EFFI_ERR_LAUNCH;
+    if (!a.zeros) return EFFI_ERR_WORKSPACE;
     a.out = out;
     a.cin = cin;
     a.cout = cout;
@@ -2128,7 +2117,7 @@ extern "C" int effi_deconv3d_k3s2_bf16x3_f32(const float* in, int cin, const voi
         else { if (half) EFFI_DC(1, false, true); else EFFI_DC(1, false, false); }
     }
 #undef EFFI_DC
-    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+    return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
 
 extern "C" int effi_conv2d_c1k7_relu_f32(const float* in, const float* weight, const float* bias, int cout, int h,

@@ -396,7 +396,7 @@ int launch_conv_z(const SrcSet& s, int cin, const float* wgt, const float* bias,
     else
         hipLaunchKernelGGL((conv3d_k3_kernel<COUT_T, SZ, SXY, ZPT, false>), grid, dim3(256), 0, st, s, cin, wgt, bias, cout, D, h, w,
                            Do, ho, wo, relu, skip, out);
-    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+    return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
 
 // Output z-slices per thread: 4 (2 for stride 2) amortises the z halo of the LDS tile; low-resolution layers
@@ -468,7 +468,7 @@ int launch_conv_pair(const Conv3dCall& a, const Conv3dCall& b, int cin, int D, i
     const int ho = (h - 1) / SXY + 1, wo = (w - 1) / SXY + 1;
     const dim3 grid(effi_cdiv(wo, TX) * effi_cdiv(ho, TY) * effi_cdiv(D, ZPT), 2);
     hipLaunchKernelGGL((conv3d_k3_pair_kernel<8, 1, SXY, ZPT>), grid, dim3(256), 0, st, a, b, cin, 8, D, h, w, D, ho, wo, relu);
-    return hipGetLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+    return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
 }  // namespace
 

@@ -4,6 +4,13 @@
 Host side: pair.txt / cam.txt parsing, intrinsics scaling, the per-stage projection dictionary, the inverse-depth samples.
 Device side: one kernel per view for /255 + bilinear resize + HWC -> CHW (``ops.image_prepare``); the sample's tensors are
 returned on ``device`` (default "cuda"), ready for the model.  Without the GPU / HIP library ``__getitem__`` raises.
+
+DataLoader workers (the reference's drivers use ``num_workers=4`` / ``8``, test_dtu_dypcd.py:406, test_tank.py:209) are forked
+processes that must not touch the GPU: inside a worker -- or with ``device="host"`` -- ``__getitem__`` stays on the host and
+returns the decoded bytes (``imgs_u8``: list over views of uint8 [h,w,3]; ``imgs_hw`` [N,2] per-view resize target;
+``std_hw`` [2] the sample's size) instead of ``imgs``; ``prepare_sample(sample)`` in the main process then runs the image
+kernel and puts ``imgs`` in place (one line in the driver's loop).  Default collation is supported
+(batch dimension in front of every entry).
 """
 import os
 
@@ -90,6 +97,41 @@ def decode_image(filename):
     return arr
 
 
+def host_only(device):
+    """True when __getitem__ must not touch the GPU: explicit host mode, or a DataLoader worker process."""
+    from torch.utils.data import get_worker_info
+    return device in (None, "host") or get_worker_info() is not None
+
+
+def prepare_sample(sample, device="cuda"):
+    """Device half of ``__getitem__`` for samples produced on the host (``host_only``): ``imgs_u8`` / ``imgs_hw`` / ``std_hw``
+    -> ``imgs`` [N,3,H,W] (or [B,N,3,H,W] for a default-collated batch) on ``device``; the other entries pass through.  A sample
+    that already holds ``imgs`` is returned unchanged."""
+    if "imgs_u8" not in sample:
+        return sample
+    out = {k: v for k, v in sample.items() if k not in ("imgs_u8", "imgs_hw", "std_hw")}
+    raws, hw, std = sample["imgs_u8"], sample["imgs_hw"], sample["std_hw"]
+    batched = std.dim() == 2
+    if not batched:
+        raws, hw, std = [r.unsqueeze(0) for r in raws], hw.unsqueeze(0), std.unsqueeze(0)
+    B, N = std.shape[0], len(raws)
+    if any((std[b] != std[0]).any() for b in range(B)):
+        raise ValueError("prepare_sample: the samples of a batch must share their size")
+    s_h, s_w = int(std[0, 0]), int(std[0, 1])
+    imgs = torch.empty(B, N, 3, s_h, s_w, device=device, dtype=torch.float32)
+    with torch.cuda.device(imgs.device):
+        for b in range(B):
+            for i in range(N):
+                dev_raw = raws[i][b].contiguous().to(imgs.device, non_blocking=True)
+                h1, w1 = int(hw[b, i, 0]), int(hw[b, i, 1])
+                if (h1, w1) == (s_h, s_w):
+                    ops.image_prepare(dev_raw, s_h, s_w, out=imgs[b, i])
+                else:       # the reference resizes twice (general_eval.py:160-166)
+                    imgs[b, i] = ops.resize_planar(ops.image_prepare(dev_raw, h1, w1), s_h, s_w)
+    out["imgs"] = imgs if batched else imgs[0]
+    return out
+
+
 class MVSDataset(Dataset):
     def __init__(self, datapath, listfile, mode, nviews, ndepths=192, interval_scale=1.06, dispmaxfirst="first", **kwargs):
         super().__init__()
@@ -137,6 +179,8 @@ class MVSDataset(Dataset):
         scan, ref_view, src_views, scene_name = self.metas[idx]
         view_ids = [ref_view] + src_views[:self.nviews - 1]
         imgs, proj_matrices, depth_values = None, [], None
+        on_host = host_only(self.device)
+        raws, sizes = [], []
         for i, vid in enumerate(view_ids):
             img_filename, cam_filename = self.view_paths(scan, vid)
             raw = decode_image(img_filename)
@@ -150,15 +194,20 @@ class MVSDataset(Dataset):
             if i == 0 and not self.fix_wh:
                 self._std = (h1, w1)
             s_h, s_w = self._std
-            dev_raw = torch.from_numpy(raw).to(self.device, non_blocking=True)
-            if imgs is None:
-                imgs = torch.empty(len(view_ids), 3, s_h, s_w, device=self.device, dtype=torch.float32)
-            if (h1, w1) == (s_h, s_w):
-                ops.image_prepare(dev_raw, s_h, s_w, out=imgs[i])
+            if on_host:
+                raws.append(torch.from_numpy(raw))
+                sizes.append((h1, w1))
             else:
-                # the reference resizes twice (to the view's own size, then to the standard one): same two passes here
-                first = ops.image_prepare(dev_raw, h1, w1)
-                imgs[i] = ops.resize_planar(first, s_h, s_w)
+                dev_raw = torch.from_numpy(raw).to(self.device, non_blocking=True)
+                if imgs is None:
+                    imgs = torch.empty(len(view_ids), 3, s_h, s_w, device=self.device, dtype=torch.float32)
+                if (h1, w1) == (s_h, s_w):
+                    ops.image_prepare(dev_raw, s_h, s_w, out=imgs[i])
+                else:
+                    # the reference resizes twice (to the view's own size, then to the standard one): same two passes here
+                    first = ops.image_prepare(dev_raw, h1, w1)
+                    imgs[i] = ops.resize_planar(first, s_h, s_w)
+            if (h1, w1) != (s_h, s_w):
                 intrinsics[0, :] *= 1.0 * s_w / w1
                 intrinsics[1, :] *= 1.0 * s_h / h1
             proj_mat = np.zeros((2, 4, 4), dtype=np.float32)
@@ -167,7 +216,12 @@ class MVSDataset(Dataset):
             proj_matrices.append(proj_mat)
             if i == 0:
                 depth_values = inverse_depth_samples(depth_min, depth_interval, self.ndepths, self.dispmaxfirst)
-        return {"imgs": imgs,
-                "proj_matrices": stage_projections(np.stack(proj_matrices)),
-                "depth_values": torch.from_numpy(depth_values.copy()).contiguous().float(),
-                "filename": scan + "/{}/" + "{:0>8}".format(view_ids[0]) + "{}"}
+        sample = {"proj_matrices": stage_projections(np.stack(proj_matrices)),
+                  "depth_values": torch.from_numpy(depth_values.copy()).contiguous().float(),
+                  "filename": scan + "/{}/" + "{:0>8}".format(view_ids[0]) + "{}"}
+        if on_host:
+            sample.update(imgs_u8=raws, imgs_hw=torch.tensor(sizes, dtype=torch.int64),
+                          std_hw=torch.tensor(self._std, dtype=torch.int64))
+        else:
+            sample["imgs"] = imgs
+        return sample

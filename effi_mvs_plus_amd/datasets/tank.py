@@ -7,7 +7,7 @@ import torch
 from torch.utils.data import Dataset
 
 from .. import ops
-from .general_eval import decode_image, parse_pair_file, stage_projections
+from .general_eval import decode_image, host_only, parse_pair_file, prepare_sample, stage_projections  # noqa: F401
 
 STAGE_SCALES = {"stage0": 0.0625, "stage1": 0.125, "stage2": 0.25, "stage3": 0.5, "stage4": 1.0}       # tank.py:161-175
 INTERMEDIATE = ["Family", "Francis", "Horse", "Lighthouse", "M60", "Panther", "Playground", "Train"]
@@ -67,11 +67,16 @@ class MVSDataset(Dataset):
         view_ids = [ref_view] + src_views[:self.n_views - 1]
         img_w, img_h = self.image_sizes[scan]
         cams = "cams_1" if split in ("intermediate", "advanced") else "cams"
-        imgs = torch.empty(len(view_ids), 3, NET_SIZE[1], NET_SIZE[0], device=self.device, dtype=torch.float32)
+        on_host = host_only(self.device)          # DataLoader worker / device="host": see general_eval.prepare_sample
+        imgs = None if on_host else torch.empty(len(view_ids), 3, NET_SIZE[1], NET_SIZE[0], device=self.device, dtype=torch.float32)
+        raws = []
         proj_matrices, depth_values = [], None
         for i, vid in enumerate(view_ids):
             raw = decode_image(os.path.join(self.datapath, split, scan, f"images/{vid:08d}.jpg"))
-            ops.image_prepare(torch.from_numpy(raw).to(self.device, non_blocking=True), NET_SIZE[1], NET_SIZE[0], out=imgs[i])
+            if on_host:
+                raws.append(torch.from_numpy(raw))
+            else:
+                ops.image_prepare(torch.from_numpy(raw).to(self.device, non_blocking=True), NET_SIZE[1], NET_SIZE[0], out=imgs[i])
             intrinsics, extrinsics, depth_min_, depth_max_ = self.read_cam_file(
                 os.path.join(self.datapath, split, scan, f"{cams}/{vid:08d}_cam.txt"))
             intrinsics[0] *= self.img_wh[0] / img_w
@@ -82,7 +87,12 @@ class MVSDataset(Dataset):
             proj_matrices.append(proj_mat)
             if i == 0:
                 depth_values = np.linspace(1 / depth_max_, 1 / depth_min_, self.ndepths, dtype=np.float32)
-        return {"imgs": imgs,
-                "proj_matrices": stage_projections(np.stack(proj_matrices), STAGE_SCALES),
-                "depth_values": torch.from_numpy(depth_values.copy()).contiguous().float(),
-                "filename": scan + "/{}/" + "{:0>8}".format(view_ids[0]) + "{}"}
+        sample = {"proj_matrices": stage_projections(np.stack(proj_matrices), STAGE_SCALES),
+                  "depth_values": torch.from_numpy(depth_values.copy()).contiguous().float(),
+                  "filename": scan + "/{}/" + "{:0>8}".format(view_ids[0]) + "{}"}
+        if on_host:
+            sample.update(imgs_u8=raws, imgs_hw=torch.tensor([[NET_SIZE[1], NET_SIZE[0]]] * len(view_ids), dtype=torch.int64),
+                          std_hw=torch.tensor([NET_SIZE[1], NET_SIZE[0]], dtype=torch.int64))
+        else:
+            sample["imgs"] = imgs
+        return sample

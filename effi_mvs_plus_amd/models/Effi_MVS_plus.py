@@ -40,6 +40,7 @@ def depth_to_disp(depth, min_depth, max_depth):
     return (1 / depth - lo) / ((hi - lo) + 1e-10)
 
 
+@ops.on_tensor_device
 def pro_bilinear_sampler(pro, depth_sample, depth_min, depth_max):
     """1-D linear lookup of per-pixel D-vectors at ``depth_sample`` (reference: Effi_MVS_plus.py:118-134).
 
@@ -57,6 +58,7 @@ def pro_bilinear_sampler(pro, depth_sample, depth_min, depth_max):
     return _stack(outs)
 
 
+@ops.on_tensor_device
 def upsample_depth(depth, mask, ratio=8):
     """Convex-combination upsampling [N,1,H,W] x [N,9*r*r,H,W] -> [N,r*H,r*W] (reference: :167-178); r = 2."""
     if ratio != 2:
@@ -84,6 +86,8 @@ class PixelwiseNet2d(nn.Sequential):
         t += [self[3].weight, self[3].bias]
         return ops.pixelwise_net(entropy, self._cache.get(t, lambda: packing.pack_pixelwise_net(self)))
 
+    @ops.on_tensor_device
+
     def forward(self, x):
         n, c, h, w = x.shape
         return self.run(x.reshape(n * c, h, w).contiguous()).view(n, c, h, w)
@@ -110,6 +114,8 @@ class DepthNet(nn.Module):
         return {"depth": d, "photometric_confidence": conf, "view_weights": weights, "reg_volume": reg[0],
                 "volume": volume.unsqueeze(0)}
 
+    @ops.on_tensor_device
+
     def forward(self, features, proj_matrices, depth_values, num_depth, cost_regularization, pixel_wise_net, G=8):
         assert len(features) == proj_matrices.shape[1], "Different number of images and projection matrices"
         assert depth_values.shape[1] == num_depth, "depth_values.shape[1]:{}  num_depth:{}".format(
@@ -131,6 +137,8 @@ class DepthNet(nn.Module):
 class GetCost_initvolume(nn.Module):
     def __init__(self):
         super().__init__()
+
+    @ops.on_tensor_device
 
     def forward(self, depth_values, features, proj_matrices, depth_interval, depth_max, depth_min, view_weights,
                 CostNum=4, Inverse=True, G=8, iter=1, inter_iter=[1, 1, 1, 1]):
@@ -185,6 +193,8 @@ class GetCost(nn.Module):
         lookup.conv1x1 = lookup_conv1x1 if CostNum in (2, 3, 4) else None
         lookup.encoder_inputs = lookup_encoder_inputs if CostNum == 3 else None
         return lookup
+
+    @ops.on_tensor_device
 
     def forward(self, depth_values, pro, features, proj_matrices, depth_interval, depth_max, depth_min, view_weights,
                 CostNum=4, Inverse=True, G=8, depth_max_cur_volume=0, depth_min_cur_volume=0, iter=1,
@@ -378,6 +388,8 @@ class Effi_MVS_plus(nn.Module):
             out["intermediates"] = inter
         return out
 
+    @ops.on_tensor_device
+
     def forward_hot(self, features, cnet_depth, proj_matrices, depth_values, want_intermediates=False):
         """The accelerated path: everything of ``forward`` after the FPN (reference: Effi_MVS_plus.py:437-568).
 
@@ -397,6 +409,8 @@ class Effi_MVS_plus(nn.Module):
         if want_intermediates:
             res["intermediates"] = {k: _stack([o["intermediates"][k] for o in outs]) for k in outs[0]["intermediates"]}
         return res
+
+    @ops.on_tensor_device
 
     def forward(self, imgs, proj_matrices, depth_values):
         # kept for callers that use it like the reference does (Effi_MVS_plus.py:423)

@@ -105,6 +105,8 @@ class Conv3d(nn.Module):
         w, b = self._packed()
         return ops.conv3d_k3(srcs, w, b, self.out_channels, stride=_triple(self.conv.stride), relu=self.relu, skip=skip)
 
+    @ops.on_tensor_device
+
     def forward(self, x):
         return _stack([self.run([x[i].contiguous()]) for i in range(x.shape[0])])
 
@@ -144,6 +146,8 @@ class Deconv3d(nn.Module):
         w, b = self._packed()
         return ops.deconv3d_k3(x, w, b, self.out_channels, sz=st[0], relu=self.relu, skip=skip)
 
+    @ops.on_tensor_device
+
     def forward(self, x):
         return _stack([self.run(x[i].contiguous()) for i in range(x.shape[0])])
 
@@ -160,6 +164,8 @@ class ConvBnReLU(nn.Module):
         super().__init__()
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=pad, bias=False)
         self.bn = nn.BatchNorm2d(out_channels)
+
+    @ops.on_tensor_device
 
     def forward(self, x):
         return F.relu(self.bn(self.conv(x)), inplace=True)
@@ -181,6 +187,8 @@ class Conv2d(nn.Module):
         else:
             self.bn = nn.BatchNorm2d(out_channels, momentum=bn_momentum)
         self.relu = relu
+
+    @ops.on_tensor_device
 
     def forward(self, x):
         x = self.conv(x)
@@ -288,6 +296,8 @@ class P_1to8_FeatureNet_Fast(nn.Module):
         outputs["stage3"] = self.out3(top)
         return outputs
 
+    @ops.on_tensor_device
+
     def forward(self, x):
         if self.training:
             return self.forward_torch(x)
@@ -328,6 +338,8 @@ class CostRegNet_2_sample_FPN3D_Fast(nn.Module):
         wp, _ = self._prob_cache.get([self.prob.weight], lambda: packing.pack_conv3d(self.prob, None))
         prob = ops.conv3d_k3([pro], wp, None, 1, stride=(1, 1, 1), relu=False)
         return prob, pro
+
+    @ops.on_tensor_device
 
     def forward(self, x):
         outs = [self.run(x[i].contiguous()) for i in range(x.shape[0])]
@@ -387,6 +399,8 @@ class cost_up_small(nn.Module):
         oa, ob = ops.deconv3d_k3_pair(c1a, w2a, b2a, c1b, w2b, b2b, 1, sz=1, relu=True)
         return (oa, c1a), (ob, c1b)
 
+    @ops.on_tensor_device
+
     def forward(self, x, IGEV_cost):
         outs = [self.run(x[i].contiguous(), IGEV_cost[i].contiguous()) for i in range(x.shape[0])]
         return _stack([o[0] for o in outs]), _stack([o[1] for o in outs])
@@ -395,6 +409,7 @@ class cost_up_small(nn.Module):
 # =============================================================================================
 # a1: homography warp (reference: models/module.py:303-344)
 # =============================================================================================
+@ops.on_tensor_device
 def homo_warping_new(src_fea, src_proj, ref_proj, depth_values):
     """src_fea [B,C,H,W]; src_proj/ref_proj [B,4,4]; depth_values [B,D] or [B,D,H,W] -> [B,C,D*H,W].
 

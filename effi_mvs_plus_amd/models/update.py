@@ -52,6 +52,8 @@ class DepthHead(nn.Module):
         w, b = _pack(self._c2, self.conv2)
         return ops.conv2d([hidden], w, b, 1, 3, epilogue=ops.EPI_HEAD, aux0=inv_depth, disp_range=disp_range)
 
+    @ops.on_tensor_device
+
     def forward(self, x_d, act_fn=torch.tanh):
         _require_eval(self)
         w, b = _pack(self._c2, self.conv2)
@@ -90,6 +92,8 @@ class ConvGRU(nn.Module):
         z, rh = ops.conv2d([h] + xs, wzr, bzr, 2 * hd, 3, epilogue=ops.EPI_GRU_ZR, aux0=h, out0=z_buf, out1=rh_buf)
         wq, bq = _pack(self._cq, self.convq)
         return ops.conv2d([rh] + xs, wq, bq, hd, 3, epilogue=ops.EPI_GRU_Q, aux0=h, aux1=z, out0=out)
+
+    @ops.on_tensor_device
 
     def forward(self, h, *x_list):
         _require_eval(self)
@@ -167,6 +171,8 @@ class ProjectionInput(nn.Module):
         mix = ops.conv2d([cor, dfm], w, b, cmix, 3, act=ops.ACT_NONE, out0=g("mix"))
         w, b = _pack(self._caches["c"], self.convc)
         return ops.conv2d([mix, context], w, b, hd, 1, act=ops.ACT_RELU, out0=g("enc"))
+
+    @ops.on_tensor_device
 
     def forward(self, disp, cost, context):
         _require_eval(self)
@@ -270,6 +276,8 @@ class BasicUpdateBlock(nn.Module):
             depth_list.append(depth)
             mask_list.append(mask if want_mask else inv_depth)
         return net, mask_list, inv_list, depth_list
+
+    @ops.on_tensor_device
 
     def forward(self, net, depth_cost_func, inv_depth, context, seq_len=4, scale_inv_depth=None):
         _require_eval(self)

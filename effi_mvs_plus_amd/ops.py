@@ -6,7 +6,9 @@ stream.  CPU tensors raise: there is no fallback path.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import os
+import threading
 
 import torch
 
@@ -82,11 +84,44 @@ def _call(key, work, fn, *args):
     return rc
 
 
+# Caller-owned per-device workspace of the C ABI (include/effi_mvs_hip.h: effi_workspace_bytes / effi_set_workspace): a small
+# zero-filled block per device ordinal, allocated here through torch the first time a tensor of that device reaches an op and
+# kept alive for the life of the process.  The library itself allocates nothing.
+_WORKSPACES = {}
+_WS_LOCK = threading.Lock()
+
+
+def ensure_workspace(index):
+    """Register the zero-filled workspace of device ``index`` with the library (idempotent)."""
+    if index in _WORKSPACES:
+        return
+    with _WS_LOCK:
+        if index in _WORKSPACES:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            raise EffiLibraryError(f"cuda:{index}: the device's workspace must be registered before stream capture starts "
+                                   "(run one pass eagerly, or call ops.ensure_workspace(index), before capturing)")
+        L = _lib.lib()
+        n = int(L.effi_workspace_bytes())
+        with torch.cuda.device(index):
+            ws = torch.zeros((n + 3) // 4, device=torch.device("cuda", index), dtype=torch.float32)
+            torch.cuda.current_stream().synchronize()       # zero-filled before ANY stream of the device can read it
+        check(L.effi_set_workspace(index, C.c_void_p(ws.data_ptr()), n), "effi_set_workspace")
+        _WORKSPACES[index] = ws
+
+
 def _t(x: torch.Tensor, name: str, contiguous=True) -> torch.Tensor:
     if not isinstance(x, torch.Tensor):
         raise TypeError(f"{name}: expected a tensor")
     if not x.is_cuda:
         raise EffiLibraryError(f"{name}: CPU tensor passed to the HIP path (no CPU fallback exists)")
+    idx = x.device.index
+    if idx != torch._C._cuda_getDevice():
+        # kernels are enqueued on the CURRENT device's stream: a tensor of another device would be a wild pointer there
+        raise EffiLibraryError(f"{name}: tensor lives on cuda:{idx} but the current device is cuda:{torch._C._cuda_getDevice()}; "
+                               "call inside `with torch.cuda.device(tensor.device):` (the public modules do this themselves)")
+    if idx not in _WORKSPACES:
+        ensure_workspace(idx)
     if x.dtype != torch.float32:
         raise TypeError(f"{name}: fp32 only (got {x.dtype}); the reference path is fp32 (models/module.py:318)")
     if contiguous and not x.is_contiguous():
@@ -96,6 +131,37 @@ def _t(x: torch.Tensor, name: str, contiguous=True) -> torch.Tensor:
 
 def _p(x):
     return C.c_void_p(x.data_ptr()) if x is not None else C.c_void_p(0)
+
+
+def _first_cuda_tensor(obj, depth=0):
+    if isinstance(obj, torch.Tensor):
+        return obj if obj.is_cuda else None
+    if depth < 3:
+        if isinstance(obj, dict):
+            obj = obj.values()
+        if isinstance(obj, (list, tuple)) or type(obj).__name__ == "dict_values":
+            for o in obj:
+                t_ = _first_cuda_tensor(o, depth + 1)
+                if t_ is not None:
+                    return t_
+    return None
+
+
+def on_tensor_device(fn):
+    """Decorator of the public entry points (module ``forward``s, the reference-named functions): run with the device of the
+    first CUDA tensor among the arguments as the current device, as stock PyTorch operators do.  The kernels are enqueued on the
+    current device's stream, so a model on cuda:1 called while cuda:0 is current would otherwise launch against foreign
+    pointers.  (Replicas of nn.DataParallel already run under their own device.)"""
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        t_ = _first_cuda_tensor(args)
+        if t_ is None and kwargs:
+            t_ = _first_cuda_tensor(kwargs)
+        if t_ is None or t_.device.index == torch._C._cuda_getDevice():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(t_.device):
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 # Independent kernel chains (the mask head, the preparation of the stages' GRU inputs, the pyramid passes of the odd views) CAN

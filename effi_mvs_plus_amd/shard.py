@@ -52,14 +52,15 @@ def run_sharded(items: Sequence, forward: Callable, dst: int = 0):
     both maps to ``dst``.  Returns {"depth": [n,H,W], "confidence": [n,h,w]} on dst, None elsewhere."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
+    if len(items) < world:
+        # checked on EVERY rank before any forward: raising only on the empty ranks would leave the others waiting in the gather
+        raise ValueError(f"more ranks ({world}) than reference views ({len(items)})")
     mine = shard_views(items, rank, world)
     depths, confs = [], []
     for it in mine:
         d, c = forward(it)
         depths.append(d)
         confs.append(c)
-    if not mine:
-        raise ValueError("more ranks than reference views")
     d_all = gather_maps(torch.stack(depths), len(items), dst)
     c_all = gather_maps(torch.stack(confs), len(items), dst)
     if rank != dst:

@@ -24,7 +24,8 @@ extern "C" {
 #define EFFI_OK               0
 #define EFFI_ERR_BADARG      -1   /* null pointer, non-positive size, unsupported channel count ... */
 #define EFFI_ERR_UNSUPPORTED -2   /* shape outside what the kernels are instantiated for */
-#define EFFI_ERR_LAUNCH      -3   /* hipGetLastError() != hipSuccess after the launch */
+#define EFFI_ERR_LAUNCH      -3   /* hipPeekAtLastError() != hipSuccess after the launch (the error is left in place for the host framework) */
+#define EFFI_ERR_WORKSPACE   -4   /* the current device has no workspace registered (effi_set_workspace) */
 
 #define EFFI_MAX_VIEWS 12         /* source views per call (T&T script uses num_view=11 -> 10 sources) */
 #define EFFI_MAX_SRC    3         /* concatenated input tensors of one 2-D / 3-D convolution */
@@ -46,6 +47,24 @@ typedef void* effi_stream_t;
 
 int effi_version(void);
 const char* effi_error_string(int code);
+
+/* ---- caller-owned per-device workspace ----------------------------------------------------------
+ * The library allocates nothing.  The split-precision convolution kernels read their zero padding from a small
+ * block of device memory instead of masking every load; the caller provides that block once per device:
+ *   effi_workspace_bytes()            bytes a device's workspace must hold (a constant of this build);
+ *   effi_set_workspace(dev, p, n)     registers `p` (device memory of device `dev`, >= effi_workspace_bytes() bytes,
+ *                                     ZERO-FILLED by the caller and never written by the library) for ordinal `dev`;
+ *                                     p = NULL unregisters.  The caller keeps ownership and must keep it alive while
+ *                                     kernels of that device may run.  Thread-safe against concurrent launches on
+ *                                     other devices (one slot per device ordinal, up to EFFI_MAX_DEVICES).
+ *   effi_get_workspace(dev)           the registered pointer or NULL.
+ * Entry points that need it look up the slot of the CURRENT device (hipGetDevice) and return EFFI_ERR_WORKSPACE
+ * when it is empty: nothing is allocated lazily, so a first call inside stream capture or from a second device of
+ * the process (nn.DataParallel, test_dtu_dypcd.py:418) is safe. */
+#define EFFI_MAX_DEVICES 64
+long effi_workspace_bytes(void);
+int effi_set_workspace(int device, void* workspace, long bytes);
+const void* effi_get_workspace(int device);
 
 /* ---- K11: projection algebra ------------------------------------------------------------------
  * models/Effi_MVS_plus.py:34-37,217-220 (K.[R|t]) and models/module.py:314-316 (src . ref^-1).

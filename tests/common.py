@@ -44,18 +44,26 @@ def stats(got, want):
             "p99": torch.quantile(diff.flatten()[:: max(1, diff.numel() // 1_000_000)], 0.99).item()}
 
 
-def check_close(name, got, want, rtol=1e-4, atol=1e-5, frac_ok=1.0):
+def check_close(name, got, want, rtol=1e-4, atol=1e-5, frac_ok=1.0, outlier_atol=None):
     """allclose with a readable report; ``frac_ok`` < 1 tolerates a small fraction of outliers
-    (discontinuities: floor / clamp / out-of-bounds flips)."""
+    (discontinuities: floor / clamp / out-of-bounds flips).  The excluded set is not ignored: its size and its largest error
+    are printed and the largest error is bounded by ``outlier_atol`` (default: the peak of ``want`` -- a flip can move a value
+    across the data's own range, garbage cannot hide behind the fraction)."""
     assert tuple(got.shape) == tuple(want.shape), f"{name}: shape {tuple(got.shape)} vs {tuple(want.shape)}"
     s = stats(got, want)
     g, w = got.detach().double().cpu(), want.detach().double().cpu()
-    ok = ((g - w).abs() <= atol + rtol * w.abs())
+    err = (g - w).abs()
+    ok = (err <= atol + rtol * w.abs())
     frac = ok.double().mean().item()
+    n_out = int((~ok).sum())
+    out_max = float(err[~ok].max()) if n_out else 0.0
     print(f"[parity] {name:42s} max_abs={s['max_abs']:.3e} mean_abs={s['mean_abs']:.3e} p99={s['p99']:.3e} "
-          f"peak={s['ref_max']:.3e} within_tol={frac:.6f}")
+          f"peak={s['ref_max']:.3e} within_tol={frac:.6f} excluded={n_out} excluded_max_abs={out_max:.3e}")
     assert torch.isfinite(g).all(), f"{name}: non-finite values"
     assert frac >= frac_ok, f"{name}: only {frac:.6f} of elements within rtol={rtol} atol={atol} (need {frac_ok})"
+    bound = s["ref_max"] + atol if outlier_atol is None else outlier_atol
+    assert out_max <= bound, f"{name}: an excluded element is off by {out_max:.3e} (bound {bound:.3e})"
+    s["excluded"], s["excluded_max_abs"] = n_out, out_max
     return s
 
 

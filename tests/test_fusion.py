@@ -26,6 +26,39 @@ def _inputs(g, tag):
     return c, d[0][None, None], d[1:][None, :, None], cams[0][None], cams[1:][None], conf
 
 
+def test_oracle_elementwise_products_equal_the_batched_matmul_form():
+    """bench.py's PyTorch-ROCm fusion baseline evaluates the per-pixel 3x3 / 4x4 products element-wise (no 19 M-batch GEMM);
+    it must be the same function as the reference's broadcast ``@`` form that the golden vectors pin."""
+    g = load_golden("g12_fusion.npz")
+    c, ref_depth, src, ref_cam, src_cams, conf = _inputs(g, "a")
+    args = (ref_depth, src, ref_cam, src_cams, conf, float(c["prob"]), int(c["dh"]), float(c["dist"]), float(c["dfilt"]), bool(c["relative"]))
+    with torch.no_grad():
+        a = O.fusion_dynamic_filter(*args)
+        with O.elementwise_mm():
+            b = O.fusion_dynamic_filter(*args)
+    assert not O.ELEMENTWISE_MM
+    assert torch.allclose(a["reproj_xyd"], b["reproj_xyd"], rtol=1e-5, atol=2e-3)
+    assert torch.allclose(a["depth"], b["depth"], rtol=1e-6, atol=1e-3)
+    assert (a["mask"] == b["mask"]).float().mean().item() >= 0.999
+
+
+def test_literal_syncs_do_not_change_values():
+    """The oracle's literal mode re-enables the reference's NaN probe and torch.unique assert (34 host syncs per view on a GPU):
+    same values, counted."""
+    from common import build_model
+    net, sd = build_model("8,8,8", seed=3)
+    imgs, pm, dv = synth.synth_sample(64, 96, 4, seed=2)
+    with torch.no_grad():
+        feats = [O.feature_net(sd, "feature", imgs[:, v]) for v in range(4)]
+        ctx = O.feature_net(sd, "cnet_depth", imgs[:, 0])
+        a = O.hot_path(sd, feats, ctx, pm, dv, ndepths=(8, 8, 8))
+        with O.literal_syncs():
+            b = O.hot_path(sd, feats, ctx, pm, dv, ndepths=(8, 8, 8))
+        assert O.SYNC_COUNT == 3 * 3 + 22 and not O.LITERAL_SYNCS      # S = 3 sources x 3 stages warps + 22 lookups
+    for x, y in zip(a["depth"], b["depth"]):
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("tag", CASES)
 def test_oracle_matches_reference_vectors(tag):
     g = load_golden("g12_fusion.npz")
@@ -70,8 +103,15 @@ def test_hip_filter_against_reference_vectors_and_oracle(tag):
                                 int(c["dh"]), float(c["dist"]), float(c["dfilt"]), bool(c["relative"]))
     assert tuple(out["depth"].shape) == tuple(g[f"{tag}_depth"].shape) and out["mask"].dtype == torch.bool
     assert torch.equal(out["depth"][0, 0], r["depth"])
-    xyd, _, _ = fusion.get_reproj_dynamic(t(ref_depth, DEV), t(src, DEV), t(ref_cam, DEV), t(src_cams, DEV))
+    xyd, ref_pts, back_pts = fusion.get_reproj_dynamic(t(ref_depth, DEV), t(src, DEV), t(ref_cam, DEV), t(src_cams, DEV))
     assert torch.equal(xyd[0], r["reproj_xyd"])
+    # the two by-product point tensors of misc/fusion.py:117-156 (same shapes; values to fp32 rounding of the element-wise algebra)
+    with torch.no_grad():
+        _, want_ref, want_back = O.fusion_get_reproj_dynamic(ref_depth, src, ref_cam, src_cams)
+    assert tuple(ref_pts.shape) == tuple(want_ref.shape) and tuple(back_pts.shape) == tuple(want_back.shape)
+    check_close(f"{tag} ref_idx_cam", ref_pts, want_ref, rtol=1e-5, atol=1e-3)
+    ok = torch.isfinite(want_back).all(-1).all(-1) & (want_back[..., 2, 0].abs() > 1.0)          # zero-padded samples: 0 * 1/(0+1e-9)
+    check_close(f"{tag} src2ref_idx_cam", back_pts.cpu()[ok], want_back[ok], rtol=1e-4, atol=5e-2, frac_ok=0.999)
 
 
 @pytest.mark.gpu

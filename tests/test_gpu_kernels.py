@@ -691,3 +691,21 @@ def test_cpu_tensor_fails_loudly():
     from effi_mvs_plus_amd._lib import EffiLibraryError
     with pytest.raises(EffiLibraryError):
         ops.view_aggregate(torch.zeros(2, 3, 4, 5), torch.zeros(2, 4, 5))
+
+
+def test_stage1_hypotheses_and_intervals():
+    """effi_stage1_hypotheses_f32 on its own: D uniform inverse-depth samples between the first and last of the [384] range, inverted
+    (models/module.py:578-583, models/Effi_MVS_plus.py:473-474), the three stage intervals (:424 x depth_interals_ratio :316) and
+    depth_min_ / depth_max_ (:413-414)."""
+    from effi_mvs_plus_amd import ops
+    from oracle import effi_oracle as O
+    for n_range, D, lo, hi in ((384, 48, 1 / 935.0, 1 / 425.0), (384, 96, 1 / 3.0, 1 / 0.5), (192, 8, 1e-3, 2e-3), (384, 32, 1 / 935.0, 1 / 425.0)):
+        dv = torch.linspace(lo, hi, n_range, dtype=torch.float32).view(1, n_range)
+        want = 1.0 / O.depth_range_samples(dv, D, None, [1, 2, 2])[0, :, 0, 0]
+        depths, misc = ops.stage1_hypotheses(dv[0].to(DEV).contiguous(), D)
+        assert torch.equal(depths.cpu(), want), (depths.cpu() - want).abs().max()
+        base = (dv[0, -1] - dv[0, 0]) / n_range
+        assert torch.equal(misc[:3].cpu(), torch.stack([base * 4, base * 2, base * 1]))
+        assert misc[3].item() == (1.0 / dv[0, -1]).item() and misc[4].item() == (1.0 / dv[0, 0]).item()
+    with pytest.raises(Exception):
+        ops.stage1_hypotheses(torch.zeros(1, device=DEV), 8)          # n_range < 2

@@ -66,11 +66,24 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 22
     for name in declared:
         assert hasattr(handle, name), f"{name} declared in include/effi_mvs_hip.h but not exported"
-    assert set(_lib.SIGNATURES) | {"effi_error_string"} == set(declared)
+    assert set(_lib.SIGNATURES) | set(_lib.NON_STATUS_SYMBOLS) == set(declared)
     handle.effi_version.restype = ctypes.c_int
     assert handle.effi_version() >= 100
     handle.effi_error_string.restype = ctypes.c_char_p
     assert b"bad argument" in handle.effi_error_string(-1)
+    # caller-owned per-device workspace registry (no GPU needed: it only stores the pointer)
+    handle.effi_workspace_bytes.restype = ctypes.c_long
+    handle.effi_get_workspace.restype = ctypes.c_void_p
+    handle.effi_set_workspace.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_long]
+    need = handle.effi_workspace_bytes()
+    assert 64 <= need <= 1 << 20
+    assert handle.effi_get_workspace(3) is None
+    assert handle.effi_set_workspace(3, ctypes.c_void_p(0x1000), need - 1) == -1          # too small
+    assert handle.effi_set_workspace(99, ctypes.c_void_p(0x1000), need) == -1             # no such ordinal
+    assert handle.effi_set_workspace(3, ctypes.c_void_p(0x1000), need) == 0 and handle.effi_get_workspace(3) == 0x1000
+    assert handle.effi_get_workspace(2) is None                                           # slots are per device
+    assert handle.effi_set_workspace(3, None, 0) == 0 and handle.effi_get_workspace(3) is None
+    assert b"workspace" in handle.effi_error_string(-4)
 
 
 def test_product_fails_loudly_without_gpu():

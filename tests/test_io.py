@@ -139,7 +139,48 @@ def test_dataset_lists_and_fails_loudly_without_gpu(tmp_path, capsys):
     assert torch.equal(st["stage1"][:, 1, 2:], torch.from_numpy(m[:, 1, 2:]))
 
 
+def test_dataloader_workers_stay_on_the_host(tmp_path, capsys):
+    """The reference's drivers wrap the dataset in DataLoader(num_workers=4/8) (test_dtu_dypcd.py:406, test_tank.py:209): forked
+    workers must not touch the GPU, so inside a worker __getitem__ returns the decoded bytes and prepare_sample() finishes the
+    sample in the main process."""
+    from torch.utils.data import DataLoader
+    root = str(tmp_path)
+    raws = _write_scan(root, "scan4", 4, [(64, 96), (48, 64)], "425.0 2.5 192.0 935.0")
+    ds = general_eval.MVSDataset(root, ["scan4"], "test", 3, 96, 1.06, max_h=64, max_w=96)       # device="cuda" (the default)
+    for batch in DataLoader(ds, batch_size=1, shuffle=False, num_workers=2, drop_last=False):
+        assert "imgs" not in batch and len(batch["imgs_u8"]) == 3
+        assert batch["imgs_u8"][0].dtype == torch.uint8 and batch["imgs_u8"][0].dim() == 4 and batch["imgs_u8"][0].shape[0] == 1
+        assert tuple(batch["imgs_hw"].shape) == (1, 3, 2) and batch["std_hw"].tolist() == [[64, 96]]
+        assert tuple(batch["proj_matrices"]["stage2"].shape) == (1, 3, 2, 4, 4) and tuple(batch["depth_values"].shape) == (1, 96)
+    ref = ds.metas[0][1]
+    assert torch.equal(general_eval.MVSDataset(root, ["scan4"], "test", 3, 96, 1.06, max_h=64, max_w=96, device="host")[0]["imgs_u8"][0],
+                       torch.from_numpy(raws[ref]))
+    done = {"imgs": torch.zeros(1)}
+    assert general_eval.prepare_sample(done) is done                    # already complete: untouched
+
+
 # ---- GPU -----------------------------------------------------------------------------------------
+@pytest.mark.gpu
+def test_prepare_sample_of_worker_batches_equals_the_main_process_sample(tmp_path, capsys):
+    from torch.utils.data import DataLoader
+    root = str(tmp_path)
+    _write_scan(root, "scan4", 4, [(64, 96), (48, 64)], "425.0 2.5 192.0 935.0")
+    mk = lambda **kw: general_eval.MVSDataset(root, ["scan4"], "test", 3, 96, 1.06, max_h=64, max_w=96, **kw)  # noqa: E731
+    direct = mk(device=DEV)
+    for idx, batch in enumerate(DataLoader(mk(device=DEV), batch_size=1, shuffle=False, num_workers=2)):
+        got = general_eval.prepare_sample(batch, device=DEV)
+        want = direct[idx]
+        assert got["imgs"].is_cuda and tuple(got["imgs"].shape) == (1,) + tuple(want["imgs"].shape)
+        assert torch.equal(got["imgs"][0], want["imgs"])
+        for k in want["proj_matrices"]:
+            assert torch.equal(got["proj_matrices"][k][0], want["proj_matrices"][k])
+        assert torch.equal(got["depth_values"][0], want["depth_values"])
+    _write_scan(os.path.join(root, "intermediate"), "Family", 3, [(135, 240)], "0.5 0.01 192 2.25", cams_dir="cams_1")
+    td = tank.MVSDataset(root, n_views=3, ndepths=64, split="intermediate", scan=["Family"], device=DEV)
+    batch = next(iter(DataLoader(td, batch_size=1, num_workers=1)))
+    assert torch.equal(tank.prepare_sample(batch, device=DEV)["imgs"][0], td[0]["imgs"])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("src,dst", [((1200, 1600), (1184, 1600)), ((1080, 1920), (1056, 1920)), ((1080, 2048), (1056, 1920)),
                                      ((37, 53), (64, 96)), ((64, 96), (64, 96)), ((50, 70), (17, 23))])
