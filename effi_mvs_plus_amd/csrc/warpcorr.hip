@@ -11,6 +11,7 @@
 // Arithmetic follows the reference op for op (models/module.py:318-341 and ATen's grid_sample with
 // bilinear / zeros / align_corners=True); built with -ffp-contract=off, FMAs are explicit.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -176,6 +177,332 @@ __global__ __launch_bounds__(256) void warpcorr_views_kernel(const float* __rest
         e = e + (-p) * logf(p + 1e-7f);
     }
     e = effi_group_sum<G::LPP>(e);
+    if (sub == 0) entropy[(long)view * hw + pix] = e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stage 1, windowed form (C = 32, hypotheses shared by all pixels): the taps are served from LDS instead of the L1 / texture
+// path.  The direct-gather kernel above issues S*D*h*w*4 wave-level 128-byte tap reads (2.9 GB at 148x200, D = 48, S = 4),
+// which costs ~74 us at the L1's 64 B/clk/CU, and spends as long again on vector instructions (the per-hypothesis projection
+// set-up is recomputed by both quads of a pixel, 8 lanes reduce a 4-channel partial dot product each).  Here:
+//   * a 512-thread workgroup owns a 16 x 8 pixel tile of the reference map and ONE source view; 4 lanes per pixel, 8
+//     channels per lane (two float4 per tap), the 4 lanes of a pixel each set up a different hypothesis and exchange the
+//     taps with quad DPP moves -- no set-up is computed twice, half the cross-lane reduction steps.
+//   * hypotheses are processed in chunks.  For a chunk [da, db) the source positions of the tile are confined to the convex
+//     hull of the tile's four corners projected at the chunk's first and last depth (for a fixed depth the map is a
+//     homography: convex -> convex while Z > 0; for a fixed pixel the position moves monotonically along the epipolar line;
+//     Z is multilinear in (pixel, depth), so Z > 0 at the 8 corner cases means Z > 0 throughout).  Wave 0 evaluates EIGHT
+//     candidate chunk lengths at once (8 lanes per candidate, one corner case each) and picks the longest whose bounding
+//     box (+1 pixel of slack each side, clipped to the image) fits the LDS window; all rows of the box are then copied with
+//     coalesced 128-byte-per-pixel reads (channel-last layout: a window row is one contiguous run) and the chunk is
+//     sampled with ds_read_b128 (256 B/clk/CU against the L1's 64).
+//   * a chunk whose box does not fit (extreme geometry, Z <= 0 inside the tile) is sampled from global memory by the same
+//     code: identical results bit for bit, which is what tests/test_gpu_kernels.py checks (EFFI_WARP_LDS_KB=0 forces it).
+//   Measured (148x200, D = 48, S = 4): 92-95 us against 116 us for the direct-gather kernel and 125 us for this kernel on
+//   global loads.  Ablation on the same box: blend + dot 20 us, per-hypothesis set-up 8 us, window copies 15 us (exposed:
+//   the two workgroups of a CU run in step), the remaining skeleton (LDS reads at 2.9 GB / 124 TB/s = 27 us with 17 %
+//   bank conflicts, tap exchange, address arithmetic, the similarity stores, the entropy epilogue) 59 us; the SIMDs issue
+//   ~100 % of the time (SQ_ACTIVE_INST_ANY ~ kernel cycles per SIMD), i.e. the kernel is now bound by instruction issue.
+//   * LDS layout: window pixel P holds its 32 channels as 8 float4; float4 q sits at slot (8P + q) ^ ((P >> 1) & 1).  Lane
+//     `sub` reads logical q = 2sub and 2sub + 1, i.e. slots A = (8P + 2sub) ^ s and A ^ 1.  A ds_read_b128 is served in
+//     groups of 16 lanes = 4 pixels; pixel P's four lanes touch banks 32(P&1) + 8sub + 4s + {0..3}, so the four pixels of a
+//     group are conflict-free when their P differ mod 4 -- true for the near-unit-scale maps of neighbouring views.
+// Arithmetic: as the reference op for op, except that the four divisions of the projection (X/Z, Y/Z, and the grid
+// normalisation by (W-1)/2, (H-1)/2) use a refined reciprocal and one FMA residual step (3 instructions each instead of the
+// ~10 of the IEEE sequence): correctly rounded except for rare 1-ulp cases, i.e. ~1e-7 relative in a CONTINUOUS function of
+// the coordinate (bilinear sampling with zeros padding has no jumps), far inside the kernel tolerance.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct WinTaps {
+    float w[4];
+    int a[4];     // LDS form: byte address of the tap pixel's swizzled slot 0, ((8P) ^ s) * 16; global form: pixel index y*W + x
+};
+
+__device__ __forceinline__ float div_by(float a, float b, float rb) {      // a / b given rb ~ 1/b (refined reciprocal)
+    const float q = a * rb;
+    return fmaf(fmaf(-q, b, a), rb, q);
+}
+__device__ __forceinline__ float refined_rcp(float b) {
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    return fmaf(fmaf(-b, r0, 1.0f), r0, r0);
+}
+
+// Unclamped source coordinates (ix, iy) of a reference pixel at one depth -- models/module.py:325-337 + grid_sampler_unnormalize
+__device__ __forceinline__ void project_xy(float X, float Y, float Z, float hw2, float rhw2, float hh2, float rhh2, float wm1,
+                                           float hm1, float& ix, float& iy) {
+    if (Z == 0.0f) Z = Z + 1e-8f;                                   // :328-329
+    const float rz = refined_rcp(Z);
+    const float px = div_by(X, Z, rz), py = div_by(Y, Z, rz);       // :330
+    const float gx = div_by(px, hw2, rhw2) - 1.0f;                  // :336
+    const float gy = div_by(py, hh2, rhh2) - 1.0f;                  // :337
+    ix = ((gx + 1.0f) * 0.5f) * wm1;
+    iy = ((gy + 1.0f) * 0.5f) * hm1;
+}
+
+template <bool LDSWIN>
+__device__ __forceinline__ void make_taps_win(float ix, float iy, int W, int H, int x_lo, int y_lo, int ww, int wh, WinTaps& t) {
+    ix = fminf(fmaxf(ix, -2.0f), (float)W + 1.0f);                  // neutral clamp (see make_taps); NaN -> outside
+    iy = fminf(fmaxf(iy, -2.0f), (float)H + 1.0f);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    // 1-D weights, zeroed when their tap column / row is outside the image (zeros padding).  The product of two masked
+    // factors equals the masked product: the factors lie in [0, 1], so a zero factor gives +0.
+    const float wx0 = ((unsigned)x0 < (unsigned)W) ? (x0f + 1.0f) - ix : 0.0f;
+    const float wx1 = ((unsigned)(x0 + 1) < (unsigned)W) ? ix - x0f : 0.0f;
+    const float wy0 = ((unsigned)y0 < (unsigned)H) ? (y0f + 1.0f) - iy : 0.0f;
+    const float wy1 = ((unsigned)(y0 + 1) < (unsigned)H) ? iy - y0f : 0.0f;
+    t.w[0] = wx0 * wy0;
+    t.w[1] = wx1 * wy0;
+    t.w[2] = wx0 * wy1;
+    t.w[3] = wx1 * wy1;
+    if (LDSWIN) {
+        // window-relative, clamped INTO the window: a no-op for every tap that carries weight (the window covers them),
+        // and zero-weight taps then read finite staged data (0 * finite = 0), never uninitialised LDS
+        const int xa = min(max(x0 - x_lo, 0), ww - 1), xb = min(max(x0 + 1 - x_lo, 0), ww - 1);
+        const int ya = __mul24(min(max(y0 - y_lo, 0), wh - 1), ww), yb = __mul24(min(max(y0 + 1 - y_lo, 0), wh - 1), ww);
+        const int p0 = ya + xa, p1 = ya + xb, p2 = yb + xa, p3 = yb + xb;
+        t.a[0] = ((p0 << 3) ^ ((p0 >> 1) & 1)) << 4;
+        t.a[1] = ((p1 << 3) ^ ((p1 >> 1) & 1)) << 4;
+        t.a[2] = ((p2 << 3) ^ ((p2 >> 1) & 1)) << 4;
+        t.a[3] = ((p3 << 3) ^ ((p3 >> 1) & 1)) << 4;
+    } else {
+        const int xa = min(max(x0, 0), W - 1), xb = min(max(x0 + 1, 0), W - 1);
+        const int ya = __mul24(min(max(y0, 0), H - 1), W), yb = __mul24(min(max(y0 + 1, 0), H - 1), W);
+        t.a[0] = ya + xa; t.a[1] = ya + xb; t.a[2] = yb + xa; t.a[3] = yb + xb;
+    }
+}
+
+template <int J>
+__device__ __forceinline__ void wintaps_bcast(const WinTaps& mine, WinTaps& out) {      // from lane J of every quad
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        out.w[k] = __int_as_float(quad_bcast_i<4, J>(__float_as_int(mine.w[k])));
+        out.a[k] = quad_bcast_i<4, J>(mine.a[k]);
+    }
+}
+
+// this lane's 8 channels of the 4 taps: two float4 per tap
+struct TapData {
+    float4 lo[4], hi[4];
+};
+
+template <bool LDSWIN>
+__device__ __forceinline__ void load_taps8(const char* __restrict__ win, const float* __restrict__ src, const WinTaps& t, int sub,
+                                           TapData& td) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (LDSWIN) {
+            // slot (8P + 2sub) ^ s = ((8P) ^ s) + 2sub (s only touches bit 0); its partner is that slot ^ 1
+            const int a = t.a[k] + sub * 32;
+            td.lo[k] = *reinterpret_cast<const float4*>(win + a);
+            td.hi[k] = *reinterpret_cast<const float4*>(win + (a ^ 16));
+        } else {
+            const float4* q = reinterpret_cast<const float4*>(src + (long)t.a[k] * 32 + sub * 8);
+            td.lo[k] = q[0];
+            td.hi[k] = q[1];
+        }
+    }
+}
+
+// sum over this lane's 8 channels of  ref[c] * (sum_t w_t * src[tap_t][c])  -- blend first, as grid_sample does, then the product
+__device__ __forceinline__ float blend_dot8(const TapData& td, const float (&w)[4], const float4 rlo, const float4 rhi) {
+    f32x2 v[4];
+#define EFFI_BLEND(dst, SRC, F0, F1)                                                            \
+    dst = f32x2{td.SRC[0].F0, td.SRC[0].F1} * f32x2{w[0], w[0]};                                \
+    dst = __builtin_elementwise_fma(f32x2{td.SRC[1].F0, td.SRC[1].F1}, f32x2{w[1], w[1]}, dst); \
+    dst = __builtin_elementwise_fma(f32x2{td.SRC[2].F0, td.SRC[2].F1}, f32x2{w[2], w[2]}, dst); \
+    dst = __builtin_elementwise_fma(f32x2{td.SRC[3].F0, td.SRC[3].F1}, f32x2{w[3], w[3]}, dst)
+    EFFI_BLEND(v[0], lo, x, y);
+    EFFI_BLEND(v[1], lo, z, w);
+    EFFI_BLEND(v[2], hi, x, y);
+    EFFI_BLEND(v[3], hi, z, w);
+#undef EFFI_BLEND
+    f32x2 acc = v[0] * f32x2{rlo.x, rlo.y};
+    acc = __builtin_elementwise_fma(v[1], f32x2{rlo.z, rlo.w}, acc);
+    acc = __builtin_elementwise_fma(v[2], f32x2{rhi.x, rhi.y}, acc);
+    acc = __builtin_elementwise_fma(v[3], f32x2{rhi.z, rhi.w}, acc);
+    return acc.x + acc.y;
+}
+
+constexpr int WIN_TW = 16, WIN_TH = 8, WIN_THREADS = 512;
+
+struct WinProj {                // per-thread projection state of its pixel and view
+    float rx, ry, rz, tx, ty, tz, hw2, rhw2, hh2, rhh2, wm1, hm1;
+};
+
+template <bool LDSWIN>
+__device__ __forceinline__ void win_sample_chunk(const char* __restrict__ win, const float* __restrict__ src, const WinProj& P,
+                                                 const float* __restrict__ hyp, int da, int db, int D, int w, int h,
+                                                 int x_lo, int y_lo, int ww, int wh, int sub, const float4 rlo, const float4 rhi,
+                                                 bool valid, float* __restrict__ simv, int hw, float& m) {
+    // (A software-pipelined form -- tap reads of sample j + 1 in flight under the blend of sample j, next group's set-up under
+    // the last reads -- was built and measured: 96.7 us against 93.8 us for this plain loop at 148x200, D = 48, S = 4; it
+    // needs the 128-register cap and spills.  Four waves per SIMD hide the LDS latency well enough.)
+    for (int d0 = da; d0 < db; d0 += 4) {
+        const float dep = hyp[d0 + sub];      // this lane's hypothesis; hyp[] is padded with the last one to a multiple of 4
+        float ix, iy;
+        project_xy(P.rx * dep + P.tx, P.ry * dep + P.ty, P.rz * dep + P.tz, P.hw2, P.rhw2, P.hh2, P.rhh2, P.wm1, P.hm1, ix, iy);
+        WinTaps mine, t;
+        make_taps_win<LDSWIN>(ix, iy, w, h, x_lo, y_lo, ww, wh, mine);
+        TapData A;
+        float s[4];
+#define EFFI_ONE(J)                                                                  \
+        wintaps_bcast<J>(mine, t);                                                   \
+        load_taps8<LDSWIN>(win, src, t, sub, A);                                     \
+        s[J] = effi_group_sum<4>(blend_dot8(A, t.w, rlo, rhi)) * (1.0f / 32.0f)      /* mean over C (:40); x 2^-5 is exact */
+        EFFI_ONE(0); EFFI_ONE(1); EFFI_ONE(2); EFFI_ONE(3);
+#undef EFFI_ONE
+        const float own = (sub == 0) ? s[0] : (sub == 1) ? s[1] : (sub == 2) ? s[2] : s[3];
+        if (valid && d0 + sub < D) simv[(long)(d0 + sub) * hw] = own;
+        m = fmaxf(m, s[0]);
+        if (d0 + 1 < D) m = fmaxf(m, s[1]);
+        if (d0 + 2 < D) m = fmaxf(m, s[2]);
+        if (d0 + 3 < D) m = fmaxf(m, s[3]);
+    }
+}
+
+// wave 0: candidate k = lane >> 3 proposes the chunk [da, da + cs_k); its 8 lanes project the tile's corners at both ends of it;
+// the longest candidate whose box fits the window is published in par[0..5] = {x_lo, y_lo, ww, wh, db, use_lds}
+__device__ __forceinline__ void win_choose_chunk(const float* __restrict__ rt, const float* __restrict__ hyp, const WinProj& P,
+                                                 int txi, int tyi, int da, int D, int w, int h, int lds_px, int lane, int* par) {
+    const int ng = (D + 3) >> 2;
+    const int k = lane >> 3, corner = lane & 7;
+    const int rem_g = (D - da + 3) >> 2;                        // groups of 4 hypotheses still to do
+    const int cs = 4 * max(1, (rem_g * (8 - k) + 7) >> 3);      // 8/8 ... 1/8 of what is left, in whole groups
+    const int db = min(D, da + cs);
+    const float dep = hyp[(corner & 4) ? db - 1 : da];
+    const float cxf = (float)min(txi * WIN_TW + ((corner & 1) ? WIN_TW - 1 : 0), w - 1);
+    const float cyf = (float)min(tyi * WIN_TH + ((corner & 2) ? WIN_TH - 1 : 0), h - 1);
+    const float X = (rt[0] * cxf + rt[1] * cyf + rt[2]) * dep + rt[9];
+    const float Y = (rt[3] * cxf + rt[4] * cyf + rt[5]) * dep + rt[10];
+    const float Z = (rt[6] * cxf + rt[7] * cyf + rt[8]) * dep + rt[11];
+    float ix, iy;
+    project_xy(X, Y, Z, P.hw2, P.rhw2, P.hh2, P.rhh2, P.wm1, P.hm1, ix, iy);
+    int ok = (Z > 0.0f) & (ix == ix) & (iy == iy);
+    ix = fminf(fmaxf(ix, -4.0f), (float)w + 3.0f);              // monotonic: bounding boxes survive the clamp
+    iy = fminf(fmaxf(iy, -4.0f), (float)h + 3.0f);
+    float mnx = ix, mxx = ix, mny = iy, mxy = iy;
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        mnx = fminf(mnx, __shfl_xor(mnx, o)); mxx = fmaxf(mxx, __shfl_xor(mxx, o));
+        mny = fminf(mny, __shfl_xor(mny, o)); mxy = fmaxf(mxy, __shfl_xor(mxy, o));
+        ok &= __shfl_xor(ok, o);
+    }
+    // taps are floor(.) and floor(.) + 1; one more pixel of slack on every side for rounding
+    int x_lo = (int)floorf(mnx) - 1, x_hi = (int)floorf(mxx) + 2;
+    int y_lo = (int)floorf(mny) - 1, y_hi = (int)floorf(mxy) + 2;
+    x_lo = min(max(x_lo, 0), w - 1); x_hi = max(min(x_hi, w - 1), x_lo);
+    y_lo = min(max(y_lo, 0), h - 1); y_hi = max(min(y_hi, h - 1), y_lo);
+    const int ww = x_hi - x_lo + 1, wh = y_hi - y_lo + 1;
+    const bool fits = ok && (ww * wh <= lds_px);
+    const unsigned long long mask = __ballot(fits && corner == 0);
+    const int pick = mask ? (int)(__ffsll((long long)mask) - 1) : 56;      // longest fitting chunk, else the shortest
+    if (lane == pick) {
+        par[0] = x_lo; par[1] = y_lo; par[2] = ww; par[3] = wh; par[4] = db; par[5] = mask ? 1 : 0;
+    }
+    (void)ng;
+}
+
+template <int MAXPX>
+__global__ __launch_bounds__(WIN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void warpcorr_views_win_kernel(const float* __restrict__ ref, EffiPtrList srcs,
+                                                                         const float* __restrict__ rt_all,
+                                                                         const float* __restrict__ depth, long dds,
+                                                                         int h, int w, int D, float* sim_views,
+                                                                         float* __restrict__ entropy, int lds_px) {
+    constexpr int C = 32, MAXD = 256;
+    __shared__ float4 win4[(MAXPX > 0 ? MAXPX : 1) * 8];
+    __shared__ float hyp[MAXD + 4];
+    __shared__ int wpar[2][8];
+    const char* win = reinterpret_cast<const char*>(win4);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tiles_x = (w + WIN_TW - 1) / WIN_TW;
+    const int tl = effi_xcd_remap(blockIdx.x, gridDim.x);
+    const int tyi = tl / tiles_x, txi = tl - tyi * tiles_x;
+    const int g = tid >> 2, sub = tid & 3;
+    const int x = txi * WIN_TW + (g & (WIN_TW - 1)), y = tyi * WIN_TH + (g >> 4);
+    const bool valid = (x < w) & (y < h);
+    const int xs = min(x, w - 1), ys = min(y, h - 1);          // out-of-image lanes shadow the border pixel (no stores)
+    const int view = blockIdx.y;
+    const float* __restrict__ src = pick_view(srcs, view);
+    const float* __restrict__ rt = rt_all + view * 12;
+    const int hw = h * w, pix = ys * w + xs;
+    // the hypotheses (shared by all pixels) once into LDS, padded with the last one to a multiple of 4
+    for (int d = tid; d < ((D + 3) & ~3); d += WIN_THREADS) hyp[d] = depth[(long)min(d, D - 1) * dds];
+    const float4 rlo = *reinterpret_cast<const float4*>(ref + (long)pix * C + sub * 8);
+    const float4 rhi = *reinterpret_cast<const float4*>(ref + (long)pix * C + sub * 8 + 4);
+    WinProj P;
+    {
+        const float fx = (float)xs, fy = (float)ys;
+        P.rx = rt[0] * fx + rt[1] * fy + rt[2];                  // rot . (x, y, 1)   module.py:324
+        P.ry = rt[3] * fx + rt[4] * fy + rt[5];
+        P.rz = rt[6] * fx + rt[7] * fy + rt[8];
+        P.tx = rt[9]; P.ty = rt[10]; P.tz = rt[11];
+        P.wm1 = (float)(w - 1); P.hm1 = (float)(h - 1);
+        P.hw2 = P.wm1 / 2.0f; P.hh2 = P.hm1 / 2.0f;
+        P.rhw2 = 1.0f / P.hw2; P.rhh2 = 1.0f / P.hh2;           // IEEE divisions: correctly rounded reciprocals
+    }
+    float* simv = sim_views + (long)view * D * hw + pix;
+    float m = -INFINITY;
+    __syncthreads();                                             // hyp[] visible
+    if (wv == 0) win_choose_chunk(rt, hyp, P, txi, tyi, 0, D, w, h, lds_px, lane, wpar[0]);
+    __syncthreads();
+    int da = 0, pb = 0;
+    while (da < D) {
+        const int x_lo = wpar[pb][0], y_lo = wpar[pb][1], ww = wpar[pb][2], wh = wpar[pb][3], db = wpar[pb][4], use_lds = wpar[pb][5];
+        if (use_lds) {
+            // copy the window: rows are contiguous runs of ww * 8 float4 in the channel-last map; up to 5 loads in flight per thread
+            const int n4 = ww * 8, total = n4 * wh;
+            const float inv_n4 = 1.0f / (float)n4;
+            const float4* __restrict__ gsrc = reinterpret_cast<const float4*>(src + ((long)y_lo * w + x_lo) * C);
+            for (int i0 = tid; i0 < total; i0 += 5 * WIN_THREADS) {
+                float4 v[5];
+                int slot[5];
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const int i = min(i0 + j * WIN_THREADS, total - 1);
+                    int row = (int)(((float)i + 0.5f) * inv_n4);           // i < 2^13: exact up to +-1, fixed below
+                    row -= (row * n4 > i);
+                    row += ((row + 1) * n4 <= i);
+                    const int c = i - row * n4;
+                    const int Pp = row * ww + (c >> 3);
+                    slot[j] = (Pp * 8 + (c & 7)) ^ ((Pp >> 1) & 1);
+                    v[j] = gsrc[(long)row * w * 8 + c];
+                }
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+                    if (i0 + j * WIN_THREADS < total) win4[slot[j]] = v[j];
+            }
+            __syncthreads();
+        }
+        // the next chunk's window is chosen by wave 0 before it joins the sampling (published by the barrier below)
+        if (wv == 0 && db < D) win_choose_chunk(rt, hyp, P, txi, tyi, db, D, w, h, lds_px, lane, wpar[pb ^ 1]);
+        if (use_lds)
+            win_sample_chunk<true>(win, src, P, hyp, da, db, D, w, h, x_lo, y_lo, ww, wh, sub, rlo, rhi, valid, simv, hw, m);
+        else
+            win_sample_chunk<false>(win, src, P, hyp, da, db, D, w, h, 0, 0, w, h, sub, rlo, rhi, valid, simv, hw, m);
+        __syncthreads();           // the window is rewritten by the next chunk; wpar[pb ^ 1] is published
+        da = db;
+        pb ^= 1;
+    }
+    if (!valid) return;
+    // softmax over D and entropy (models/Effi_MVS_plus.py:43-44); lane `sub` owns (and wrote) d = sub, sub + 4, ...
+    // exp(s - m) is evaluated once and parked in the (now free) window, [i][thread]: conflict-free, no second exp pass
+    float* ebuf = reinterpret_cast<float*>(win4) + tid;
+    const bool park = ((D + 3) >> 2) * WIN_THREADS <= (MAXPX > 0 ? MAXPX : 1) * 32;
+    float z = 0.0f;
+    for (int d = sub, i = 0; d < D; d += 4, ++i) {
+        const float ex = expf(simv[(long)d * hw] - m);
+        if (park) ebuf[i * WIN_THREADS] = ex;
+        z = z + ex;
+    }
+    z = effi_group_sum<4>(z);
+    float e = 0.0f;
+    for (int d = sub, i = 0; d < D; d += 4, ++i) {
+        const float p = (park ? ebuf[i * WIN_THREADS] : expf(simv[(long)d * hw] - m)) / z;
+        e = e + (-p) * logf(p + 1e-7f);
+    }
+    e = effi_group_sum<4>(e);
     if (sub == 0) entropy[(long)view * hw + pix] = e;
 }
 
@@ -419,6 +746,20 @@ extern "C" int effi_homo_warp_bwd_f32(const float* rt, const float* depth, long 
     return EFFI_OK;
 }
 
+// Window capacity of the stage-1 LDS kernel in pixels (128 B each): 72 KB leaves room for two 512-thread workgroups per CU.
+constexpr int WIN_MAXPX = 576;
+
+// EFFI_WARP_LDS_KB (read at every call; tests and A/B runs only): unset = the windowed kernel with its full 72 KB window;
+// 0 = the windowed kernel with every chunk sampled from global memory (same arithmetic, the bitwise cross-check);
+// -1 = the direct-gather kernel (also what C != 32 and per-pixel hypotheses use).
+static int warp_lds_px() {
+    const char* e = getenv("EFFI_WARP_LDS_KB");
+    if (!e || !*e) return WIN_MAXPX;
+    const int kb = atoi(e);
+    if (kb < 0) return -1;
+    return min(WIN_MAXPX, kb * 1024 / 128);
+}
+
 extern "C" int effi_warpcorr_views_f32(const float* ref_nhwc, const float* const* src_nhwc, int S, const float* rt,
                                        const float* depth, long dds, long dps, int C, int h, int w, int D,
                                        float* sim_views, float* entropy, effi_stream_t stream) {
@@ -426,6 +767,15 @@ extern "C" int effi_warpcorr_views_f32(const float* ref_nhwc, const float* const
     if (!fill_views(src_nhwc, S, l) || !ref_nhwc || !rt || !depth || !sim_views || !entropy) return EFFI_ERR_BADARG;
     if (h < 2 || w < 2 || D < 1) return EFFI_ERR_BADARG;
     hipStream_t s = effi_s(stream);
+    const int lds_px = warp_lds_px();
+    if (C == 32 && dps == 0 && lds_px >= 0 && D <= 256) {
+        // hypotheses shared by all pixels (the cascade's stage 1): taps served from an LDS window
+        const int tiles = ((w + WIN_TW - 1) / WIN_TW) * ((h + WIN_TH - 1) / WIN_TH);
+        hipLaunchKernelGGL(warpcorr_views_win_kernel<WIN_MAXPX>, dim3(tiles, S), dim3(WIN_THREADS), 0, s, ref_nhwc, l, rt, depth,
+                           dds, h, w, D, sim_views, entropy, lds_px);
+        EFFI_LAUNCH_CHECK();
+        return EFFI_OK;
+    }
     switch (C) {
         case 32: hipLaunchKernelGGL(warpcorr_views_kernel<32>, dim3(grid_blocks<32>(h, w), S), dim3(256), 0, s, ref_nhwc, l, rt, depth, dds, dps, h, w, D, sim_views, entropy); break;
         case 16: hipLaunchKernelGGL(warpcorr_views_kernel<16>, dim3(grid_blocks<16>(h, w), S), dim3(256), 0, s, ref_nhwc, l, rt, depth, dds, dps, h, w, D, sim_views, entropy); break;
@@ -467,6 +817,9 @@ extern "C" int effi_warpcorr_dyn_f32(const float* ref_nhwc, const float* const* 
     if (h < 2 || w < 2 || D < 2 || vw_shift < 0 || vw_shift > 4) return EFFI_ERR_BADARG;
     if ((h >> vw_shift) << vw_shift != h || (w >> vw_shift) << vw_shift != w) return EFFI_ERR_BADARG;
     hipStream_t s = effi_s(stream);
+    // (An 8-channels-per-lane form of this kernel -- one lane per pixel at C = 8, no exchange, no reduction, cheaper projection --
+    // was built and measured at 592x800: 121 us against 109 us; at 296x400, C = 16: 63 against 58.  These kernels are bound by the
+    // number of distinct cache lines a wave-instruction touches in the L1 / texture path, not by instruction issue.)
     switch (C) {
         case 32: hipLaunchKernelGGL(warpcorr_dyn_kernel<32>, dim3(grid_blocks<32>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples); break;
         case 16: hipLaunchKernelGGL(warpcorr_dyn_kernel<16>, dim3(grid_blocks<16>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples); break;

@@ -125,6 +125,78 @@ def test_warpcorr_views(O, C, h, w, D, N):
     check_close(f"warpcorr_views entropy C={C} D={D}", ent, want_ent, rtol=1e-4, atol=2e-4, frac_ok=0.998)
 
 
+def _with_env(name, value, fn):
+    import os
+    before = os.environ.get(name)
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = value
+    try:
+        return fn()
+    finally:
+        if before is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = before
+
+
+def _edge_cameras(h, w, N, kind):
+    """Camera rigs that stress the window logic of the stage-1 kernel: `rolled` = source views rotated about the optical
+    axis (slanted epipolar lines, windows taller than wide), `wide` = large baselines (windows that exceed the LDS budget:
+    chunks shrink, then fall back to global loads), `inside` = a source camera inside the depth range (Z <= 0 for part of
+    the volume: those chunks must take the global path), `far` = a view that looks away (every tap out of bounds)."""
+    import math
+    pm = synth.synth_cameras(h * 8, w * 8, N)["stage1"].clone()
+    for v in range(1, N):
+        E = pm[0, v, 0]
+        if kind == "rolled":
+            a = math.radians(25.0 * v)
+            Rz = torch.tensor([[math.cos(a), -math.sin(a), 0], [math.sin(a), math.cos(a), 0], [0, 0, 1.0]])
+            E[:3, :3] = Rz @ E[:3, :3]
+            E[:3, 3] = Rz @ E[:3, 3]
+        elif kind == "wide":
+            E[:3, 3] = E[:3, 3] * (4.0 + v)
+        elif kind == "inside":
+            E[2, 3] = E[2, 3] - 600.0 - 40.0 * v          # camera centre moved into the scene
+        elif kind == "far":
+            a = math.radians(100.0)
+            Ry = torch.tensor([[math.cos(a), 0, math.sin(a)], [0, 1.0, 0], [-math.sin(a), 0, math.cos(a)]])
+            E[:3, :3] = Ry @ E[:3, :3]
+    return pm
+
+
+@pytest.mark.parametrize("kind", ["rig", "rolled", "wide", "inside", "far"])
+@pytest.mark.parametrize("h,w,D,N", [(37, 50, 48, 4), (16, 20, 8, 3), (9, 13, 6, 2), (74, 100, 96, 3), (20, 24, 1, 2)])
+def test_warpcorr_views_window_kernel(O, kind, h, w, D, N):
+    """The stage-1 kernel that serves its taps from an LDS window (C = 32, hypotheses shared by all pixels): (a) against the
+    oracle, (b) bit for bit against itself with every chunk forced onto the global-load path (EFFI_WARP_LDS_KB=0) and with a
+    window so small that chunks must shrink (8 KB), (c) against the direct-gather kernel (EFFI_WARP_LDS_KB=-1; another summation
+    order, so to rounding)."""
+    from effi_mvs_plus_amd import ops
+    C = 32
+    feats = synth.smooth_features(N, C, h, w, seed=300 + h)
+    pm = synth.synth_cameras(h * 8, w * 8, N)["stage1"] if kind == "rig" else _edge_cameras(h, w, N, kind)
+    samples = (1.0 / torch.linspace(1 / 935.0, 1 / 425.0, D)) if D > 1 else torch.tensor([600.0])
+    want_sim, want_ent = _oracle_sim_views(O, feats, pm, samples.view(1, D, 1, 1).expand(1, D, h, w))
+    nhwc = ops.to_nhwc([t(f[0], DEV) for f in feats])
+    rt = ops.compose_rel_proj(t(pm[0], DEV))
+    run = lambda: ops.warpcorr_views(nhwc[0], nhwc[1:], rt, t(samples, DEV), D)       # noqa: E731
+    sim, ent = _with_env("EFFI_WARP_LDS_KB", None, run)
+    sim_g, ent_g = _with_env("EFFI_WARP_LDS_KB", "0", run)
+    sim_s, ent_s = _with_env("EFFI_WARP_LDS_KB", "8", run)
+    sim_o, ent_o = _with_env("EFFI_WARP_LDS_KB", "-1", run)
+    assert torch.equal(sim, sim_g) and torch.equal(ent, ent_g), "LDS-window and global-load paths of the kernel must agree bitwise"
+    assert torch.equal(sim, sim_s) and torch.equal(ent, ent_s), "chunking must not change the result"
+    tol = dict(rtol=1e-4, atol=2e-4, frac_ok=0.998)
+    if kind == "inside":
+        # where Z crosses zero the projection is discontinuous: coordinates near the pole are ill-conditioned in fp32
+        tol = dict(rtol=1e-4, atol=2e-4, frac_ok=0.97)
+    check_close(f"window kernel sim [{kind} {h}x{w} D={D}]", sim, want_sim, **tol)
+    check_close(f"window kernel entropy [{kind} {h}x{w} D={D}]", ent, want_ent, **tol)
+    check_close(f"window vs direct-gather kernel sim [{kind}]", sim, sim_o, rtol=1e-5, atol=2e-5, frac_ok=0.999 if kind != "inside" else 0.97)
+
+
 @pytest.mark.parametrize("C,h,w,D,N", [(32, 16, 20, 8, 4), (16, 18, 30, 5, 3), (8, 21, 27, 6, 3)])
 def test_warp_correlate_backward_matches_torch_autograd(O, C, h, w, D, N):
     """Scope row n2, first piece: gradients of the stage-1 warp + correlation w.r.t. reference and source features from the HIP
