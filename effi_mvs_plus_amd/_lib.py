@@ -65,6 +65,19 @@ SIGNATURES = {
     "effi_depth_to_inv_f32": [_vp, _vp, _i, _i, _vp, _vp],
     "effi_stage1_hypotheses_f32": [_vp, _i, _i, _vp, _vp, _vp],
     "effi_upsample_nearest_f32": [_vp, _i, _i, _i, _i, _vp, _vp],
+    # scope row n2: training kernels
+    "effi_conv_wgrad_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "effi_channel_sum_f32": [_vp, _i, _i, _l, _vp, _vp],
+    "effi_bn_moment_f32": [_vp, _i, _i, _l, _vp, _i, _vp, _vp],
+    "effi_bn_apply_f32": [_vp, _i, _i, _l, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "effi_bn_bwd_f32": [_vp, _vp, _vp, _i, _i, _l, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "effi_pointwise_f32": [_i, _vp, _vp, _vp, _vp, _f, _f, _l, _l, _i, _vp, _vp, _vp, _vp],
+    "effi_vol_lookup1d_bwd_f32": [_vp, _l, _l, _i, _vp, _l, _l, _l, _i, _vp, _vp, _l, _i, _i, _vp, _vp],
+    "effi_getcost_bwd_f32": [_vp, _vp, _i, _i, _vp, _vp, _l, _l, _i, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _vp, _vp],
+    "effi_softargmin_bwd_f32": [_vp, _vp, _l, _l, _i, _i, _vp, _vp, _vp],
+    "effi_view_aggregate_bwd_f32": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "effi_convex_upsample2x_bwd_f32": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "effi_warpcorr_dyn_bwd_f32": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 
 # entry points whose return type is not the int status code (bound explicitly in lib())

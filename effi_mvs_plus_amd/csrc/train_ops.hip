@@ -1,0 +1,503 @@
+// Scope row n2: the kernels that make the path trainable -- what `loss.backward()` of the
+// reference's train.py:229-263 needs below the modules of models/module.py, models/update.py, models/Effi_MVS_plus.py.
+//
+//   * weight gradients of every convolution on the path (2-D k1/k3/k7, 3-D k3 with stride (1|2, 1|2, 1|2), and the
+//     transposed 3-D convolutions) through ONE kernel family: dW[a][b][tap] = sum_o A[a][o] * B[b][o*stride + tap - pad].
+//     For a convolution A = grad_out, B = input (torch layout [cout][cin][k..]); for a transposed convolution A = input,
+//     B = grad_out ([cin][cout][k..]).  Input gradients reuse the forward kernels with re-arranged weights (host side).
+//   * BatchNorm in training mode (batch statistics) forward / backward, with the ReLU that always follows it fused.
+//   * the element-wise epilogues of the GRU block and the depth head (activation derivatives, gating) forward / backward.
+//   * backward of the 1-D volume lookups (pro_bilinear_sampler / GetCost), of the soft-argmin, of the view-weighted
+//     aggregation, of the stage-2/3 warp + correlation and of the convex upsampling.
+// Everything is fp32; sums over many elements are accumulated per thread, reduced per workgroup and added with fp32 atomics,
+// so the last bits of a gradient vary between runs (as they do in PyTorch's own convolution backward).
+#include "common.hpp"
+
+namespace {
+
+constexpr int TPB = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient, generic: A on the small grid (Da,ha,wa), B on the large one (Db,hb,wb), position o of A meets
+// B at o*stride + tap - pad.  grid = (ceil(ca / CAB), cb, strips); every workgroup reduces its strip and adds atomically.
+// ------------------------------------------------------------------------------------------------
+template <int KD, int KS, int CAB>
+__global__ __launch_bounds__(TPB) void wgrad_nd_kernel(const float* __restrict__ A, const float* __restrict__ Bm, int ca,
+                                                       int cb_total, int cb_off, int Da, int ha, int wa, int Db, int hb, int wb,
+                                                       int sz, int sxy, float* __restrict__ dW) {
+    constexpr int TAPS = KD * KS * KS, PZ = KD / 2, PXY = KS / 2;
+    const int ca0 = blockIdx.x * CAB, cbi = blockIdx.y;
+    const long na = (long)Da * ha * wa, nb = (long)Db * hb * wb;
+    const long per = (na + gridDim.z - 1) / gridDim.z;
+    const long o0 = blockIdx.z * per, o1 = min(na, o0 + per);
+    float acc[CAB][TAPS];
+#pragma unroll
+    for (int i = 0; i < CAB; ++i)
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) acc[i][t] = 0.0f;
+    const float* __restrict__ Bc = Bm + (long)cbi * nb;
+    for (long o = o0 + threadIdx.x; o < o1; o += TPB) {
+        const int x = (int)(o % wa);
+        const long t_ = o / wa;
+        const int y = (int)(t_ % ha), z = (int)(t_ / ha);
+        float a[CAB];
+#pragma unroll
+        for (int i = 0; i < CAB; ++i) a[i] = (ca0 + i < ca) ? A[(long)(ca0 + i) * na + o] : 0.0f;
+#pragma unroll
+        for (int kz = 0; kz < KD; ++kz) {
+            const int bz = z * sz + kz - PZ;
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+                const int by = y * sxy + ky - PXY;
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    const int bx = x * sxy + kx - PXY;
+                    const bool in = (bz >= 0) & (bz < Db) & (by >= 0) & (by < hb) & (bx >= 0) & (bx < wb);
+                    const float b = in ? Bc[((long)bz * hb + by) * wb + bx] : 0.0f;
+                    const int tap = (kz * KS + ky) * KS + kx;
+#pragma unroll
+                    for (int i = 0; i < CAB; ++i) acc[i][tap] = fmaf(a[i], b, acc[i][tap]);
+                }
+            }
+        }
+    }
+    __shared__ float red[TPB / 64][CAB * TAPS];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < CAB; ++i)
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            const float v = wave_sum(acc[i][t]);
+            if (lane == 0) red[wv][i * TAPS + t] = v;
+        }
+    __syncthreads();
+    for (int e = threadIdx.x; e < CAB * TAPS; e += TPB) {
+        const int i = e / TAPS, t = e - i * TAPS;
+        if (ca0 + i >= ca) continue;
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < TPB / 64; ++k) s += red[k][e];
+        unsafeAtomicAdd(&dW[((long)(ca0 + i) * cb_total + cb_off + cbi) * TAPS + t], s);
+    }
+}
+
+// per-channel sums of a [B][C][n] tensor (bias gradients): out[c] += sum_{b,i} g[b][c][i]
+__global__ __launch_bounds__(TPB) void channel_sum_kernel(const float* __restrict__ g, int Bn, int C, long n, float* __restrict__ out) {
+    const int c = blockIdx.x;
+    const long total = (long)Bn * n;
+    const long per = (total + gridDim.y - 1) / gridDim.y;
+    const long i0 = blockIdx.y * per, i1 = min(total, i0 + per);
+    float s = 0.0f;
+    for (long i = i0 + threadIdx.x; i < i1; i += TPB) {
+        const long b = i / n, r = i - b * n;
+        s += g[((long)b * C + c) * n + r];
+    }
+    __shared__ float red[TPB / 64];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(&out[c], red[0] + red[1] + red[2] + red[3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm, training mode (nn.BatchNorm2d / 3d on batch statistics; models/module.py:148-157,191-200,217-220)
+// ------------------------------------------------------------------------------------------------
+// out[c] += sum (x - shift[c])^P over batch and positions (P = 1 with shift = nullptr: the sum; P = 2 with shift = mean)
+template <int P>
+__global__ __launch_bounds__(TPB) void bn_moment_kernel(const float* __restrict__ x, int Bn, int C, long n, const float* __restrict__ shift,
+                                                        float* __restrict__ out) {
+    const int c = blockIdx.x;
+    const long total = (long)Bn * n;
+    const long per = (total + gridDim.y - 1) / gridDim.y;
+    const long i0 = blockIdx.y * per, i1 = min(total, i0 + per);
+    const float sh = shift ? shift[c] : 0.0f;
+    float s = 0.0f;
+    for (long i = i0 + threadIdx.x; i < i1; i += TPB) {
+        const long b = i / n, r = i - b * n;
+        const float v = x[((long)b * C + c) * n + r] - sh;
+        s += (P == 1) ? v : v * v;
+    }
+    __shared__ float red[TPB / 64];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(&out[c], red[0] + red[1] + red[2] + red[3]);
+}
+
+// y = (x - mean) * invstd * gamma + beta, then ReLU if asked
+__global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__ x, int Bn, int C, long n, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int relu, float* __restrict__ y) {
+    const long total = (long)Bn * C * n;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const int c = (int)((i / n) % C);
+        float v = (x[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+        if (relu) v = fmaxf(v, 0.0f);
+        y[i] = v;
+    }
+}
+
+// s1[c] += sum g', s2[c] += sum g' * xhat, with g' = gy masked by the ReLU (y > 0) and xhat = (x - mean) * invstd
+__global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                            const float* __restrict__ x, int Bn, int C, long n,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
+                                                            float* __restrict__ s1, float* __restrict__ s2) {
+    const int c = blockIdx.x;
+    const long total = (long)Bn * n;
+    const long per = (total + gridDim.y - 1) / gridDim.y;
+    const long i0 = blockIdx.y * per, i1 = min(total, i0 + per);
+    const float mu = mean[c], is = invstd[c];
+    float a = 0.0f, b2 = 0.0f;
+    for (long i = i0 + threadIdx.x; i < i1; i += TPB) {
+        const long b = i / n, r = i - b * n;
+        const long e = ((long)b * C + c) * n + r;
+        float g = gy[e];
+        if (relu && !(y[e] > 0.0f)) g = 0.0f;
+        a += g;
+        b2 += g * ((x[e] - mu) * is);
+    }
+    __shared__ float red[2][TPB / 64];
+    a = wave_sum(a);
+    b2 = wave_sum(b2);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsafeAtomicAdd(&s1[c], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+        unsafeAtomicAdd(&s2[c], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    }
+}
+
+// gx = gamma * invstd * (g' - s1/N - xhat * s2/N)
+__global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                                                           const float* __restrict__ x, int Bn, int C, long n,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ s1,
+                                                           const float* __restrict__ s2, int relu, float* __restrict__ gx) {
+    const long total = (long)Bn * C * n;
+    const float invN = 1.0f / (float)((long)Bn * n);
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
+        const int c = (int)((i / n) % C);
+        float g = gy[i];
+        if (relu && !(y[i] > 0.0f)) g = 0.0f;
+        const float xh = (x[i] - mean[c]) * invstd[c];
+        gx[i] = gamma[c] * invstd[c] * (g - s1[c] * invN - xh * (s2[c] * invN));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// element-wise pieces of the GRU block / heads (models/update.py:20-27,40-49,86-99; Effi_MVS_plus.py:138-148)
+// ------------------------------------------------------------------------------------------------
+struct PwArgs {
+    const float* a; const float* b; const float* c; const float* d;
+    float* o0; float* o1; float* o2;
+    float s0, s1;
+    long n, inner;       // inner: elements per channel (EFFI_PW_SCALE_CH)
+    int C;
+};
+
+__global__ __launch_bounds__(TPB) void pointwise_kernel(int op, PwArgs p) {
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < p.n; i += (long)gridDim.x * TPB) {
+        switch (op) {
+            case EFFI_PW_ACT_BWD_RELU: p.o0[i] = (p.b[i] > 0.0f) ? p.a[i] : 0.0f; break;                      // a = g, b = y
+            case EFFI_PW_ACT_BWD_SIGMOID: { const float y = p.b[i]; p.o0[i] = p.a[i] * (y * (1.0f - y)); } break;
+            case EFFI_PW_ACT_BWD_TANH: { const float y = p.b[i]; p.o0[i] = p.a[i] * (1.0f - y * y); } break;
+            case EFFI_PW_TANH: p.o0[i] = tanhf(p.a[i]); break;
+            case EFFI_PW_RELU: p.o0[i] = fmaxf(p.a[i], 0.0f); break;
+            case EFFI_PW_SIGMOID: p.o0[i] = effi_sigmoid(p.a[i]); break;
+            case EFFI_PW_MUL: p.o0[i] = p.a[i] * p.b[i]; break;
+            case EFFI_PW_MUL_BWD: { const float g = p.a[i]; p.o0[i] = g * p.c[i]; p.o1[i] = g * p.b[i]; } break;   // b = x, c = y
+            case EFFI_PW_GRU: { const float z = p.a[i]; p.o0[i] = (1.0f - z) * p.b[i] + z * p.c[i]; } break;       // a = z, b = h, c = q
+            case EFFI_PW_GRU_BWD: {                                                                                // a = g, b = z, c = h, d = q
+                const float g = p.a[i], z = p.b[i];
+                p.o0[i] = g * (p.d[i] - p.c[i]);      // d/dz
+                p.o1[i] = g * (1.0f - z);             // d/dh
+                p.o2[i] = g * z;                      // d/dq
+            } break;
+            case EFFI_PW_INV_TO_DEPTH: p.o0[i] = effi_inv_to_depth(p.a[i], p.s0, p.s1); break;                      // s0 = lo, s1 = hi
+            case EFFI_PW_INV_TO_DEPTH_BWD: {                                                                       // a = g, b = inv
+                const float max_depth = 1.0f / p.s0, min_depth = 1.0f / p.s1;
+                const float min_disp = 1.0f / max_depth, max_disp = 1.0f / min_depth;
+                const float s = min_disp + (max_disp - min_disp) * p.b[i];
+                p.o0[i] = (s > 1e-4f) ? -p.a[i] * (max_disp - min_disp) / (s * s) : 0.0f;
+            } break;
+            case EFFI_PW_SCALE_CH: p.o0[i] = p.a[i] * p.b[(i / p.inner) % p.C]; break;                              // b = per-channel factor
+            default: break;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 1-D lookup backward (pro_bilinear_sampler, models/Effi_MVS_plus.py:102-134): the query coordinates carry no gradient on
+// this path (they come from detached depths); the looked-up vector receives g * (w0, w1) at (x0, x0 + 1).
+// One thread owns one pixel's D-vector, so the accumulation is a plain read-modify-write.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void lookup1d_bwd(float* __restrict__ gvol, long dstride, int Dp, float q_depth, float dmin, float dmax,
+                                             float g) {
+    const float scaled = 1.0f / q_depth;
+    const float min_disp = 1.0f / dmax, max_disp = 1.0f / dmin;
+    const float disp = (scaled - min_disp) / ((max_disp - min_disp) + 1e-10f);
+    const float dm1 = (float)(Dp - 1);
+    const float t = disp * dm1;
+    const float gg = 2.0f * t / dm1 - 1.0f;
+    float ix = ((gg + 1.0f) / 2.0f) * dm1;
+    ix = fminf(fmaxf(ix, -2.0f), dm1 + 2.0f);
+    const float x0f = floorf(ix);
+    const int x0 = (int)x0f;
+    const float w1 = ix - x0f, w0 = (x0f + 1.0f) - ix;
+    if (x0 >= 0 && x0 <= Dp - 1) gvol[x0 * dstride] += g * w0;
+    if (x0 + 1 >= 0 && x0 + 1 <= Dp - 1) gvol[(x0 + 1) * dstride] += g * w1;
+}
+
+__global__ void vol_lookup1d_bwd_kernel(float* __restrict__ gvol, long vds, long vps, int Dp, const float* __restrict__ query,
+                                        long qds, long qys, long qxs, int nq, const float* __restrict__ dmin,
+                                        const float* __restrict__ dmax, long rps, int h, int w, const float* __restrict__ gout) {
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= h * w) return;
+    const int y = p / w, x = p - y * w;
+    const float lo = dmin[p * rps], hi = dmax[p * rps];
+    for (int k = 0; k < nq; ++k)
+        lookup1d_bwd(gvol + p * vps, vds, Dp, query[k * qds + y * qys + x * qxs], lo, hi, gout[(long)k * h * w + p]);
+}
+
+// GetCost backward (models/Effi_MVS_plus.py:257-303): gcost [2*nq][hw] -> gcur [Dcur][hw], greg [Dreg][hw] (accumulated)
+__global__ void getcost_bwd_kernel(const float* __restrict__ inv_depth, const float* __restrict__ disp_range, int n_range,
+                                   int input_is_depth, const float* __restrict__ interval, float* __restrict__ gcur, long cds,
+                                   long cps, int Dcur, float* __restrict__ greg, long rds, long rps_, int Dreg,
+                                   const float* __restrict__ dmin, const float* __restrict__ dmax, long range_ps, int nq, int hw,
+                                   const float* __restrict__ gcost) {
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= hw) return;
+    const float itv = interval[0];
+    float depth = inv_depth[p];
+    if (!input_is_depth) depth = effi_inv_to_depth(depth, disp_range[0], disp_range[n_range - 1]);
+    const float dv = 1.0f / depth;
+    const float half = (float)(nq / 2) * itv;
+    const float smin = fmaxf(dv - half, 1e-4f);
+    const float smax = fminf(fmaxf(dv + half, 1e-4f), 1e4f);
+    const float step = (smax - smin) / (float)(nq - 1);
+    const float rlo = dmin[p * range_ps], rhi = dmax[p * range_ps];
+    for (int k = 0; k < nq; ++k) {
+        const float s = fmaxf(smin + (float)k * step, 1e-5f);
+        const float qd = 1.0f / s;
+        lookup1d_bwd(gcur + p * cps, cds, Dcur, qd, rlo, rhi, gcost[(long)k * hw + p]);
+        lookup1d_bwd(greg + p * rps_, rds, Dreg, qd, rlo, rhi, gcost[(long)(nq + k) * hw + p]);
+    }
+}
+
+// soft-argmin backward (models/Effi_MVS_plus.py:79-81): depth = sum_d p_d * hyp_d, p = softmax(logits)
+//   d depth / d logit_d = p_d * (hyp_d - depth)
+__global__ void softargmin_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ hyp, long dds, long dps, int D,
+                                      int hw, const float* __restrict__ gdepth, float* __restrict__ glogits) {
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= hw) return;
+    float m = -INFINITY;
+    for (int d = 0; d < D; ++d) m = fmaxf(m, logits[(long)d * hw + p]);
+    float sum = 0.0f;
+    for (int d = 0; d < D; ++d) sum += expf(logits[(long)d * hw + p] - m);
+    float dep = 0.0f;
+    for (int d = 0; d < D; ++d) dep += (expf(logits[(long)d * hw + p] - m) / sum) * hyp[d * dds + p * dps];
+    const float g = gdepth[p];
+    for (int d = 0; d < D; ++d) {
+        const float pr = expf(logits[(long)d * hw + p] - m) / sum;
+        glogits[(long)d * hw + p] = g * pr * (hyp[d * dds + p * dps] - dep);
+    }
+}
+
+// view-weighted aggregation backward (models/Effi_MVS_plus.py:48-53,67): out_d = sum_v s_vd w_v / (sum_v w_v + 1e-6)
+//   g s_vd = g_d w_v / den;   g w_v = sum_d g_d (s_vd - out_d) / den
+__global__ void view_aggregate_bwd_kernel(const float* __restrict__ sim_views, const float* __restrict__ weights, int S, int D, int hw,
+                                          const float* __restrict__ gout, float* __restrict__ gsim, float* __restrict__ gw) {
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= hw) return;
+    float wsum = 0.0f;
+    for (int v = 0; v < S; ++v) wsum += weights[(long)v * hw + p];
+    const float den = wsum + 1e-6f;
+    for (int v = 0; v < S; ++v) gw[(long)v * hw + p] = 0.0f;
+    for (int d = 0; d < D; ++d) {
+        float acc = 0.0f;
+        for (int v = 0; v < S; ++v) acc += sim_views[((long)v * D + d) * hw + p] * weights[(long)v * hw + p];
+        const float o = acc / den, g = gout[(long)d * hw + p];
+        for (int v = 0; v < S; ++v) {
+            const float s = sim_views[((long)v * D + d) * hw + p];
+            gsim[((long)v * D + d) * hw + p] = g * weights[(long)v * hw + p] / den;
+            gw[(long)v * hw + p] += g * (s - o) / den;
+        }
+    }
+}
+
+// convex upsampling backward (models/Effi_MVS_plus.py:167-178), ratio 2: up[2y+i][2x+j] = sum_k softmax_k(mask[k][i][j]) * nb_k,
+// nb_k = inv at (y + k/3 - 1, x + k%3 - 1) (zero outside).  gmask is written; ginv receives atomic adds (zero on entry).
+__global__ void convex_upsample2x_bwd_kernel(const float* __restrict__ inv, const float* __restrict__ mask, int h, int w,
+                                             const float* __restrict__ gup, float* __restrict__ gmask, float* __restrict__ ginv) {
+    const int p = blockIdx.x * TPB + threadIdx.x;
+    if (p >= h * w) return;
+    const int y = p / w, x = p - y * w;
+    const long hw = (long)h * w;
+    float nb[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+        nb[k] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? inv[(long)yy * w + xx] : 0.0f;
+    }
+    float gn[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) gn[k] = 0.0f;
+#pragma unroll
+    for (int ij = 0; ij < 4; ++ij) {
+        const int i = ij >> 1, j = ij & 1;
+        float m[9], mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {                       // mask channel = k*4 + i*2 + j  (view(N,1,9,r,r,H,W))
+            m[k] = mask[(long)(k * 4 + ij) * hw + p];
+            mx = fmaxf(mx, m[k]);
+        }
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { m[k] = expf(m[k] - mx); sum += m[k]; }
+        float up = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { m[k] = m[k] / sum; up += m[k] * nb[k]; }
+        const float g = gup[(long)(2 * y + i) * (2 * w) + 2 * x + j];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            gmask[(long)(k * 4 + ij) * hw + p] = g * m[k] * (nb[k] - up);
+            gn[k] += g * m[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w) unsafeAtomicAdd(&ginv[(long)yy * w + xx], gn[k]);
+    }
+}
+
+int split_for(long n) { return (int)max(1L, min(64L, n / 8192)); }
+
+}  // namespace
+
+// ================================================================================================
+extern "C" int effi_conv_wgrad_f32(const float* a, const float* b, int ca, int cb, int cb_total, int cb_off, int kd, int ks, int Da,
+                                   int ha, int wa, int Db, int hb, int wb, int sz, int sxy, float* dw, effi_stream_t stream) {
+    if (!a || !b || !dw || ca < 1 || cb < 1 || cb_off < 0 || cb_off + cb > cb_total) return EFFI_ERR_BADARG;
+    if (Da < 1 || ha < 1 || wa < 1 || Db < 1 || hb < 1 || wb < 1 || sz < 1 || sz > 2 || sxy < 1 || sxy > 2) return EFFI_ERR_BADARG;
+    hipStream_t s = effi_s(stream);
+    const long na = (long)Da * ha * wa;
+    const int strips = (int)max(1L, min(32L, na / 4096));
+#define EFFI_WG(KD_, KS_, CAB_)                                                                                            \
+    hipLaunchKernelGGL((wgrad_nd_kernel<KD_, KS_, CAB_>), dim3((ca + CAB_ - 1) / CAB_, cb, strips), dim3(TPB), 0, s, a, b, ca, \
+                       cb_total, cb_off, Da, ha, wa, Db, hb, wb, sz, sxy, dw)
+    if (kd == 1 && ks == 1) EFFI_WG(1, 1, 16);
+    else if (kd == 1 && ks == 3) EFFI_WG(1, 3, 8);
+    else if (kd == 1 && ks == 7) EFFI_WG(1, 7, 2);
+    else if (kd == 3 && ks == 3) EFFI_WG(3, 3, 4);
+    else return EFFI_ERR_UNSUPPORTED;
+#undef EFFI_WG
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_channel_sum_f32(const float* g, int B, int C, long n, float* out, effi_stream_t stream) {
+    if (!g || !out || B < 1 || C < 1 || n < 1) return EFFI_ERR_BADARG;
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, split_for((long)B * n)), dim3(TPB), 0, effi_s(stream), g, B, C, n, out);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_bn_moment_f32(const float* x, int B, int C, long n, const float* shift, int power, float* out,
+                                  effi_stream_t stream) {
+    if (!x || !out || B < 1 || C < 1 || n < 1 || (power != 1 && power != 2)) return EFFI_ERR_BADARG;
+    const dim3 grid(C, split_for((long)B * n));
+    if (power == 1) hipLaunchKernelGGL(bn_moment_kernel<1>, grid, dim3(TPB), 0, effi_s(stream), x, B, C, n, shift, out);
+    else hipLaunchKernelGGL(bn_moment_kernel<2>, grid, dim3(TPB), 0, effi_s(stream), x, B, C, n, shift, out);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_bn_apply_f32(const float* x, int B, int C, long n, const float* mean, const float* invstd, const float* gamma,
+                                 const float* beta, int relu, float* y, effi_stream_t stream) {
+    if (!x || !mean || !invstd || !gamma || !beta || !y || B < 1 || C < 1 || n < 1) return EFFI_ERR_BADARG;
+    const long total = (long)B * C * n;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)min((total + TPB - 1) / TPB, 16384L)), dim3(TPB), 0, effi_s(stream), x, B, C, n,
+                       mean, invstd, gamma, beta, relu, y);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_bn_bwd_f32(const float* gy, const float* y, const float* x, int B, int C, long n, const float* mean,
+                               const float* invstd, const float* gamma, int relu, float* s1, float* s2, float* gx,
+                               effi_stream_t stream) {
+    if (!gy || !y || !x || !mean || !invstd || !gamma || !s1 || !s2 || !gx || B < 1 || C < 1 || n < 1) return EFFI_ERR_BADARG;
+    hipStream_t s = effi_s(stream);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, split_for((long)B * n)), dim3(TPB), 0, s, gy, y, x, B, C, n, mean, invstd, relu, s1,
+                       s2);
+    const long total = (long)B * C * n;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)min((total + TPB - 1) / TPB, 16384L)), dim3(TPB), 0, s, gy, y, x, B, C, n, mean,
+                       invstd, gamma, s1, s2, relu, gx);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_pointwise_f32(int op, const float* a, const float* b, const float* c, const float* d, float s0, float s1, long n,
+                                  long inner, int C, float* o0, float* o1, float* o2, effi_stream_t stream) {
+    if (!a || !o0 || n < 1 || op < 0 || op >= EFFI_PW_COUNT) return EFFI_ERR_BADARG;
+    PwArgs p{a, b, c, d, o0, o1, o2, s0, s1, n, inner > 0 ? inner : 1, C > 0 ? C : 1};
+    hipLaunchKernelGGL(pointwise_kernel, dim3((unsigned)min((n + TPB - 1) / TPB, 16384L)), dim3(TPB), 0, effi_s(stream), op, p);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_vol_lookup1d_bwd_f32(float* gvol, long vds, long vps, int Dp, const float* query, long qds, long qys, long qxs,
+                                         int nq, const float* dmin, const float* dmax, long rps, int h, int w, const float* gout,
+                                         effi_stream_t stream) {
+    if (!gvol || !query || !dmin || !dmax || !gout || Dp < 2 || nq < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    hipLaunchKernelGGL(vol_lookup1d_bwd_kernel, dim3(effi_cdiv((long)h * w, TPB)), dim3(TPB), 0, effi_s(stream), gvol, vds, vps, Dp, query,
+                       qds, qys, qxs, nq, dmin, dmax, rps, h, w, gout);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_getcost_bwd_f32(const float* inv_depth, const float* disp_range, int n_range, int input_is_depth,
+                                    const float* interval, float* gcur, long cds, long cps, int Dcur, float* greg, long rds, long rps,
+                                    int Dreg, const float* dmin, const float* dmax, long range_ps, int nq, int h, int w,
+                                    const float* gcost, effi_stream_t stream) {
+    if (!inv_depth || !interval || !gcur || !greg || !dmin || !dmax || !gcost || nq < 2 || h < 1 || w < 1 || Dcur < 2 || Dreg < 2)
+        return EFFI_ERR_BADARG;
+    if (!input_is_depth && (!disp_range || n_range < 2)) return EFFI_ERR_BADARG;
+    hipLaunchKernelGGL(getcost_bwd_kernel, dim3(effi_cdiv((long)h * w, TPB)), dim3(TPB), 0, effi_s(stream), inv_depth, disp_range, n_range,
+                       input_is_depth, interval, gcur, cds, cps, Dcur, greg, rds, rps, Dreg, dmin, dmax, range_ps, nq, h * w, gcost);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_softargmin_bwd_f32(const float* logits, const float* hyp, long dds, long dps, int D, int hw, const float* gdepth,
+                                       float* glogits, effi_stream_t stream) {
+    if (!logits || !hyp || !gdepth || !glogits || D < 1 || hw < 1) return EFFI_ERR_BADARG;
+    hipLaunchKernelGGL(softargmin_bwd_kernel, dim3(effi_cdiv(hw, TPB)), dim3(TPB), 0, effi_s(stream), logits, hyp, dds, dps, D, hw, gdepth,
+                       glogits);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_view_aggregate_bwd_f32(const float* sim_views, const float* weights, int S, int D, int hw, const float* gout,
+                                           float* gsim, float* gw, effi_stream_t stream) {
+    if (!sim_views || !weights || !gout || !gsim || !gw || S < 1 || S > EFFI_MAX_VIEWS || D < 1 || hw < 1) return EFFI_ERR_BADARG;
+    hipLaunchKernelGGL(view_aggregate_bwd_kernel, dim3(effi_cdiv(hw, TPB)), dim3(TPB), 0, effi_s(stream), sim_views, weights, S, D, hw,
+                       gout, gsim, gw);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_convex_upsample2x_bwd_f32(const float* inv_depth, const float* mask, int h, int w, const float* gup, float* gmask,
+                                              float* ginv, effi_stream_t stream) {
+    if (!inv_depth || !mask || !gup || !gmask || !ginv || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    hipLaunchKernelGGL(convex_upsample2x_bwd_kernel, dim3(effi_cdiv((long)h * w, TPB)), dim3(TPB), 0, effi_s(stream), inv_depth, mask, h,
+                       w, gup, gmask, ginv);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}

@@ -701,6 +701,86 @@ __global__ __launch_bounds__(256) void homo_warp_bwd_kernel(const float* __restr
     }
 }
 
+// Backward of warpcorr_dyn_kernel (scope row n2; models/Effi_MVS_plus.py:184-251 under autograd): with s_vd = mean_c ref_c *
+// warp_v(src_v)_c at hypothesis d and sim_d = sum_v w_v s_vd / den, den = sum_v w_v + 1e-6, and g_d the incoming gradient:
+//   grad ref_c        = sum_{d,v} g_d w_v / (den C) * warp_vdc                       (plain store: the lane group owns its pixel)
+//   grad src_v[tap]_c += g_d w_v / (den C) * w_tap * ref_c                           (scatter, fp32 atomics; zero on entry)
+//   grad w_v (coarse) += sum_d g_d (s_vd - sim_d) / den                              (atomics into the 1/2^k-resolution map)
+// The hypotheses come from the detached current depth (models/Effi_MVS_plus.py:495): no gradient there.
+template <int C>
+__global__ __launch_bounds__(256) void warpcorr_dyn_bwd_kernel(const float* __restrict__ ref, EffiPtrList srcs, int S,
+                                                               const float* __restrict__ rt_all, const float* __restrict__ cur_depth,
+                                                               const float* __restrict__ interval, const float* __restrict__ view_w,
+                                                               int vw_shift, int h, int w, int D, const float* __restrict__ sim,
+                                                               const float* __restrict__ gsim, float* __restrict__ grad_ref,
+                                                               EffiOutList grad_srcs, float* __restrict__ grad_vw) {
+    using G = WarpGeom<C>;
+    int x, y, sub;
+    if (!tile_pixel<C>(blockIdx.x, gridDim.x, h, w, x, y, sub)) return;
+    const int hw = h * w, pix = y * w + x, sub4 = 4 * sub;
+    const float4 r4 = *reinterpret_cast<const float4*>(ref + (long)pix * C + sub4);
+    const float fx = (float)x, fy = (float)y;
+    const float inv = 1.0f / cur_depth[pix];
+    const float half = (float)(D / 2) * interval[0];
+    const float smin = fmaxf(inv - half, 1e-4f);
+    const float smax = fminf(fmaxf(inv + half, 1e-4f), 1e4f);
+    const float step = (smax - smin) / (float)(D - 1);
+    const int vh = h >> vw_shift, vw = w >> vw_shift;
+    const int vpix = (y >> vw_shift) * vw + (x >> vw_shift);
+    float wsum = 0.0f;
+    for (int v = 0; v < S; ++v) wsum = wsum + view_w[(long)v * vh * vw + vpix];
+    const float den = wsum + 1e-6f;
+    float4 gr = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int v = 0; v < S; ++v) {
+        const float* __restrict__ src = pick_view(srcs, v);
+        float* gs = grad_srcs.p[0];
+#pragma unroll
+        for (int i = 1; i <= EFFI_MAX_VIEWS; ++i)
+            if (v == i) gs = grad_srcs.p[i];
+        const float* __restrict__ rt = rt_all + v * 12;
+        const float rx = rt[0] * fx + rt[1] * fy + rt[2];
+        const float ry = rt[3] * fx + rt[4] * fy + rt[5];
+        const float rz = rt[6] * fx + rt[7] * fy + rt[8];
+        const float wv = view_w[(long)v * vh * vw + vpix];
+        float gwv = 0.0f;
+        for (int d = 0; d < D; ++d) {
+            const float dep = 1.0f / fmaxf(smin + (float)d * step, 1e-5f);
+            Taps t;
+            make_taps(rx * dep + rt[9], ry * dep + rt[10], rz * dep + rt[11], w, h, C, t);
+            float4 tv[4];
+            float4 wp = make_float4(0.0f, 0.0f, 0.0f, 0.0f);          // warped source, this lane's 4 channels
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                tv[k] = *reinterpret_cast<const float4*>(src + t.off[k] + sub4);
+                wp.x = fmaf(t.w[k], tv[k].x, wp.x);
+                wp.y = fmaf(t.w[k], tv[k].y, wp.y);
+                wp.z = fmaf(t.w[k], tv[k].z, wp.z);
+                wp.w = fmaf(t.w[k], tv[k].w, wp.w);
+            }
+            const float s_vd = effi_group_sum<G::LPP>(dot4(wp, r4)) / (float)C;
+            const float g = gsim[(long)d * hw + pix];
+            const float coef = g * wv / (den * (float)C);
+            gr.x = fmaf(coef, wp.x, gr.x);
+            gr.y = fmaf(coef, wp.y, gr.y);
+            gr.z = fmaf(coef, wp.z, gr.z);
+            gr.w = fmaf(coef, wp.w, gr.w);
+            gwv = fmaf(g, (s_vd - sim[(long)d * hw + pix]) / den, gwv);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (t.w[k] == 0.0f) continue;
+                const float cw = coef * t.w[k];
+                float* o = gs + t.off[k] + sub4;
+                unsafeAtomicAdd(o + 0, cw * r4.x);
+                unsafeAtomicAdd(o + 1, cw * r4.y);
+                unsafeAtomicAdd(o + 2, cw * r4.z);
+                unsafeAtomicAdd(o + 3, cw * r4.w);
+            }
+        }
+        if (sub == 0) unsafeAtomicAdd(&grad_vw[(long)v * vh * vw + vpix], gwv);
+    }
+    *reinterpret_cast<float4*>(grad_ref + (long)pix * C + sub4) = gr;
+}
+
 template <int C> int grid_blocks(int h, int w) {
     using G = WarpGeom<C>;
     return ((w + G::TW - 1) / G::TW) * ((h + G::TH - 1) / G::TH);
@@ -824,6 +904,31 @@ extern "C" int effi_warpcorr_dyn_f32(const float* ref_nhwc, const float* const* 
         case 32: hipLaunchKernelGGL(warpcorr_dyn_kernel<32>, dim3(grid_blocks<32>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples); break;
         case 16: hipLaunchKernelGGL(warpcorr_dyn_kernel<16>, dim3(grid_blocks<16>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples); break;
         case 8:  hipLaunchKernelGGL(warpcorr_dyn_kernel<8>, dim3(grid_blocks<8>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples); break;
+        default: return EFFI_ERR_UNSUPPORTED;
+    }
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_warpcorr_dyn_bwd_f32(const float* ref_nhwc, const float* const* src_nhwc, int S, const float* rt,
+                                         const float* cur_depth, const float* interval, const float* view_w, int vw_shift, int C, int h,
+                                         int w, int D, const float* sim, const float* grad_sim, float* grad_ref_nhwc,
+                                         float* const* grad_src_nhwc, float* grad_view_w, effi_stream_t stream) {
+    EffiPtrList l;
+    if (!fill_views(src_nhwc, S, l) || !ref_nhwc || !rt || !cur_depth || !interval || !view_w || !sim || !grad_sim || !grad_ref_nhwc ||
+        !grad_src_nhwc || !grad_view_w)
+        return EFFI_ERR_BADARG;
+    if (h < 2 || w < 2 || D < 2 || vw_shift < 0 || vw_shift > 4) return EFFI_ERR_BADARG;
+    if ((h >> vw_shift) << vw_shift != h || (w >> vw_shift) << vw_shift != w) return EFFI_ERR_BADARG;
+    EffiOutList g;
+    for (int i = 0; i <= EFFI_MAX_VIEWS; ++i) g.p[i] = (i < S) ? grad_src_nhwc[i] : nullptr;
+    for (int i = 0; i < S; ++i)
+        if (!g.p[i]) return EFFI_ERR_BADARG;
+    hipStream_t s = effi_s(stream);
+    switch (C) {
+        case 32: hipLaunchKernelGGL(warpcorr_dyn_bwd_kernel<32>, dim3(grid_blocks<32>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, grad_sim, grad_ref_nhwc, g, grad_view_w); break;
+        case 16: hipLaunchKernelGGL(warpcorr_dyn_bwd_kernel<16>, dim3(grid_blocks<16>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, grad_sim, grad_ref_nhwc, g, grad_view_w); break;
+        case 8:  hipLaunchKernelGGL(warpcorr_dyn_bwd_kernel<8>, dim3(grid_blocks<8>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, grad_sim, grad_ref_nhwc, g, grad_view_w); break;
         default: return EFFI_ERR_UNSUPPORTED;
     }
     EFFI_LAUNCH_CHECK();

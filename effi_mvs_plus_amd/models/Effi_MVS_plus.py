@@ -124,6 +124,9 @@ class DepthNet(nn.Module):
             raise NotImplementedError("DepthNet: group-wise correlation is instantiated for G=1 (the shipped model)")
         if pixel_wise_net is None:
             raise NotImplementedError("DepthNet: the unweighted average (pixel_wise_net=None) is not on the HIP path")
+        if self.training:
+            from .. import train_path
+            return train_path.depthnet(pixel_wise_net, cost_regularization, features, proj_matrices, depth_values)
         outs = []
         for b in range(features[0].shape[0]):
             outs.append(self.run([f[b] for f in features], proj_matrices[b].contiguous(), depth_values[b], num_depth,
@@ -146,6 +149,13 @@ class GetCost_initvolume(nn.Module):
             raise NotImplementedError("GetCost_initvolume: HIP path covers Inverse=True, G=1, weighted views")
         interval = depth_interval * inter_iter[iter] if inter_iter[iter] != 1 else depth_interval
         sims, samples = [], []
+        if torch.is_grad_enabled() and (self.training or any(f.requires_grad for f in features) or view_weights.requires_grad):
+            from .. import autograd as A          # differentiable form: gradients to the feature maps and the view weights
+            for b in range(depth_values.shape[0]):
+                s, d = A.warp_correlate_dyn(features[0][b], [f[b] for f in features[1:]], view_weights[b], proj_matrices[b],
+                                            depth_values[b, 0], interval[b].reshape(1), CostNum)
+                sims.append(s), samples.append(d)
+            return _stack(sims), _stack(samples)
         for b in range(depth_values.shape[0]):
             nhwc = ops.to_nhwc([f[b] for f in features])
             rt = ops.compose_rel_proj(proj_matrices[b].contiguous())
@@ -204,6 +214,11 @@ class GetCost(nn.Module):
         interval = depth_interval * inter_iter[iter] if inter_iter[iter] != 1 else depth_interval
         B, _, h, w = depth_values.shape
         n = h * w
+        if torch.is_grad_enabled() and (pro[0].requires_grad or pro[-1].requires_grad):
+            from .. import autograd as A          # differentiable form: gradients to the two cached volumes
+            planar = lambda v: v.reshape(B, h, w, v.shape[-1]).permute(0, 3, 1, 2)      # noqa: E731  ([B*h*w,1,1,D] -> [B,D,h,w])
+            return A.getcost(planar(pro[-1]), planar(pro[0]), depth_values, None, interval.reshape(B), depth_min_cur_volume,
+                             depth_max_cur_volume, CostNum, input_is_depth=True)
         outs = []
         for b in range(B):
             lo = depth_min_cur_volume[b] if depth_min_cur_volume.shape[0] == B else depth_min_cur_volume[0]
@@ -396,7 +411,9 @@ class Effi_MVS_plus(nn.Module):
         features: list over views of {"stageK": [B,C,h,w]}; cnet_depth: {"stageK": [B,hd+cd,h,w]};
         proj_matrices: {"stageK": [B,N,2,4,4]}; depth_values [B,384].
         """
-        _require_eval(self)
+        if self.training:
+            from .. import train_path
+            return train_path.hot_path(self, features, cnet_depth, proj_matrices, depth_values)
         B = depth_values.shape[0]
         outs = []
         for b in range(B):

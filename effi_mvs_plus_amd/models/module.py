@@ -16,10 +16,12 @@ from .. import ops, packing
 
 
 def _require_eval(mod):
+    """The fused single-sample launches (``run`` methods) are the inference form of a module; in training mode ``forward`` goes
+    through ``effi_mvs_plus_amd.train_path`` (differentiable operators, BatchNorm on batch statistics) instead."""
     if mod.training:
         raise NotImplementedError(
-            f"{type(mod).__name__}: the HIP path implements inference (eval mode) only; backward kernels are "
-            "the next scope row (SURVEY.md section 8(f) n2). Call model.eval().")
+            f"{type(mod).__name__}.run is the fused inference launch; in training mode call the module itself (its forward takes "
+            "the differentiable path of effi_mvs_plus_amd.train_path), or model.eval() for inference.")
 
 
 def _stack(ts):

@@ -55,7 +55,11 @@ class DepthHead(nn.Module):
     @ops.on_tensor_device
 
     def forward(self, x_d, act_fn=torch.tanh):
-        _require_eval(self)
+        if self.training:
+            if act_fn is not torch.tanh:
+                raise NotImplementedError("DepthHead (training): act_fn=torch.tanh, as the update block calls it")
+            from .. import train_path
+            return train_path.depth_head(self, x_d)
         w, b = _pack(self._c2, self.conv2)
         outs = []
         for x in _unbatched(x_d):
@@ -96,9 +100,11 @@ class ConvGRU(nn.Module):
     @ops.on_tensor_device
 
     def forward(self, h, *x_list):
-        _require_eval(self)
         if len(x_list) > 2:
             raise NotImplementedError("ConvGRU: at most two input tensors besides h")
+        if self.training:
+            from .. import train_path
+            return train_path.conv_gru(self, h, *x_list)
         xs = [_unbatched(x) for x in x_list]
         return _stack([self.run(hb, [x[i] for x in xs]) for i, hb in enumerate(_unbatched(h))])
 
@@ -175,7 +181,9 @@ class ProjectionInput(nn.Module):
     @ops.on_tensor_device
 
     def forward(self, disp, cost, context):
-        _require_eval(self)
+        if self.training:
+            from .. import train_path
+            return train_path.projection_input(self, disp, cost, context)
         d, c, x = _unbatched(disp), _unbatched(cost), _unbatched(context)
         return _stack([self.run(d[i], c[i], x[i]) for i in range(len(d))])
 
@@ -280,7 +288,10 @@ class BasicUpdateBlock(nn.Module):
     @ops.on_tensor_device
 
     def forward(self, net, depth_cost_func, inv_depth, context, seq_len=4, scale_inv_depth=None):
-        _require_eval(self)
+        if self.training:
+            from .. import train_path
+            return train_path.update_block(self, net, lambda inv, i: depth_cost_func(scale_inv_depth(inv)[1], iter=i), inv_depth,
+                                           context, seq_len)
         from .Effi_MVS_plus import GetCost, disp_to_depth     # late import (module cycle)
         B = net.shape[0]
         fused = (isinstance(depth_cost_func, functools.partial) and isinstance(depth_cost_func.func, GetCost)

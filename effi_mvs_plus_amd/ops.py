@@ -988,3 +988,163 @@ def upsample_nearest(x, f):
     out = torch.empty(Cc, h * f, w * f, device=x.device, dtype=torch.float32)
     check(_lib.lib().effi_upsample_nearest_f32(_p(x), Cc, h, w, f, _p(out), _stream()), "effi_upsample_nearest_f32")
     return out
+
+
+# =============================================================================================
+# scope row n2: training kernels (csrc/train_ops.hip, warpcorr_dyn backward); thin wrappers, shapes checked here
+# =============================================================================================
+PW_ACT_BWD = {ACT_RELU: 0, ACT_SIGMOID: 1, ACT_TANH: 2}
+PW_TANH, PW_RELU, PW_SIGMOID, PW_MUL, PW_MUL_BWD, PW_GRU, PW_GRU_BWD, PW_INV_TO_DEPTH, PW_INV_TO_DEPTH_BWD, PW_SCALE_CH = 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
+
+
+def conv_wgrad(a, b, dw, cb_off, kd, ks, stride=(1, 1)):
+    """dw[ca][cb_off + cb][taps] += sum_o a[ca][o] * b[cb][o*stride + tap - pad]   (a on the small grid, b on the large one;
+    [c,h,w] or [c,D,h,w]); see effi_conv_wgrad_f32."""
+    _t(a, "wgrad a"), _t(b, "wgrad b"), _t(dw, "wgrad dw")
+    if a.dim() == 3:
+        a, b = a.unsqueeze(1), b.unsqueeze(1)
+    ca, Da, ha, wa = a.shape
+    cb, Db, hb, wb = b.shape
+    sz, sxy = int(stride[0]), int(stride[1])
+    if (Da, ha, wa) != ((Db - 1) // sz + 1 if kd == 3 else Db, (hb - 1) // sxy + 1, (wb - 1) // sxy + 1):
+        raise ValueError(f"conv_wgrad: grids {tuple(a.shape)} / {tuple(b.shape)} do not match stride {stride}")
+    if dw.shape[0] != ca or dw.numel() != ca * dw.shape[1] * kd * ks * ks:
+        raise ValueError("conv_wgrad: dw shape")
+    check(_lib.lib().effi_conv_wgrad_f32(_p(a), _p(b), ca, cb, dw.shape[1], cb_off, kd, ks, Da, ha, wa, Db, hb, wb, sz, sxy, _p(dw),
+                                         _stream()), "effi_conv_wgrad_f32")
+    return dw
+
+
+def channel_sum(g):
+    """[B,C,...] -> [C] sums over batch and positions."""
+    _t(g, "channel_sum input")
+    B, Cc = g.shape[0], g.shape[1]
+    n = g.numel() // (B * Cc)
+    out = torch.zeros(Cc, device=g.device, dtype=torch.float32)
+    check(_lib.lib().effi_channel_sum_f32(_p(g), B, Cc, n, _p(out), _stream()), "effi_channel_sum_f32")
+    return out
+
+
+def bn_moments(x):
+    """[B,C,...] -> (mean [C], biased variance [C]) over batch and positions (two passes: sum, then centred squares)."""
+    _t(x, "bn input")
+    B, Cc = x.shape[0], x.shape[1]
+    n = x.numel() // (B * Cc)
+    mean = torch.zeros(Cc, device=x.device, dtype=torch.float32)
+    check(_lib.lib().effi_bn_moment_f32(_p(x), B, Cc, n, None, 1, _p(mean), _stream()), "effi_bn_moment_f32")
+    mean = mean / float(B * n)
+    var = torch.zeros(Cc, device=x.device, dtype=torch.float32)
+    check(_lib.lib().effi_bn_moment_f32(_p(x), B, Cc, n, _p(mean), 2, _p(var), _stream()), "effi_bn_moment_f32")
+    return mean, var / float(B * n)
+
+
+def bn_apply(x, mean, invstd, gamma, beta, relu):
+    _t(x, "bn input")
+    B, Cc = x.shape[0], x.shape[1]
+    y = torch.empty_like(x)
+    check(_lib.lib().effi_bn_apply_f32(_p(x), B, Cc, x.numel() // (B * Cc), _p(mean), _p(invstd), _p(gamma), _p(beta), int(relu), _p(y),
+                                       _stream()), "effi_bn_apply_f32")
+    return y
+
+
+def bn_bwd(gy, y, x, mean, invstd, gamma, relu):
+    """-> (gx, s1 = grad beta, s2 = grad gamma)."""
+    _t(gy, "bn grad"), _t(y, "bn output"), _t(x, "bn input")
+    B, Cc = x.shape[0], x.shape[1]
+    s1 = torch.zeros(Cc, device=x.device, dtype=torch.float32)
+    s2 = torch.zeros(Cc, device=x.device, dtype=torch.float32)
+    gx = torch.empty_like(x)
+    check(_lib.lib().effi_bn_bwd_f32(_p(gy), _p(y), _p(x), B, Cc, x.numel() // (B * Cc), _p(mean), _p(invstd), _p(gamma), int(relu),
+                                     _p(s1), _p(s2), _p(gx), _stream()), "effi_bn_bwd_f32")
+    return gx, s1, s2
+
+
+def pointwise(op, a, b=None, c=None, d=None, s0=0.0, s1=0.0, inner=1, C=1, n_out=1):
+    """One of the EFFI_PW_* element-wise ops over ``a.numel()`` elements -> 1..3 outputs shaped like ``a``."""
+    for t_ in (a, b, c, d):
+        if t_ is not None:
+            _t(t_, "pointwise operand")
+    outs = [torch.empty_like(a) for _ in range(n_out)]
+    o = outs + [None] * (3 - n_out)
+    check(_lib.lib().effi_pointwise_f32(op, _p(a), _p(b), _p(c), _p(d), float(s0), float(s1), a.numel(), inner, C, _p(o[0]), _p(o[1]),
+                                        _p(o[2]), _stream()), "effi_pointwise_f32")
+    return outs[0] if n_out == 1 else outs
+
+
+def vol_lookup1d_bwd(gout, Dp, query, dmin, dmax, h, w):
+    """Gradient of ``vol_lookup1d`` w.r.t. a planar [Dp,h,w] volume: gout [nq,h,w] -> [Dp,h,w]."""
+    _t(gout, "grad"), _t(query, "query")
+    nq, qh, qw = query.shape
+    if (qh, qw) == (h, w):
+        qys, qxs = qw, 1
+    elif (qh // 2, qw // 2) == (h, w):
+        qys, qxs = 2 * qw, 2
+    else:
+        raise ValueError("query resolution must equal the volume's or be twice it")
+    dmin_t, rps = _range_ptr(dmin, h, w)
+    dmax_t, _ = _range_ptr(dmax, h, w)
+    gvol = torch.zeros(Dp, h, w, device=gout.device, dtype=torch.float32)
+    check(_lib.lib().effi_vol_lookup1d_bwd_f32(_p(gvol), h * w, 1, Dp, _p(query), qh * qw, qys, qxs, nq, _p(dmin_t), _p(dmax_t), rps, h, w,
+                                               _p(gout), _stream()), "effi_vol_lookup1d_bwd_f32")
+    return gvol
+
+
+def getcost_bwd(gcost, x, disp_range, interval, Dcur, Dreg, dmin, dmax, nq, h, w, input_is_depth=False):
+    """Gradient of ``getcost`` w.r.t. planar cur [Dcur,h,w] and reg [Dreg,h,w] volumes: gcost [2nq,h,w] -> (gcur, greg)."""
+    _t(gcost, "grad"), _t(x, "inv_depth"), _t(interval, "interval")
+    dmin_t, gps = _range_ptr(dmin, h, w)
+    dmax_t, _ = _range_ptr(dmax, h, w)
+    gcur = torch.zeros(Dcur, h, w, device=x.device, dtype=torch.float32)
+    greg = torch.zeros(Dreg, h, w, device=x.device, dtype=torch.float32)
+    n_range = 0 if disp_range is None else disp_range.numel()
+    check(_lib.lib().effi_getcost_bwd_f32(_p(x), _p(disp_range), n_range, int(input_is_depth), _p(interval), _p(gcur), h * w, 1, Dcur,
+                                          _p(greg), h * w, 1, Dreg, _p(dmin_t), _p(dmax_t), gps, nq, h, w, _p(gcost), _stream()),
+          "effi_getcost_bwd_f32")
+    return gcur, greg
+
+
+def softargmin_bwd(logits, hyp, gdepth):
+    D, h, w = logits.shape
+    _t(logits, "logits"), _t(hyp, "hypotheses", contiguous=False), _t(gdepth, "grad")
+    hyp, dds, dps = _depth_strides(hyp, D, h, w)
+    gl = torch.empty_like(logits)
+    check(_lib.lib().effi_softargmin_bwd_f32(_p(logits), _p(hyp), dds, dps, D, h * w, _p(gdepth), _p(gl), _stream()), "effi_softargmin_bwd_f32")
+    return gl
+
+
+def view_aggregate_bwd(sim_views, weights, gout):
+    S, D, h, w = sim_views.shape
+    _t(sim_views, "sim_views"), _t(weights, "weights"), _t(gout, "grad")
+    gsim, gw = torch.empty_like(sim_views), torch.empty_like(weights)
+    check(_lib.lib().effi_view_aggregate_bwd_f32(_p(sim_views), _p(weights), S, D, h * w, _p(gout), _p(gsim), _p(gw), _stream()),
+          "effi_view_aggregate_bwd_f32")
+    return gsim, gw
+
+
+def convex_upsample2x_bwd(inv_depth, mask, gup):
+    _t(inv_depth, "inv_depth"), _t(mask, "mask"), _t(gup, "grad")
+    h, w = inv_depth.shape[-2:]
+    gmask = torch.empty_like(mask)
+    ginv = torch.zeros_like(inv_depth)
+    check(_lib.lib().effi_convex_upsample2x_bwd_f32(_p(inv_depth), _p(mask), h, w, _p(gup), _p(gmask), _p(ginv), _stream()),
+          "effi_convex_upsample2x_bwd_f32")
+    return gmask, ginv
+
+
+def warpcorr_dyn_bwd(ref_nhwc, srcs_nhwc, rt, cur_depth, interval, view_w, D, sim, grad_sim):
+    """Backward of ``warpcorr_dyn``: -> (grad_ref [h,w,C], [grad_src_v [h,w,C]], grad_view_w [S,vh,vw])."""
+    h, w, Cc = ref_nhwc.shape
+    S = len(srcs_nhwc)
+    for t_ in (ref_nhwc, rt, cur_depth, interval, view_w, sim, grad_sim):
+        _t(t_, "warpcorr_dyn_bwd operand")
+    vh = view_w.shape[1]
+    shift = 0
+    while (vh << shift) < h:
+        shift += 1
+    g_ref = torch.empty_like(ref_nhwc)
+    g_src = [torch.zeros_like(s_) for s_ in srcs_nhwc]
+    g_vw = torch.zeros_like(view_w)
+    check(_lib.lib().effi_warpcorr_dyn_bwd_f32(_p(ref_nhwc), _ptr_array(srcs_nhwc), S, _p(rt), _p(cur_depth), _p(interval), _p(view_w), shift,
+                                               Cc, h, w, D, _p(sim), _p(grad_sim), _p(g_ref), _ptr_array(g_src), _p(g_vw), _stream()),
+          "effi_warpcorr_dyn_bwd_f32")
+    return g_ref, g_src, g_vw

@@ -379,6 +379,82 @@ int effi_image_prepare_u8_f32(const unsigned char* img_hwc, int src_h, int src_w
 int effi_resize_linear_f32(const float* in_chw, int channels, int src_h, int src_w, int dst_h, int dst_w, float* out_chw,
                            effi_stream_t stream);
 
+/* ==== scope row n2: what makes the path trainable (train.py:229-263: model.train() -> forward -> loss.backward()) =============
+ * The reference gets these from torch autograd through nn.Conv2d / nn.Conv3d / nn.ConvTranspose3d / nn.BatchNorm / F.grid_sample;
+ * here every one is an explicit kernel.  Input gradients of the convolutions reuse the forward entries above with re-arranged
+ * weights (effi_mvs_plus_amd/autograd.py); the entries below are the rest. */
+
+/* Weight gradient of every convolution on the path:  dw[a][cb_off + b][tap] += sum_o A[a][o] * B[b][o*stride + tap - pad],
+ * A planar [ca][Da][ha][wa] (small grid), B planar [cb][Db][hb][wb] (large grid), tap = (kz, ky, kx) of a kd x ks x ks kernel,
+ * pad = k/2, stride (sz, sxy, sxy) in {1, 2}.  dw planar [ca][cb_total][kd*ks*ks], ACCUMULATED (atomics; zero it first).
+ *   nn.Conv2d / nn.Conv3d (models/module.py:124-166, models/update.py:14-15,36-38,73-81,109-112): A = grad_out, B = input
+ *     -> torch's [cout][cin][k..]; a concatenated input is handled per part (cb_off = its first channel).
+ *   nn.ConvTranspose3d (models/module.py:168-209): A = input, B = grad_out -> torch's [cin][cout][k..].
+ * (kd, ks) in {(1,1), (1,3), (1,7), (3,3)}; 2-D: Da = Db = 1. */
+int effi_conv_wgrad_f32(const float* a, const float* b, int ca, int cb, int cb_total, int cb_off, int kd, int ks, int Da, int ha,
+                        int wa, int Db, int hb, int wb, int sz, int sxy, float* dw, effi_stream_t stream);
+/* out[c] += sum over batch and positions of g [B][C][n]  (bias gradients). */
+int effi_channel_sum_f32(const float* g, int B, int C, long n, float* out, effi_stream_t stream);
+
+/* nn.BatchNorm2d / nn.BatchNorm3d on batch statistics (models/module.py:148-157,191-200,217-220), x planar [B][C][n]:
+ *   effi_bn_moment_f32: out[c] += sum (x - shift[c])^power   (power 1 with shift = NULL: sum; power 2 with shift = mean);
+ *   effi_bn_apply_f32:  y = (x - mean) * invstd * gamma + beta, then ReLU if relu != 0;
+ *   effi_bn_bwd_f32:    s1[c] += sum g', s2[c] += sum g' * xhat (both zero on entry), then
+ *                       gx = gamma * invstd * (g' - s1/N - xhat * s2/N), g' = gy masked by y > 0 when relu != 0.
+ *                       (grad gamma = s2, grad beta = s1.) */
+int effi_bn_moment_f32(const float* x, int B, int C, long n, const float* shift, int power, float* out, effi_stream_t stream);
+int effi_bn_apply_f32(const float* x, int B, int C, long n, const float* mean, const float* invstd, const float* gamma,
+                      const float* beta, int relu, float* y, effi_stream_t stream);
+int effi_bn_bwd_f32(const float* gy, const float* y, const float* x, int B, int C, long n, const float* mean, const float* invstd,
+                    const float* gamma, int relu, float* s1, float* s2, float* gx, effi_stream_t stream);
+
+/* Element-wise pieces of the GRU block and heads, forward and backward (models/update.py:20-27,40-49,86-99;
+ * models/Effi_MVS_plus.py:138-148).  n elements; unused pointers NULL. */
+#define EFFI_PW_ACT_BWD_RELU     0   /* o0 = a * (b > 0)            a = grad, b = the activation's OUTPUT */
+#define EFFI_PW_ACT_BWD_SIGMOID  1   /* o0 = a * b (1 - b) */
+#define EFFI_PW_ACT_BWD_TANH     2   /* o0 = a * (1 - b^2) */
+#define EFFI_PW_TANH             3   /* o0 = tanh(a) */
+#define EFFI_PW_RELU             4   /* o0 = max(a, 0) */
+#define EFFI_PW_SIGMOID          5   /* o0 = sigmoid(a) */
+#define EFFI_PW_MUL              6   /* o0 = a * b                  (r * h, update.py:46) */
+#define EFFI_PW_MUL_BWD          7   /* o0 = a * c, o1 = a * b      a = grad, b = x, c = y of x * y */
+#define EFFI_PW_GRU              8   /* o0 = (1 - a) b + a c        a = z, b = h, c = q (update.py:48) */
+#define EFFI_PW_GRU_BWD          9   /* o0 = a (d - c) [z], o1 = a (1 - b) [h], o2 = a b [q];  a = grad, b = z, c = h, d = q */
+#define EFFI_PW_INV_TO_DEPTH     10  /* o0 = 1 / max(lo + (hi - lo) a, 1e-4); s0 = lo, s1 = hi (scale_inv_depth) */
+#define EFFI_PW_INV_TO_DEPTH_BWD 11  /* o0 = grad of the above w.r.t. b = inv; a = grad */
+#define EFFI_PW_SCALE_CH         12  /* o0[i] = a[i] * b[(i / inner) % C]  (Dropout2d: per-(sample, channel) factors) */
+#define EFFI_PW_COUNT            13
+int effi_pointwise_f32(int op, const float* a, const float* b, const float* c, const float* d, float s0, float s1, long n, long inner,
+                       int C, float* o0, float* o1, float* o2, effi_stream_t stream);
+
+/* Backward of effi_vol_lookup1d_f32 w.r.t. the looked-up volume (pro_bilinear_sampler, models/Effi_MVS_plus.py:102-134; the query
+ * coordinates come from detached depths): gvol (layout as the forward's vol) is ACCUMULATED without atomics (a thread owns a pixel). */
+int effi_vol_lookup1d_bwd_f32(float* gvol, long vol_dstride, long vol_pstride, int Dp, const float* query, long q_dstride,
+                              long q_ystride, long q_xstride, int nq, const float* dmin, const float* dmax, long range_pstride, int h,
+                              int w, const float* gout, effi_stream_t stream);
+/* Backward of effi_getcost_f32 w.r.t. the two cached volumes (GetCost.forward, models/Effi_MVS_plus.py:257-303):
+ * gcost [2*nq][h*w] -> gcur, greg accumulated. */
+int effi_getcost_bwd_f32(const float* inv_depth, const float* disp_range, int n_range, int input_is_depth, const float* interval,
+                         float* gcur, long cur_dstride, long cur_pstride, int Dcur, float* greg, long reg_dstride, long reg_pstride,
+                         int Dreg, const float* dmin, const float* dmax, long range_pstride, int nq, int h, int w, const float* gcost,
+                         effi_stream_t stream);
+/* Backward of the soft-argmin (models/Effi_MVS_plus.py:79-81): glogits[d] = gdepth * p_d * (hyp_d - depth). */
+int effi_softargmin_bwd_f32(const float* logits, const float* hyp, long depth_dstride, long depth_pstride, int D, int hw,
+                            const float* gdepth, float* glogits, effi_stream_t stream);
+/* Backward of effi_view_aggregate_f32 (models/Effi_MVS_plus.py:48-53,67): gsim [S][D][hw], gw [S][hw] are written. */
+int effi_view_aggregate_bwd_f32(const float* sim_views, const float* weights, int S, int D, int hw, const float* gout, float* gsim,
+                                float* gw, effi_stream_t stream);
+/* Backward of the convex x2 upsampling (models/Effi_MVS_plus.py:167-178): gup [2h][2w] -> gmask [36][h][w] (written),
+ * ginv [h][w] (atomic adds; zero on entry). */
+int effi_convex_upsample2x_bwd_f32(const float* inv_depth, const float* mask, int h, int w, const float* gup, float* gmask, float* ginv,
+                                   effi_stream_t stream);
+/* Backward of effi_warpcorr_dyn_f32 (GetCost_initvolume.forward, models/Effi_MVS_plus.py:184-251): sim = the forward's output,
+ * grad_sim [D][h*w]; grad_ref_nhwc is written; grad_src_nhwc[v] and grad_view_w [S][h>>k][w>>k] must be ZERO on entry (atomics). */
+int effi_warpcorr_dyn_bwd_f32(const float* ref_nhwc, const float* const* src_nhwc, int S, const float* rt, const float* cur_depth,
+                              const float* interval, const float* view_w, int vw_shift, int C, int h, int w, int D, const float* sim,
+                              const float* grad_sim, float* grad_ref_nhwc, float* const* grad_src_nhwc, float* grad_view_w,
+                              effi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,8 +16,11 @@ implemented by the torch build in this image (2.10 CPU).
 
 Style: weights come in as a flat ``state_dict`` (the reference's key names) and every function is
 a pure function of tensors; nothing here is an ``nn.Module``.  All ``file:line`` citations are
-relative to the reference repository root.  Only eval-mode semantics are restated (BatchNorm uses
-running statistics, Dropout2d is the identity).
+relative to the reference repository root.  Eval-mode semantics by default (BatchNorm uses running
+statistics, Dropout2d is the identity); ``with training(dropout_p):`` switches to the reference's
+``model.train()`` semantics (batch statistics + running-stat update with momentum 0.1, Dropout2d at
+update.py:22-23,97-98) so that torch autograd through these functions is the training-path checker
+of scope row n2 (pinned against the imported reference in tests/test_oracle_vs_reference.py).
 """
 from __future__ import annotations
 
@@ -33,6 +36,35 @@ BN_EPS = 1e-5  # nn.BatchNorm2d / nn.BatchNorm3d default, models/module.py:148,1
 # reference-style PyTorch-ROCm baseline"  times the path that way.  SYNC_COUNT counts them.
 LITERAL_SYNCS = False
 SYNC_COUNT = 0
+
+# model.train() semantics (train.py:229-263): BatchNorm on batch statistics (updating the running ones in ``sd`` in place),
+# Dropout2d(p) where the reference has it.
+TRAINING = False
+DROPOUT_P = 0.1      # nn.Dropout2d(p=0.1), models/update.py:18,84
+BN_MOMENTUM = 0.1    # Conv3d / Deconv3d / Conv2d wrappers pass bn_momentum=0.1 (module.py:35,127,171); nn.BatchNorm2d default too
+
+
+class training:
+    def __init__(self, dropout_p=0.1):
+        self.p = dropout_p
+
+    def __enter__(self):
+        global TRAINING, DROPOUT_P
+        self._before = (TRAINING, DROPOUT_P)
+        TRAINING, DROPOUT_P = True, self.p
+        return self
+
+    def __exit__(self, *exc):
+        global TRAINING, DROPOUT_P
+        TRAINING, DROPOUT_P = self._before
+        return False
+
+
+def _dropout2d(x):
+    """``self.dropout(x)`` under ``if self.training`` (models/update.py:22-23,97-98)."""
+    if TRAINING and DROPOUT_P > 0:
+        return F.dropout2d(x, DROPOUT_P, True)
+    return x
 
 
 class literal_syncs:
@@ -52,7 +84,13 @@ class literal_syncs:
 # small layer helpers
 # --------------------------------------------------------------------------------------------
 def _bn(x, sd, prefix):
-    """Eval-mode batch norm with running statistics (models/module.py:148-157,217-220)."""
+    """Batch norm (models/module.py:148-157,217-220): running statistics in eval mode; batch statistics in training mode,
+    where the running statistics in ``sd`` are updated in place exactly as nn.BatchNorm does."""
+    if TRAINING:
+        if prefix + ".num_batches_tracked" in sd:
+            sd[prefix + ".num_batches_tracked"] += 1
+        return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
+                            sd[prefix + ".weight"], sd[prefix + ".bias"], True, BN_MOMENTUM, BN_EPS)
     return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"],
                         sd[prefix + ".weight"], sd[prefix + ".bias"], False, 0.0, BN_EPS)
 
@@ -286,7 +324,7 @@ def depthnet(sd, features, proj_matrices, depth_values, num_depth, regnet_prefix
         warped = homo_warping_new(src, compose_projection(sp), ref_new, depth_values)
         warped = warped.view(B, G, C // G, num_depth, H, W)
         sim = (warped * ref_g.unsqueeze(3)).mean(2)                              # [B,G,D,H,W]
-        p = F.softmax(sim.squeeze(1), dim=1)
+        p = F.softmax(sim.squeeze(1).detach(), dim=1)                            # :43 (detached: no gradient through the entropy)
         entropy = (-p * torch.log(p + 1e-7)).sum(dim=1, keepdim=True)
         vw = pixelwise_net(sd, pixelwise_prefix, entropy)                        # [B,1,H,W]
         view_weights.append(vw)
@@ -354,7 +392,7 @@ def projection_input(sd, prefix, disp, cost, context):
     dfm = F.relu(conv2d(dfm, sd, prefix + ".convd2", 1))
     x = conv2d(torch.cat([cor, dfm], dim=1), sd, prefix + ".convd", 1)
     x = conv2d(torch.cat([x, context], dim=1), sd, prefix + ".convc", 0)
-    return F.relu(x)
+    return _dropout2d(F.relu(x))                                      # update.py:95-98
 
 
 def conv_gru(sd, prefix, h, x):
@@ -368,7 +406,7 @@ def conv_gru(sd, prefix, h, x):
 
 def depth_head(sd, prefix, x):
     """``DepthHead.forward`` (eval, act_fn=tanh).  models/update.py:20-27."""
-    return torch.tanh(conv2d(F.relu(conv2d(x, sd, prefix + ".conv1", 1)), sd, prefix + ".conv2", 1))
+    return torch.tanh(_dropout2d(conv2d(F.relu(conv2d(x, sd, prefix + ".conv1", 1)), sd, prefix + ".conv2", 1)))   # :21-27
 
 
 def mask_head(sd, prefix, net):
@@ -380,6 +418,7 @@ def update_block(sd, prefix, net, depth_cost_func, inv_depth, context, seq_len, 
     """``BasicUpdateBlock.forward`` (eval, UpMask=True).  models/update.py:114-141."""
     inv_list, mask_list = [], []
     for i in range(seq_len):
+        inv_depth = inv_depth.detach()                                  # update.py:121
         cost = depth_cost_func(scale_inv_depth(inv_depth)[1], i)
         x = projection_input(sd, prefix + ".encoder", inv_depth, cost, context)
         net = conv_gru(sd, prefix + ".depth_gru", net, x)
@@ -477,7 +516,7 @@ def hot_path(sd, features, context, proj_matrices, depth_values, ndepths=(48, 8,
             cur_depth = out["depth"].unsqueeze(1)
             preds = [out["depth"]]
         else:
-            cur_depth = preds[-1].unsqueeze(1)
+            cur_depth = preds[-1].unsqueeze(1).detach()                # models/Effi_MVS_plus.py:494-495
             view_weights = F.interpolate(view_weights, scale_factor=2, mode="nearest")
             cur_volume, samples_ = getcost_initvolume(cur_depth, feats, pm, depth_interval * INTERVAL_RATIO[s],
                                                       view_weights, ndepths[s])
@@ -519,6 +558,20 @@ def hot_path(sd, features, context, proj_matrices, depth_values, ndepths=(48, 8,
     if return_intermediates:
         res["intermediates"] = inter
     return res
+
+
+def mvs_loss(inputs, depth_gt_ms, mask_ms, dloss, loss_rate=0.9):
+    """Smooth-L1 over the cascade's outputs, geometric weights.  models/module.py:526-552 -> (total, {l_i})."""
+    total = torch.tensor(0.0, dtype=torch.float32, device=mask_ms["stage1"].device)
+    per = {}
+    n = len(inputs)
+    for i, est in enumerate(inputs):
+        key = "stage{}".format(dloss[i])
+        mask = mask_ms[key] > 0.5
+        li = F.smooth_l1_loss(est[mask], depth_gt_ms[key][mask], reduction="mean")
+        per["l{}".format(i)] = li
+        total = total + (1.0 if i == 0 else loss_rate ** (n - i - 1)) * li
+    return total, per
 
 
 def full_forward(sd, imgs, proj_matrices, depth_values, **kw):

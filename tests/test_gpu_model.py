@@ -259,15 +259,15 @@ def test_hip_graph_replay_is_bitwise_equal_to_eager(precision):
             g(samples[0][0][:2], *samples[0][1:])
 
 
-def test_training_mode_and_cpu_are_refused():
+def test_cpu_tensors_are_refused():
     from effi_mvs_plus_amd._lib import EffiLibraryError
     net, _ = build_model("8,8,8", seed=1, device=DEV)
     imgs, pm, dv = synth.synth_sample(64, 96, 3, seed=0)
-    net.train()
-    with pytest.raises(NotImplementedError):
-        net(imgs.to(DEV), {k: v.to(DEV) for k, v in pm.items()}, dv.to(DEV))
     net.eval().cpu()
     with pytest.raises(EffiLibraryError):
+        net(imgs, pm, dv)
+    net.train()
+    with pytest.raises(EffiLibraryError):                # the training path has no CPU fallback either
         net(imgs, pm, dv)
 
 

@@ -93,8 +93,10 @@ def test_product_fails_loudly_without_gpu():
     with pytest.raises(EffiLibraryError):                # CPU tensors: no fallback
         net(imgs, pm, dv)
     net.train()
-    with pytest.raises(NotImplementedError):
-        net.forward_hot([], {}, {}, dv)
+    with pytest.raises(EffiLibraryError):                # training mode takes the differentiable HIP path: no CPU fallback either
+        net(imgs, pm, dv)
+    with pytest.raises(NotImplementedError):             # the fused single-sample launches are inference only
+        net.cost_regularization.run(torch.zeros(1, 8, 8, 8))
 
 
 def test_product_never_imports_the_oracle():

@@ -57,3 +57,74 @@ def test_our_modules_load_the_shipped_checkpoint_strictly():
     sd = torch.load(ckpt, map_location="cpu", weights_only=True)["model"]
     res = net.load_state_dict(sd, strict=True)
     assert not res.missing_keys and not res.unexpected_keys
+
+
+def _loss_inputs(H, W, seed):
+    """Synthetic ground truth for mvs_loss: per-stage depth maps + masks (stage k at 1/8, 1/4, 1/2, 1 of the image)."""
+    g = torch.Generator().manual_seed(seed)
+    gt, mask = {}, {}
+    for k, f in (("stage1", 8), ("stage2", 4), ("stage3", 2), ("stage4", 1)):
+        gt[k] = synth.DEPTH_MIN_MM + (synth.DEPTH_MAX_MM - synth.DEPTH_MIN_MM) * torch.rand(1, H // f, W // f, generator=g)
+        mask[k] = (torch.rand(1, H // f, W // f, generator=g) > 0.3).float()
+    return gt, mask
+
+
+DLOSS = [1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4]       # train.py:246: which ground-truth scale each of the 13 outputs is compared with
+
+
+@pytest.mark.parametrize("dropout_p", [0.0, 0.1])
+def test_training_mode_loss_and_gradients_match_the_reference(dropout_p):
+    """Scope row n2's checker: torch autograd through the oracle in training mode (batch-statistics BatchNorm, Dropout2d, the
+    detach points of update.py:121 and Effi_MVS_plus.py:495) reproduces the reference's model.train() forward, loss and
+    parameter gradients on CPU.  The FPN is included (its BatchNorms also run on batch statistics)."""
+    ref, net = reference_model("8,8,8")
+    sd = synth.randomize_state_dict(net.state_dict(), seed=11)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = dropout_p
+    H, W, N = 64, 96, 3
+    imgs, pm, dv = synth.synth_sample(H, W, N, seed=6)
+    gt, mask = _loss_inputs(H, W, 1)
+    torch.manual_seed(123)
+    out = net(imgs, pm, dv)
+    loss, _ = ref.module.mvs_loss(out["depth"], gt, mask, DLOSS)
+    loss.backward()
+    want = {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+    want_stats = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k or "num_batches" in k}
+
+    # the reference registers some modules under two names (update_block.N / update_block_depthN+1, CSP_R.N / CSP_RN+1): tie the
+    # aliases to one leaf tensor, as the shared nn.Parameter is
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    groups = {}
+    for k, p_ in net.named_parameters(remove_duplicate=False):
+        groups.setdefault(id(p_), []).append(k)
+    leaves = {}
+    for ks in groups.values():
+        leaf = sd2[ks[0]].requires_grad_(True)
+        for k in ks:
+            sd2[k] = leaf
+            leaves[k] = leaf
+    bgroups = {}
+    for k, b_ in net.named_buffers(remove_duplicate=False):
+        bgroups.setdefault(id(b_), []).append(k)
+    for ks in bgroups.values():
+        for k in ks[1:]:
+            sd2[k] = sd2[ks[0]]
+    torch.manual_seed(123)
+    with O.training(dropout_p):
+        got = O.full_forward(sd2, imgs, pm, dv, ndepths=(8, 8, 8))
+        loss2, _ = O.mvs_loss(got["depth"], gt, mask, DLOSS)
+    loss2.backward()
+    assert torch.equal(loss2.detach(), loss.detach()), (float(loss2), float(loss))
+    for a, b in zip(got["depth"], out["depth"]):
+        assert torch.equal(a.detach(), b.detach())
+    n_checked = 0
+    for k, g in want.items():
+        assert leaves[k].grad is not None, k
+        assert torch.allclose(leaves[k].grad, g, rtol=1e-5, atol=1e-7 * float(g.abs().max()) + 1e-12), k
+        n_checked += 1
+    assert n_checked > 150
+    for k, v in want_stats.items():                     # running statistics were updated the same way
+        assert torch.allclose(sd2[k].detach().float(), v.float(), rtol=1e-6, atol=1e-7), k
