@@ -34,7 +34,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3                 # MI355X_MICROARCH.md, dense fp32 
 PEAK_BF16_MFMA_TFLOPS = 2500.0                # dense bf16 matrix peak; a split-precision product costs three bf16 MFMAs
 PEAK_HBM_GBPS = 8000.0
 DTYPE = {"split": "f32 (3x3 MFMA convs: products as 3 bf16 partial products hi*hi+hi*lo+lo*hi, f32 accumulate; all else f32)",
-         "fp32": "f32"}
+         "fp32": "f32",
+         "bf16": "bf16 operands in the 3x3 / 3-D MFMA convs (hi*hi only), f32 accumulate; all else f32 -- NOT fp32-grade, own tolerance 1e-2"}
 
 
 def self_launch(n, backend, ndev):
@@ -68,7 +69,7 @@ def main():
                     help="also time the reference-style composite PyTorch-ROCm path (the oracle's op sequence run on the GPU); 0 = skip")
     ap.add_argument("--profile-key", default=None, help="kernel key to bracket with events (default: auto = largest total time)")
     ap.add_argument("--no-whole-forward", action="store_true", help="skip the secondary whole-forward timings (profiling runs)")
-    ap.add_argument("--precision", default=None, choices=["split", "fp32"],
+    ap.add_argument("--precision", default=None, choices=["split", "fp32", "bf16"],
                     help="arithmetic of the 3x3 MFMA convolutions (default: the library default, EFFI_MVS_PRECISION or 'split')")
     ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
                     help="graph (default): the step copies its inputs into the static buffers of a captured hipGraph of the hot path "
@@ -258,6 +259,7 @@ def main():
     ksum = prof.summary()[key]
 
     result = None
+    bf16_outputs = None
     if rank == 0:
         views = args.steps * world
         avg_ms = ksum["ms"] / ksum["launches"]
@@ -319,7 +321,7 @@ def main():
     # same way as the headline (its own captured graph, K replays + output clones) and, for reference, eagerly -- and the
     # distance between the two modes' final depth maps (normalised by the depth range, as the parity tests do)
     if rank == 0 and world == 1 and not args.no_other_precision:
-        other = "fp32" if precision == "split" else "split"
+        other = "fp32" if precision != "fp32" else "split"
         with torch.no_grad():
             ref_out = step(0)["depth"][-1].clone()
             ops.set_precision(other)
@@ -369,6 +371,35 @@ def main():
                 ops.set_profile(None)
             result["eager_launch"] = {"value": args.steps / dt_eager, "unit": "views/s", "ms_per_step": dt_eager / args.steps * 1e3,
                                       "note": "same kernels enqueued from Python (~100 launches per view): the host needs about as long as the GPU"}
+        # BASELINE.json's literal "bf16 (MFMA 3D-conv path)" configuration: the same kernels compiled with plain bf16 operands (hi*hi
+        # only, fp32 accumulation), timed like the headline.  Its own line with its own tolerance; never the headline.
+        if precision != "bf16" and graphed is not None:
+            from effi_mvs_plus_amd.graph import HotPathGraph
+            try:
+                ops.set_precision("bf16")
+                with torch.no_grad():
+                    bg = HotPathGraph(net, *inputs[0], slots=n_scenes)
+                    for i in range(n_scenes):
+                        bg.load(i, *inputs[i % n_scenes])
+                    bf16_outputs = [d_.clone() for d_ in bg.replay(0)["depth"]]
+                    bg.replay(1)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    keep = []
+                    for i in range(args.steps):
+                        o = bg.replay(i % n_scenes)
+                        keep.append((o["depth"][-1].clone(), o["photometric_confidence"].clone()))
+                    torch.cuda.synchronize()
+                    dtb = time.perf_counter() - t0
+                result["bf16_operands"] = {"value": args.steps / dtb, "unit": "views/s", "ms_per_step": dtb / args.steps * 1e3, "dtype": DTYPE["bf16"],
+                                           "launch": "hipGraph replay, as the headline"}
+                del bg, keep
+            except Exception as exc:
+                result["bf16_operands"] = {"error": f"{type(exc).__name__}: {exc}"}
+                bf16_outputs = None
+            finally:
+                ops.set_precision(precision)
+            torch.cuda.empty_cache()
         result["other_precision"] = {"mode": other, "dtype": DTYPE[other],
                                      "graph_replay": other_graph,        # like-for-like with the headline line
                                      "eager": {"value": args.steps / dt_other, "unit": "views/s", "ms_per_step": dt_other / args.steps * 1e3},
@@ -629,6 +660,12 @@ def main():
                 "pass": bool(max(x["mean_norm"] for x in per) <= 1e-3 and max(x["p99_norm"] for x in per) <= 5e-3 and cf["mean_norm"] <= 1e-3),
                 "note": f"{len(per)} depth maps + confidence of the timed workload ({args.workload}, view 0, precision {precision}) vs "
                         "oracle/effi_oracle.py on the host; |d - d_ref| / (depth_max - depth_min)"}
+            if bf16_outputs is not None:        # parity of the bf16-operand variant timed above (own tolerance: final depth <= 1e-2)
+                perb = [dist_(a_, b_, rng) for a_, b_ in zip(bf16_outputs, want["depth"])]
+                result["bf16_operands"]["parity_vs_oracle"] = {
+                    "final_depth": perb[-1], "worst_depth_mean_norm": max(x["mean_norm"] for x in perb),
+                    "worst_depth_p99_norm": max(x["p99_norm"] for x in perb), "gate": {"final_depth_mean_norm": 1e-2},
+                    "pass": bool(perb[-1]["mean_norm"] <= 1e-2)}
     if rank == 0:
         print(json.dumps(result))
     if distributed:

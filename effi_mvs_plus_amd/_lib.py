@@ -80,6 +80,13 @@ SIGNATURES = {
     "effi_warpcorr_dyn_bwd_f32": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 
+# plain-bf16-operand variants (hi*hi only) of the split-precision convolution entries: same signatures, suffix _bf16
+BF16X3_ENTRIES = ("effi_conv2d_k3_bf16x3_pair_f32", "effi_conv2d_k3_bf16x3_f32", "effi_conv2d_k3_k1_bf16x3_f32",
+                  "effi_conv2d_k3_k1_up2x_bf16x3_f32", "effi_conv3d_k3s1_bf16x3_f32", "effi_conv3d_k3s1_roll_bf16x3_f32",
+                  "effi_conv3d_k3s1_roll_bf16x3_pair_f32", "effi_deconv3d_k3s2_bf16x3_f32")
+for _n in BF16X3_ENTRIES:
+    SIGNATURES[_n + "_bf16"] = SIGNATURES[_n]
+
 # entry points whose return type is not the int status code (bound explicitly in lib())
 NON_STATUS_SYMBOLS = ("effi_error_string", "effi_workspace_bytes", "effi_get_workspace")
 

@@ -14,7 +14,23 @@
 // Epilogues (bias, activation, GRU gating, depth-head update) are fused; see EFFI_EPI_* in the header.
 #include "common.hpp"
 
+// This file is compiled twice (csrc/Makefile): as it stands, and with -DEFFI_BF16_ONLY, which keeps only the *_bf16x3_* entry points,
+// appends _bf16 to their names and drops the two lo terms of every split product (hi*hi only: plain bf16 operands, fp32
+// accumulation -- BASELINE.json's "bf16 (MFMA 3D-conv path)" configuration).  A compile-time constant, not a runtime flag: a flag
+// tested inside the MFMA loops cost the default build 5 % per view (rolling 3-D conv +17 %).
+#ifdef EFFI_BF16_ONLY
+#define EFFI_FN(name) name##_bf16
+#else
+#define EFFI_FN(name) name
+#endif
+
 namespace {
+
+#ifdef EFFI_BF16_ONLY
+constexpr bool kHiOnly = true;
+#else
+constexpr bool kHiOnly = false;
+#endif
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -670,7 +686,7 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
                 bf16x8 hi, lo;
                 split_octet(pa, px, hi, lo);
                 *reinterpret_cast<bf16x8*>(&lds_ah[s_lds + px * 8]) = hi;
-                *reinterpret_cast<bf16x8*>(&lds_al[s_lds + px * 8]) = lo;
+                if (!kHiOnly) *reinterpret_cast<bf16x8*>(&lds_al[s_lds + px * 8]) = lo;
             }
         }
 #pragma unroll
@@ -703,18 +719,21 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
                 ah[m] = *reinterpret_cast<const bf16x8*>(&lds_ah[koff[s_] + m * (MROW + MCOL)]);
-                al[m] = *reinterpret_cast<const bf16x8*>(&lds_al[koff[s_] + m * (MROW + MCOL)]);
+                if (!kHiOnly) al[m] = *reinterpret_cast<const bf16x8*>(&lds_al[koff[s_] + m * (MROW + MCOL)]);
             }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&lds_b[(((s_ * NT + n) * 2 + 0) * 64 + lane) * 8]);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&lds_b[(((s_ * NT + n) * 2 + 1) * 64 + lane) * 8]);
+                bf16x8 bl = bh;
+                if (!kHiOnly) bl = *reinterpret_cast<const bf16x8*>(&lds_b[(((s_ * NT + n) * 2 + 1) * 64 + lane) * 8]);
 #pragma unroll
                 for (int m = 0; m < MR; ++m) {
                     // weights x pixels: D[cout][pixel] (transposed fragment, see conv_epilogue_store_t)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[m], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[m], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[m], acc[m][n], 0, 0, 0);
+                    if (!kHiOnly) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[m], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[m], acc[m][n], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -794,8 +813,10 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
 #pragma unroll
                     for (int n = 0; n <= NT; ++n) {
                         o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[n], xh[m][n], o, 0, 0, 0);
-                        o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wl[n], xh[m][n], o, 0, 0, 0);
-                        o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[n], xl[m][n], o, 0, 0, 0);
+                        if (!kHiOnly) {
+                            o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wl[n], xh[m][n], o, 0, 0, 0);
+                            o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[n], xl[m][n], o, 0, 0, 0);
+                        }
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) om[m][t][r] = o[r] + a.disp_range[co + r];
@@ -856,8 +877,10 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
 #pragma unroll
                 for (int n = 0; n <= NT; ++n) {
                     o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[n], xh[m][n], o, 0, 0, 0);
-                    o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wl[n], xh[m][n], o, 0, 0, 0);
-                    o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[n], xl[m][n], o, 0, 0, 0);
+                    if (!kHiOnly) {
+                        o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wl[n], xh[m][n], o, 0, 0, 0);
+                        o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[n], xl[m][n], o, 0, 0, 0);
+                    }
                 }
                 if (inside[m]) {
 #pragma unroll
@@ -1013,18 +1036,21 @@ __device__ __forceinline__ void conv3d_roll_bf16x3_body(const Conv2dArgs a, int 
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
                 ah[m] = *reinterpret_cast<const bf16x8*>(&lds_ah[off + m * AW * 8]);
-                al[m] = *reinterpret_cast<const bf16x8*>(&lds_al[off + m * AW * 8]);
+                if (!kHiOnly) al[m] = *reinterpret_cast<const bf16x8*>(&lds_al[off + m * AW * 8]);
             }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&lds_b[(((s_ * NT + n) * 2 + 0) * 64 + lane) * 8]);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&lds_b[(((s_ * NT + n) * 2 + 1) * 64 + lane) * 8]);
+                bf16x8 bl = bh;
+                if (!kHiOnly) bl = *reinterpret_cast<const bf16x8*>(&lds_b[(((s_ * NT + n) * 2 + 1) * 64 + lane) * 8]);
 #pragma unroll
                 for (int m = 0; m < MR; ++m) {
                     // weights x pixels: D[cout][pixel] (transposed fragment, see conv_epilogue_store_t)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[m], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[m], acc[m][n], 0, 0, 0);
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[m], acc[m][n], 0, 0, 0);
+                    if (!kHiOnly) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[m], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[m], acc[m][n], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -1190,7 +1216,7 @@ __global__ __launch_bounds__(256) void deconv3d_s2_bf16x3_kernel(const DeconvArg
                 bf16x8 hi, lo;
                 split_octet(pa, px, hi, lo);
                 *reinterpret_cast<bf16x8*>(&lds_ah[s_lds + px * 8]) = hi;
-                *reinterpret_cast<bf16x8*>(&lds_al[s_lds + px * 8]) = lo;
+                if (!kHiOnly) *reinterpret_cast<bf16x8*>(&lds_al[s_lds + px * 8]) = lo;
             }
         }
         __syncthreads();
@@ -1200,7 +1226,7 @@ __global__ __launch_bounds__(256) void deconv3d_s2_bf16x3_kernel(const DeconvArg
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
                 ah[m] = *reinterpret_cast<const bf16x8*>(&lds_ah[koff[s_] + m * AW * 8]);
-                al[m] = *reinterpret_cast<const bf16x8*>(&lds_al[koff[s_] + m * AW * 8]);
+                if (!kHiOnly) al[m] = *reinterpret_cast<const bf16x8*>(&lds_al[koff[s_] + m * AW * 8]);
             }
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
@@ -1208,12 +1234,15 @@ __global__ __launch_bounds__(256) void deconv3d_s2_bf16x3_kernel(const DeconvArg
                 if (!deconv_step_used(pfull, s_)) continue;
                 const int slot = HALF ? deconv_slot_half(p, s_) : deconv_slot(p, s_);   // compile-time after unrolling
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&lds_b[((slot * 2 + 0) * 64 + lane) * 8]);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&lds_b[((slot * 2 + 1) * 64 + lane) * 8]);
+                bf16x8 bl = bh;
+                if (!kHiOnly) bl = *reinterpret_cast<const bf16x8*>(&lds_b[((slot * 2 + 1) * 64 + lane) * 8]);
 #pragma unroll
                 for (int m = 0; m < MR; ++m) {
                     acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[m], acc[m][p], 0, 0, 0);
-                    acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[m], acc[m][p], 0, 0, 0);
-                    acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[m], acc[m][p], 0, 0, 0);
+                    if (!kHiOnly) {
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[m], acc[m][p], 0, 0, 0);
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[m], acc[m][p], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -1459,6 +1488,7 @@ static int dispatch3d_planes(const Conv2dArgs& a, hipStream_t st) {
     return al ? launch3d_planes<NT, 1, true>(a, st) : launch3d_planes<NT, 1, false>(a, st);
 }
 
+#ifndef EFFI_BF16_ONLY
 extern "C" int effi_conv3d_k3s1_mfma_f32(const float* in, int cin, const float* wpack, const float* bias, int cout, int D,
                                          int h, int w, int relu, float* out, effi_stream_t stream) {
     if (!in || !wpack || !bias || !out || cin < 1 || D < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
@@ -1488,6 +1518,7 @@ extern "C" int effi_conv3d_k3s1_mfma_f32(const float* in, int cin, const float* 
     a.win = w;
     return cout == 16 ? dispatch3d_planes<1>(a, effi_s(stream)) : dispatch3d_planes<2>(a, effi_s(stream));
 }
+#endif
 
 // Stride-2 form (models/module.py:442,445: conv2 8->16, conv4 16->32): output plane z reads input planes 2z-1, 2z, 2z+1.
 template <int NT, int MR, bool ALIGNED>
@@ -1506,6 +1537,7 @@ static int dispatch3d_planes_s2(const Conv2dArgs& a, hipStream_t st) {
     return al ? launch3d_planes_s2<NT, 1, true>(a, st) : launch3d_planes_s2<NT, 1, false>(a, st);
 }
 
+#ifndef EFFI_BF16_ONLY
 extern "C" int effi_conv3d_k3s2_mfma_f32(const float* in, int cin, const float* wpack, const float* bias, int cout, int D,
                                          int h, int w, int relu, float* out, effi_stream_t stream) {
     if (!in || !wpack || !bias || !out || cin < 1 || D < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
@@ -1536,7 +1568,9 @@ extern "C" int effi_conv3d_k3s2_mfma_f32(const float* in, int cin, const float* 
     a.ostride = (long)a.zcount * a.h * a.w;
     return cout == 16 ? dispatch3d_planes_s2<1>(a, effi_s(stream)) : dispatch3d_planes_s2<2>(a, effi_s(stream));
 }
+#endif
 
+#ifndef EFFI_BF16_ONLY
 extern "C" int effi_conv2d_f32(const float* const* srcs, const int* src_channels, int n_src, const float* wpack,
                                const float* bias, int cout, int ks, int h, int w, int epilogue, int act,
                                const float* aux0, const float* aux1, const float* disp_range, int n_range,
@@ -1614,6 +1648,7 @@ extern "C" int effi_conv2d_f32(const float* const* srcs, const int* src_channels
             return EFFI_ERR_BADARG;
     }
 }
+#endif
 
 // ---- 5x5 stride-2 convolution (feature pyramid down-sampling) ---------------------------------------------------
 template <int NT, int MR, bool ALIGNED>
@@ -1632,6 +1667,7 @@ static int dispatch_k5s2(const Conv2dArgs& a, hipStream_t st) {
     return al ? launch_k5s2<NT, 1, true>(a, st) : launch_k5s2<NT, 1, false>(a, st);
 }
 
+#ifndef EFFI_BF16_ONLY
 extern "C" int effi_conv2d_k5s2_f32(const float* in, int cin, const float* wpack, const float* bias, int cout, int hin,
                                     int win, int act, float* out, effi_stream_t stream) {
     if (!in || !wpack || !bias || !out || cin < 1 || cout < 1 || hin < 1 || win < 1) return EFFI_ERR_BADARG;
@@ -1667,6 +1703,7 @@ extern "C" int effi_conv2d_k5s2_f32(const float* in, int cin, const float* wpack
         default: return EFFI_ERR_UNSUPPORTED;
     }
 }
+#endif
 
 // ---- split-bf16 3x3 convolution entry --------------------------------------------------------------------------
 // Rows per wave (MR): 4 rows amortise the B fragments best, but the grid must still cover the 256 CUs (>= ~400 workgroups),
@@ -1769,7 +1806,7 @@ static int fill_bf16x3_plain(Conv2dArgs& a, const float* const* srcs, const int*
     return EFFI_OK;
 }
 
-extern "C" int effi_conv2d_k3_bf16x3_pair_f32(const float* const* srcs_a, const int* src_channels_a, int n_src_a,
+extern "C" int EFFI_FN(effi_conv2d_k3_bf16x3_pair_f32)(const float* const* srcs_a, const int* src_channels_a, int n_src_a,
                                               const void* wpack_a, const float* bias_a, float* out_a,
                                               const float* const* srcs_b, const int* src_channels_b, int n_src_b,
                                               const void* wpack_b, const float* bias_b, float* out_b, int cout, int h, int w,
@@ -1791,7 +1828,7 @@ extern "C" int effi_conv2d_k3_bf16x3_pair_f32(const float* const* srcs_a, const 
     }
 }
 
-extern "C" int effi_conv2d_k3_bf16x3_f32(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
+extern "C" int EFFI_FN(effi_conv2d_k3_bf16x3_f32)(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
                                          const float* bias, int cout, int h, int w, int epilogue, int act, const float* aux0,
                                          const float* aux1, const float* disp_range, int n_range, float* out0, float* out1,
                                          effi_stream_t stream) {
@@ -1851,7 +1888,7 @@ extern "C" int effi_conv2d_k3_bf16x3_f32(const float* const* srcs, const int* sr
     }
 }
 
-extern "C" int effi_conv2d_k3_k1_bf16x3_f32(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
+extern "C" int EFFI_FN(effi_conv2d_k3_k1_bf16x3_f32)(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
                                             const float* bias, int cout1, int relu1, const float* extra, int c_extra,
                                             const void* w2pack_bf16, const float* bias2, int cout2, int relu, int h, int w,
                                             float* out, effi_stream_t stream) {
@@ -1897,7 +1934,7 @@ extern "C" int effi_conv2d_k3_k1_bf16x3_f32(const float* const* srcs, const int*
     }
 }
 
-extern "C" int effi_conv2d_k3_k1_up2x_bf16x3_f32(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
+extern "C" int EFFI_FN(effi_conv2d_k3_k1_up2x_bf16x3_f32)(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
                                                  const float* bias, int cout1, const void* w2pack_bf16, const float* bias2,
                                                  const float* inv_depth, const float* disp_range, int n_range, int h, int w,
                                                  float* out_depth, float* out_depth_inv, effi_stream_t stream) {
@@ -1944,7 +1981,7 @@ extern "C" int effi_conv2d_k3_k1_up2x_bf16x3_f32(const float* const* srcs, const
     }
 }
 
-extern "C" int effi_conv3d_k3s1_bf16x3_f32(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
+extern "C" int EFFI_FN(effi_conv3d_k3s1_bf16x3_f32)(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
                                            const float* bias, int cout, int D, int h, int w, int relu, float* out,
                                            effi_stream_t stream) {
     if (!srcs || !src_channels || n_src < 1 || n_src > EFFI_MAX_SRC || !wpack_bf16 || !bias || !out) return EFFI_ERR_BADARG;
@@ -2052,7 +2089,7 @@ static int fill_roll_args(Conv2dArgs& a, const float* const* srcs, const int* sr
     return EFFI_OK;
 }
 
-extern "C" int effi_conv3d_k3s1_roll_bf16x3_f32(const float* const* srcs, const int* src_channels, int n_src,
+extern "C" int EFFI_FN(effi_conv3d_k3s1_roll_bf16x3_f32)(const float* const* srcs, const int* src_channels, int n_src,
                                                 const void* wpack_bf16, const float* bias, int cout, int D, int h, int w,
                                                 int relu, float* out, effi_stream_t stream) {
     Conv2dArgs a;
@@ -2064,7 +2101,7 @@ extern "C" int effi_conv3d_k3s1_roll_bf16x3_f32(const float* const* srcs, const 
     return nt == 1 ? launch_roll<2, 1>(a, st) : launch_roll<2, 2>(a, st);
 }
 
-extern "C" int effi_conv3d_k3s1_roll_bf16x3_pair_f32(const float* const* srcs_a, const void* wpack_a, const float* bias_a,
+extern "C" int EFFI_FN(effi_conv3d_k3s1_roll_bf16x3_pair_f32)(const float* const* srcs_a, const void* wpack_a, const float* bias_a,
                                                      float* out_a, const float* const* srcs_b, const void* wpack_b,
                                                      const float* bias_b, float* out_b, const int* src_channels, int n_src,
                                                      int cout, int D, int h, int w, int relu, effi_stream_t stream) {
@@ -2078,7 +2115,7 @@ extern "C" int effi_conv3d_k3s1_roll_bf16x3_pair_f32(const float* const* srcs_a,
     return a.cin == 8 ? launch_roll<1, 1>(a, st, &b) : launch_roll<2, 1>(a, st, &b);
 }
 
-extern "C" int effi_deconv3d_k3s2_bf16x3_f32(const float* in, int cin, const void* wpack_bf16, const float* bias, int cout, int D,
+extern "C" int EFFI_FN(effi_deconv3d_k3s2_bf16x3_f32)(const float* in, int cin, const void* wpack_bf16, const float* bias, int cout, int D,
                                              int h, int w, int relu, const float* skip, float* out, effi_stream_t stream) {
     if (!in || !wpack_bf16 || !bias || !out || D < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
     if (cin < 16 || (cin & 15) || cout < 1 || cout > 16) return EFFI_ERR_UNSUPPORTED;
@@ -2120,6 +2157,7 @@ extern "C" int effi_deconv3d_k3s2_bf16x3_f32(const float* in, int cin, const voi
     return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
 
+#ifndef EFFI_BF16_ONLY
 extern "C" int effi_conv2d_c1k7_relu_f32(const float* in, const float* weight, const float* bias, int cout, int h,
                                          int w, float* out, effi_stream_t stream) {
     if (!in || !weight || !bias || !out || h < 1 || w < 1) return EFFI_ERR_BADARG;
@@ -2134,3 +2172,4 @@ extern "C" int effi_conv2d_c1k7_relu_f32(const float* in, const float* weight, c
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
 }
+#endif

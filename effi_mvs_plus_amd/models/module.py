@@ -72,7 +72,7 @@ class Conv3d(nn.Module):
         cin_total = sum(x.shape[0] for x in srcs)
         if (skip is None and _triple(self.conv.stride) == (1, 1, 1) and 1 < self.out_channels <= 32 and len(srcs) <= 2
                 and cin_total in (8, 16) and srcs[0].shape[0] % 8 == 0 and srcs[0].shape[-1] % 4 == 0
-                and ops.get_precision() == "split"):
+                and ops.uses_split()):
             # 8 / 16 input channels: rolling window of input planes in LDS, each plane fetched once
             t = [self.conv.weight, self.conv.bias]
             if self.bn is not None:
@@ -80,7 +80,7 @@ class Conv3d(nn.Module):
             wp, bp = self._cache_roll.get(t, lambda: packing.pack_conv3d_roll_bf16x3(self.conv, self.bn))
             return ops.conv3d_k3s1_roll(srcs, wp, bp, self.out_channels, relu=self.relu)
         if (skip is None and _triple(self.conv.stride) == (1, 1, 1) and 1 < self.out_channels <= 32
-                and self.conv.in_channels >= 8 and srcs[0].shape[-1] % 4 == 0 and ops.get_precision() == "split"):
+                and self.conv.in_channels >= 8 and srcs[0].shape[-1] % 4 == 0 and ops.uses_split()):
             # stride-1 layers with >= 8 input channels: z-batched 2-D convolutions on the bf16 matrix cores in split
             # precision (single-channel inputs stay on the vector kernel: 3 of 16 K-slots used, measured slower)
             t = [self.conv.weight, self.conv.bias]
@@ -139,7 +139,7 @@ class Deconv3d(nn.Module):
         if _triple(self.conv.kernel_size) != (3, 3, 3) or pad != (1, 1, 1) or st[1:] != (2, 2) or \
                 op != (st[0] - 1, 1, 1) or st[0] not in (1, 2):
             raise NotImplementedError("Deconv3d: only k3 / p1 / stride (s,2,2) / output_padding (s-1,1,1) is instantiated")
-        if st == (2, 2, 2) and x.shape[0] % 16 == 0 and self.out_channels <= 16 and ops.get_precision() == "split":
+        if st == (2, 2, 2) and x.shape[0] % 16 == 0 and self.out_channels <= 16 and ops.uses_split():
             t = [self.conv.weight, self.conv.bias]
             if self.bn is not None:
                 t += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
@@ -385,7 +385,7 @@ class cost_up_small(nn.Module):
                     and _triple(m.conv1.conv.stride) == (1, 1, 1) and m.conv2.out_channels == 1
                     and _triple(m.conv2.conv.stride) == (1, 2, 2) and m.conv0.relu and m.conv_cost.relu and m.conv1.relu
                     and m.conv2.relu and not m.training)
-        return stock(a) and stock(b) and ops.get_precision() == "split" and x.shape[0] == 1 and prior_w % 4 == 0
+        return stock(a) and stock(b) and ops.uses_split() and x.shape[0] == 1 and prior_w % 4 == 0
 
     @staticmethod
     def run_pair(a, b, x, prior_a, prior_b):

@@ -146,7 +146,7 @@ class ProjectionInput(nn.Module):
         g = (lambda k: bufs.get(k)) if bufs is not None else (lambda k: None)
         wd2, bd2 = _pack(self._caches["d2"], self.convd2)
         wc2, bc2 = _pack(self._caches["c2"], self.convc2)
-        if (inputs is not None and ops.get_precision() == "split" and wd2.wx is not None and wc2.wx is not None
+        if (inputs is not None and ops.uses_split() and wd2.wx is not None and wc2.wx is not None
                 and disp.shape[-1] % 4 == 0 and hd <= 64):
             # the cost chain (lookup + 1x1 -> 3x3) and the depth chain (7x7 -> 3x3) are independent: each level of the two
             # chains is ONE launch whose workgroups are shared between them (no second stream, no fork / join bubbles)
@@ -168,7 +168,7 @@ class ProjectionInput(nn.Module):
             br.join(dfm)
         w, b = _pack(self._caches["d"], self.convd)
         cmix, cd = self.convd.out_channels, context.shape[0]
-        if (ops.get_precision() == "split" and w.wx is not None and cor.shape[-1] % 4 == 0 and hd % 8 == 0 and hd % 16 == 0
+        if (ops.uses_split() and w.wx is not None and cor.shape[-1] % 4 == 0 and hd % 8 == 0 and hd % 16 == 0
                 and cmix <= 48 and cd <= 16 and self.convc.in_channels == cmix + cd):
             # convd (3x3) and convc (1x1 over [convd, context], ReLU) in one kernel: the intermediate stays in registers
             w2, b2 = self._caches["c_after"].get([self.convc.weight, self.convc.bias],
@@ -210,7 +210,7 @@ class BasicUpdateBlock(nn.Module):
         """0.25 * mask(net); the factor is folded into the 1x1 conv's weights and bias (exact: power of two)."""
         w, b = _pack(self._m0, self.mask[0])
         c1, c2 = self.mask[0].out_channels, self.mask[2].out_channels
-        if (ops.get_precision() == "split" and w.wx is not None and net.shape[-1] % 4 == 0 and c1 <= 96 and c1 // 16 in (1, 2, 3, 4, 6)
+        if (ops.uses_split() and w.wx is not None and net.shape[-1] % 4 == 0 and c1 <= 96 and c1 // 16 in (1, 2, 3, 4, 6)
                 and c1 % 16 == 0 and c2 <= 96):
             # 3x3 + ReLU + 1x1 (x0.25) in one kernel: the 2*hidden-channel intermediate stays in registers
             w2, b2 = self._m2x.get([self.mask[2].weight, self.mask[2].bias],
@@ -222,7 +222,7 @@ class BasicUpdateBlock(nn.Module):
 
     def mask_upsample_fusable(self, net):
         c1, c2 = self.mask[0].out_channels, self.mask[2].out_channels
-        return (ops.get_precision() == "split" and net.shape[-1] % 4 == 0 and c1 in (32, 64, 96) and c2 == 36
+        return (ops.uses_split() and net.shape[-1] % 4 == 0 and c1 in (32, 64, 96) and c2 == 36
                 and self.mask[0].in_channels % 8 == 0)
 
     def run_mask_upsample(self, net, inv_depth, disp_range):

@@ -46,7 +46,10 @@ _PROF = None
 # Arithmetic of the 3x3 MFMA convolutions: "split" = every fp32 product as hi*hi + hi*lo + lo*hi on the bf16 MFMA with
 # fp32 accumulation (~5e-6 of the output scale), "fp32" = v_mfma_f32_16x16x4_f32 (exact products).  Everything else on the
 # path (warps, 3-D regularisation, soft-argmin, lookups, epilogues) is plain fp32 in both modes.
-PRECISIONS = ("split", "fp32")
+# "bf16" = the same kernels as "split" compiled with ONLY the hi*hi term (entry points *_bf16): plain bf16 operands, fp32 accumulation --
+# BASELINE.json's "bf16 (MFMA 3D-conv path)" configuration.  It is NOT fp32-grade: its own tolerance is a normalised mean depth
+# error <= 1e-2; never the default, never the headline.
+PRECISIONS = ("split", "fp32", "bf16")
 _PRECISION = os.environ.get("EFFI_MVS_PRECISION", "split")
 if _PRECISION not in PRECISIONS:
     raise ValueError(f"EFFI_MVS_PRECISION must be one of {PRECISIONS}, got {_PRECISION!r}")
@@ -61,6 +64,16 @@ def set_precision(mode):
 
 def get_precision():
     return _PRECISION
+
+
+def uses_split():
+    """True when the 3x3 / 3-D MFMA convolutions run on the bf16 matrix cores (split-precision products or bf16 operands)."""
+    return _PRECISION in ("split", "bf16")
+
+
+def _x3(name):
+    """The split-precision entry ``name`` of the library, or its plain-bf16-operand twin (suffix _bf16) in "bf16" precision."""
+    return getattr(_lib.lib(), name + "_bf16" if _PRECISION == "bf16" else name)
 
 
 def set_profile(p):
@@ -460,7 +473,7 @@ def conv3d_k3s1_bf16x3(srcs, wpack, bias, cout, relu=True):
     cin = sum(s.shape[0] for s in srcs)
     out = torch.empty(cout, D, h, w, device=srcs[0].device, dtype=torch.float32)
     work = lambda: {"flops": 2.0 * 27 * cin * cout * D * h * w, "bytes": 4.0 * (cin + cout) * D * h * w}
-    check(_call(f"conv3d_x3_nt{(cout + 15) // 16}", work, _lib.lib().effi_conv3d_k3s1_bf16x3_f32, _ptr_array(srcs),
+    check(_call(f"conv3d_x3_nt{(cout + 15) // 16}", work, _x3("effi_conv3d_k3s1_bf16x3_f32"), _ptr_array(srcs),
                 _int_array([s.shape[0] for s in srcs]), len(srcs), _p(wpack), _p(bias), cout, D, h, w, int(relu), _p(out),
                 _stream()), "effi_conv3d_k3s1_bf16x3_f32")
     return out
@@ -475,7 +488,7 @@ def conv3d_k3s1_roll(srcs, wpack, bias, cout, relu=True):
     cin = sum(s.shape[0] for s in srcs)
     out = torch.empty(cout, D, h, w, device=srcs[0].device, dtype=torch.float32)
     work = lambda: {"flops": 2.0 * 27 * cin * cout * D * h * w, "bytes": 4.0 * (cin + cout) * D * h * w}
-    check(_call(f"conv3d_roll_oct{cin // 8}_nt{(cout + 15) // 16}", work, _lib.lib().effi_conv3d_k3s1_roll_bf16x3_f32, _ptr_array(srcs),
+    check(_call(f"conv3d_roll_oct{cin // 8}_nt{(cout + 15) // 16}", work, _x3("effi_conv3d_k3s1_roll_bf16x3_f32"), _ptr_array(srcs),
                 _int_array([s.shape[0] for s in srcs]), len(srcs), _p(wpack), _p(bias), cout, D, h, w, int(relu), _p(out),
                 _stream()), "effi_conv3d_k3s1_roll_bf16x3_f32")
     return out
@@ -518,7 +531,7 @@ def deconv3d_k3s2_x3(x, wpack, bias, cout, relu=True, skip=None):
         assert skip.shape == out.shape, f"skip {tuple(skip.shape)} vs out {tuple(out.shape)}"
     work = lambda: {"flops": 2.0 * 27 * cin * cout * D * h * w,
                     "bytes": 4.0 * (cin * D * h * w + cout * 8 * D * h * w * (2 if skip is not None else 1))}
-    check(_call("deconv3d_x3", work, _lib.lib().effi_deconv3d_k3s2_bf16x3_f32, _p(x), cin, _p(wpack), _p(bias), cout,
+    check(_call("deconv3d_x3", work, _x3("effi_deconv3d_k3s2_bf16x3_f32"), _p(x), cin, _p(wpack), _p(bias), cout,
                 D, h, w, int(relu), _p(skip), _p(out), _stream()), "effi_deconv3d_k3s2_bf16x3_f32")
     return out
 
@@ -693,7 +706,7 @@ def conv3d_k3s1_roll_pair(srcs_a, wpack_a, bias_a, srcs_b, wpack_b, bias_b, cout
     out_a = torch.empty(cout, D, h, w, device=srcs_a[0].device, dtype=torch.float32)
     out_b = torch.empty_like(out_a)
     work = lambda: {"flops": 2 * 2.0 * 27 * cin * cout * D * h * w, "bytes": 2 * 4.0 * (cin + cout) * D * h * w}
-    check(_call(f"conv3d_roll_pair_oct{cin // 8}", work, _lib.lib().effi_conv3d_k3s1_roll_bf16x3_pair_f32, _ptr_array(srcs_a),
+    check(_call(f"conv3d_roll_pair_oct{cin // 8}", work, _x3("effi_conv3d_k3s1_roll_bf16x3_pair_f32"), _ptr_array(srcs_a),
                 _p(wpack_a), _p(bias_a), _p(out_a), _ptr_array(srcs_b), _p(wpack_b), _p(bias_b), _p(out_b),
                 _int_array([s.shape[0] for s in srcs_a]), len(srcs_a), cout, D, h, w, int(relu), _stream()),
           "effi_conv3d_k3s1_roll_bf16x3_pair_f32")
@@ -790,7 +803,7 @@ def conv2d_k3_bf16x3_pair(srcs_a, wpack_a, bias_a, srcs_b, wpack_b, bias_b, cout
         out_b = torch.empty(cout, h, w, device=dev, dtype=torch.float32)
     cin = sum(s.shape[0] for s in srcs_a) + sum(s.shape[0] for s in srcs_b)
     work = lambda: {"flops": 2.0 * h * w * cin * cout * 9, "bytes": 4.0 * h * w * (cin + 2 * cout)}
-    check(_call(f"conv2d_k3x3_pair_nt{(cout + 15) // 16}", work, _lib.lib().effi_conv2d_k3_bf16x3_pair_f32, _ptr_array(srcs_a),
+    check(_call(f"conv2d_k3x3_pair_nt{(cout + 15) // 16}", work, _x3("effi_conv2d_k3_bf16x3_pair_f32"), _ptr_array(srcs_a),
                 _int_array([s.shape[0] for s in srcs_a]), len(srcs_a), _p(wpack_a), _p(bias_a), _p(out_a), _ptr_array(srcs_b),
                 _int_array([s.shape[0] for s in srcs_b]), len(srcs_b), _p(wpack_b), _p(bias_b), _p(out_b), cout, h, w, act,
                 _stream()), "effi_conv2d_k3_bf16x3_pair_f32")
@@ -819,7 +832,7 @@ def conv2d(srcs, wpack, bias, cout, ks, epilogue=EPI_PLAIN, act=ACT_NONE, aux0=N
     n_range = 0 if disp_range is None else disp_range.numel()
     cin = sum(s.shape[0] for s in srcs)
     if hasattr(wpack, "w32"):                 # packing.Conv2dWeights: both operand orders, pick the arithmetic here
-        if (_PRECISION == "split" and wpack.wx is not None and ks == 3 and w % 4 == 0
+        if (uses_split() and wpack.wx is not None and ks == 3 and w % 4 == 0
                 and epilogue in (EPI_PLAIN, EPI_NHWC, EPI_GRU_ZR, EPI_GRU_Q)
                 and all(s.shape[0] % 8 == 0 for s in srcs[:-1])):
             return conv2d_k3_bf16x3(srcs, wpack.wx, bias, cout, epilogue=epilogue, act=act, aux0=aux0, aux1=aux1,
@@ -851,7 +864,7 @@ def conv2d_k3_bf16x3(srcs, wpack, bias, cout, epilogue=EPI_PLAIN, act=ACT_NONE, 
         out1 = torch.empty(cout // 2, h, w, device=dev, dtype=torch.float32)
     cin = sum(s.shape[0] for s in srcs)
     work = lambda: {"flops": 2.0 * h * w * cin * cout * 9, "bytes": 4.0 * h * w * (cin + cout)}
-    check(_call(f"conv2d_k3x3_nt{(cout + 15) // 16}_epi{epilogue}", work, _lib.lib().effi_conv2d_k3_bf16x3_f32, _ptr_array(srcs),
+    check(_call(f"conv2d_k3x3_nt{(cout + 15) // 16}_epi{epilogue}", work, _x3("effi_conv2d_k3_bf16x3_f32"), _ptr_array(srcs),
                 _int_array([s.shape[0] for s in srcs]), len(srcs), _p(wpack), _p(bias), cout, h, w, epilogue, act,
                 _p(aux0), _p(aux1), None, 0, _p(out0), _p(out1), _stream()), "effi_conv2d_k3_bf16x3_f32")
     return (out0, out1) if out1 is not None else out0
@@ -872,7 +885,7 @@ def conv2d_k3_k1_x3(srcs, wpack, bias, cout1, extra, w2pack, bias2, cout2, relu=
     cin = sum(s.shape[0] for s in srcs)
     work = lambda: {"flops": 2.0 * h * w * (cin * cout1 * 9 + (cout1 + c_extra) * cout2),
                     "bytes": 4.0 * h * w * (cin + c_extra + cout2)}
-    check(_call(f"conv2d_k3k1_nt{(cout1 + 15) // 16}", work, _lib.lib().effi_conv2d_k3_k1_bf16x3_f32, _ptr_array(srcs),
+    check(_call(f"conv2d_k3k1_nt{(cout1 + 15) // 16}", work, _x3("effi_conv2d_k3_k1_bf16x3_f32"), _ptr_array(srcs),
                 _int_array([s.shape[0] for s in srcs]), len(srcs), _p(wpack), _p(bias), cout1, int(relu1), _p(extra), c_extra,
                 _p(w2pack), _p(bias2), cout2, int(relu), h, w, _p(out), _stream()), "effi_conv2d_k3_k1_bf16x3_f32")
     return out
@@ -890,7 +903,7 @@ def conv2d_k3_k1_up2x(srcs, wpack, bias, cout1, w2pack, bias2, inv_depth, disp_r
     out_dinv = torch.empty(2 * h, 2 * w, device=dev, dtype=torch.float32) if want_depth_inv else None
     cin = sum(s_.shape[0] for s_ in srcs)
     work = lambda: {"flops": 2.0 * h * w * (cin * cout1 * 9 + cout1 * 36), "bytes": 4.0 * h * w * (cin + 1 + 8)}
-    check(_call(f"conv2d_k3k1up_nt{(cout1 + 15) // 16}", work, _lib.lib().effi_conv2d_k3_k1_up2x_bf16x3_f32, _ptr_array(srcs),
+    check(_call(f"conv2d_k3k1up_nt{(cout1 + 15) // 16}", work, _x3("effi_conv2d_k3_k1_up2x_bf16x3_f32"), _ptr_array(srcs),
                 _int_array([s_.shape[0] for s_ in srcs]), len(srcs), _p(wpack), _p(bias), cout1, _p(w2pack), _p(bias2), _p(inv_depth),
                 _p(disp_range), disp_range.numel(), h, w, _p(out_depth), _p(out_dinv), _stream()), "effi_conv2d_k3_k1_up2x_bf16x3_f32")
     return out_depth, out_dinv

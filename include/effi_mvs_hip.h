@@ -455,6 +455,40 @@ int effi_warpcorr_dyn_bwd_f32(const float* ref_nhwc, const float* const* src_nhw
                               const float* grad_sim, float* grad_ref_nhwc, float* const* grad_src_nhwc, float* grad_view_w,
                               effi_stream_t stream);
 
+/* ---- plain-bf16-operand variants of the split-precision convolution entries -------------------------------------------------
+ * BASELINE.json's "bf16 (MFMA 3D-conv path)" configuration: every *_bf16x3_* entry above exists a second time with the suffix
+ * _bf16 -- same arguments, same packed weights, same kernels compiled with the two lo terms of each product removed (hi*hi only:
+ * bf16 operands, fp32 accumulation).  NOT fp32-grade: the stated tolerance of this variant is a normalised mean depth error
+ * <= 1e-2; the reference itself is fp32 only (models/module.py:318). */
+int effi_conv2d_k3_bf16x3_pair_f32_bf16(const float* const* srcs_a, const int* src_channels_a, int n_src_a, const void* wpack_a,
+                                   const float* bias_a, float* out_a, const float* const* srcs_b,
+                                   const int* src_channels_b, int n_src_b, const void* wpack_b, const float* bias_b,
+                                   float* out_b, int cout, int h, int w, int act, effi_stream_t stream);
+int effi_conv2d_k3_bf16x3_f32_bf16(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
+                              const float* bias, int cout, int h, int w, int epilogue, int act,
+                              const float* aux0, const float* aux1, const float* disp_range, int n_range,
+                              float* out0, float* out1, effi_stream_t stream);
+int effi_conv2d_k3_k1_bf16x3_f32_bf16(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
+                                 const float* bias, int cout1, int relu1, const float* extra, int c_extra,
+                                 const void* w2pack_bf16, const float* bias2, int cout2, int relu, int h, int w, float* out,
+                                 effi_stream_t stream);
+int effi_conv2d_k3_k1_up2x_bf16x3_f32_bf16(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
+                                      const float* bias, int cout1, const void* w2pack_bf16, const float* bias2,
+                                      const float* inv_depth, const float* disp_range, int n_range, int h, int w,
+                                      float* out_depth, float* out_depth_inv, effi_stream_t stream);
+int effi_conv3d_k3s1_bf16x3_f32_bf16(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
+                                const float* bias, int cout, int D, int h, int w, int relu, float* out,
+                                effi_stream_t stream);
+int effi_conv3d_k3s1_roll_bf16x3_f32_bf16(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
+                                     const float* bias, int cout, int D, int h, int w, int relu, float* out,
+                                     effi_stream_t stream);
+int effi_conv3d_k3s1_roll_bf16x3_pair_f32_bf16(const float* const* srcs_a, const void* wpack_a, const float* bias_a, float* out_a,
+                                          const float* const* srcs_b, const void* wpack_b, const float* bias_b, float* out_b,
+                                          const int* src_channels, int n_src, int cout, int D, int h, int w, int relu,
+                                          effi_stream_t stream);
+int effi_deconv3d_k3s2_bf16x3_f32_bf16(const float* in, int cin, const void* wpack_bf16, const float* bias, int cout,
+                                  int D, int h, int w, int relu, const float* skip, float* out, effi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -144,6 +144,33 @@ def test_full_size_cascade_vs_oracle(name, precision):
     assert conf_err <= 1e-3
 
 
+@pytest.mark.parametrize("name", ["cfg2 800x576 S=4 48,8,8", "cfg3 1600x1184 S=4 48,8,8"])
+def test_bf16_operand_mode_within_its_own_tolerance(name):
+    """BASELINE.json's "bf16 (MFMA 3D-conv path)" configuration: the split-precision kernels with plain bf16 operands (hi*hi only,
+    fp32 accumulation; ops.set_precision("bf16")).  Not fp32-grade: its stated tolerance is a normalised mean depth error <= 1e-2 per
+    output; the default mode is held to 1e-3 by the tests above."""
+    from effi_mvs_plus_amd import ops
+    net, feats, ctx, pm, dv, want = _full_size_case(name)
+    before = ops.get_precision()
+    ops.set_precision("bf16")
+    try:
+        with torch.no_grad():
+            out = net.forward_hot([{k: t(v, DEV) for k, v in f.items()} for f in feats], {k: t(v, DEV) for k, v in ctx.items()},
+                                  {k: t(v, DEV) for k, v in pm.items()}, t(dv, DEV))
+    finally:
+        ops.set_precision(before)
+    assert ops.get_precision() == before
+    worst = 0.0
+    for i, d in enumerate(out["depth"]):
+        mean, p99, mx = _norm_err(d, want["depth"][i])
+        print(f"[bf16 operands | {name}] depth[{i:2d}] normalised err: mean={mean:.3e} p99={p99:.3e} max={mx:.3e}")
+        # SURVEY.md section 8(d): "bf16 variant: final depth normalised mean <= 1e-2"; the twelve intermediate maps are held to 2e-2
+        # (measured at 1600x1184: final 3.7e-3, worst intermediate 1.0e-2)
+        assert mean <= (1e-2 if i == 12 else 2e-2), f"{name}: depth[{i}] outside the bf16 variant's tolerance"
+        worst = max(worst, mean)
+    assert worst > 1e-6, "bf16 operands must differ from the fp32-grade result (is the mode switch wired?)"
+
+
 def test_data_parallel_wrapper_and_foreign_current_device():
     """The reference's DTU driver wraps the model in nn.DataParallel (test_dtu_dypcd.py:418): the wrapped model must give the
     unwrapped model's result.  (On a one-GPU box DataParallel has a single replica; the per-device workspace and the
