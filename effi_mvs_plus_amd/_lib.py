@@ -68,6 +68,7 @@ SIGNATURES = {
     # scope row n2: training kernels
     "effi_conv_wgrad_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "effi_channel_sum_f32": [_vp, _i, _i, _l, _vp, _vp],
+    "effi_conv2d_k5s2_dgrad_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "effi_bn_moment_f32": [_vp, _i, _i, _l, _vp, _i, _vp, _vp],
     "effi_bn_apply_f32": [_vp, _i, _i, _l, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "effi_bn_bwd_f32": [_vp, _vp, _vp, _i, _i, _l, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],

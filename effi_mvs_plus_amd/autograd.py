@@ -88,6 +88,41 @@ def conv2d(xs, weight, bias=None, act=ops.ACT_NONE):
     return _Conv2d.apply(weight, bias, act, *xs)
 
 
+class _Conv2dK5S2(torch.autograd.Function):
+    """nn.Conv2d 5x5 / stride 2 / padding 2 / no bias of the feature pyramid's down-sampling layers (models/module.py:376-388;
+    BatchNorm + ReLU follow separately)."""
+
+    @staticmethod
+    def forward(ctx, weight, x):
+        x = _c(x)
+        cout = weight.shape[0]
+        with torch.no_grad():
+            wp, bp = packing.pack_conv2d_mfma(weight, None)
+            y = _stack([ops.conv2d_k5s2(x[b], wp, bp, cout, act=ops.ACT_NONE) for b in range(x.shape[0])])
+        ctx.save_for_backward(weight, x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        weight, x = ctx.saved_tensors
+        g = _c(gy)
+        B, cin, hin, win = x.shape
+        gw = gx = None
+        if ctx.needs_input_grad[0]:
+            gw = torch.zeros_like(weight)
+            dw = gw.view(weight.shape[0], cin, 25)
+            for b in range(B):
+                ops.conv_wgrad(g[b], x[b], dw, 0, 1, 5, stride=(1, 2))
+        if ctx.needs_input_grad[1]:
+            wc = _c(weight)
+            gx = _stack([ops.conv2d_k5s2_dgrad(g[b], wc, hin, win) for b in range(B)])
+        return gw, gx
+
+
+def conv2d_k5s2(x, weight):
+    return _Conv2dK5S2.apply(weight, x)
+
+
 def _stride3(stride):
     s = tuple(stride) if isinstance(stride, (tuple, list)) else (stride,) * 3
     if s not in ((1, 1, 1), (2, 2, 2), (1, 2, 2)):

@@ -1154,8 +1154,12 @@ __global__ __launch_bounds__(256) void deconv3d_s2_bf16x3_kernel(const DeconvArg
     const int li = lane & 15, lk = lane >> 4;
     const int h = a.h, w = a.w, D = a.D;
     const long hw = (long)h * w, cstride = (long)D * hw;
-    const int z = blockIdx.y;
-    const int t = blockIdx.x;
+    // XCD-aware order over (z, tile): workgroups are dealt to the 8 XCDs round-robin, so with the plain (tile, z) grid every XCD's
+    // L2 fetched the whole input (PMC: 48.5 MB fetched per launch against 35.5 MB algorithmic, L2 hit 33 %); a contiguous run of
+    // (z, tile) per XCD makes each L2 fetch its own z-slab only.
+    const int lin = effi_xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int z = lin / (int)gridDim.x;
+    const int t = lin - z * (int)gridDim.x;
     const int ty_ = t / tiles_x;
     const int x0 = (t - ty_ * tiles_x) * 16, y0 = ty_ * TR;
 
@@ -2161,7 +2165,7 @@ extern "C" int EFFI_FN(effi_deconv3d_k3s2_bf16x3_f32)(const float* in, int cin, 
 extern "C" int effi_conv2d_c1k7_relu_f32(const float* in, const float* weight, const float* bias, int cout, int h,
                                          int w, float* out, effi_stream_t stream) {
     if (!in || !weight || !bias || !out || h < 1 || w < 1) return EFFI_ERR_BADARG;
-    dim3 grid(effi_cdiv(w, 32), effi_cdiv(h, 8), cout / 16);
+    dim3 grid(effi_cdiv(w, EFFI_C1K7_TX), effi_cdiv(h, EFFI_C1K7_TY), cout / 16);
     hipStream_t st = effi_s(stream);
     switch (cout) {
         case 16: hipLaunchKernelGGL(conv2d_c1k7_relu_kernel<16>, grid, dim3(256), 0, st, in, weight, bias, h, w, out); break;

@@ -394,6 +394,7 @@ extern "C" int effi_conv_wgrad_f32(const float* a, const float* b, int ca, int c
                        cb_total, cb_off, Da, ha, wa, Db, hb, wb, sz, sxy, dw)
     if (kd == 1 && ks == 1) EFFI_WG(1, 1, 16);
     else if (kd == 1 && ks == 3) EFFI_WG(1, 3, 8);
+    else if (kd == 1 && ks == 5) EFFI_WG(1, 5, 4);
     else if (kd == 1 && ks == 7) EFFI_WG(1, 7, 2);
     else if (kd == 3 && ks == 3) EFFI_WG(3, 3, 4);
     else return EFFI_ERR_UNSUPPORTED;
@@ -498,6 +499,54 @@ extern "C" int effi_convex_upsample2x_bwd_f32(const float* inv_depth, const floa
     if (!inv_depth || !mask || !gup || !gmask || !ginv || h < 1 || w < 1) return EFFI_ERR_BADARG;
     hipLaunchKernelGGL(convex_upsample2x_bwd_kernel, dim3(effi_cdiv((long)h * w, TPB)), dim3(TPB), 0, effi_s(stream), inv_depth, mask, h,
                        w, gup, gmask, ginv);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Input gradient of the feature pyramid's 5x5 / stride-2 / padding-2 convolutions (models/module.py:32-75,376-388):
+//   dx[ci][y][x] = sum_co sum_{ky,kx} g[co][(y + 2 - ky) / 2][(x + 2 - kx) / 2] * W[co][ci][ky][kx]   over the taps whose
+//   (y + 2 - ky), (x + 2 - kx) are even and land inside g.
+// One thread per input pixel and block of 8 input channels; taps of the wrong parity are skipped by stepping ky, kx by 2.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void conv2d_k5s2_dgrad_kernel(const float* __restrict__ g, const float* __restrict__ wgt, int cin,
+                                                                int cout, int hin, int win, int ho, int wo, float* __restrict__ dx) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= hin * win) return;
+    const int y = p / win, x = p - y * win;
+    const int c0 = blockIdx.y * 8;
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
+    for (int co = 0; co < cout; ++co) {
+        const float* __restrict__ gc = g + (long)co * ho * wo;
+        const float* __restrict__ wc = wgt + ((long)co * cin + c0) * 25;
+        for (int ky = y & 1; ky < 5; ky += 2) {
+            const int oy = (y + 2 - ky) >> 1;
+            if ((y + 2 - ky) < 0 || oy >= ho) continue;
+            for (int kx = x & 1; kx < 5; kx += 2) {
+                const int ox = (x + 2 - kx) >> 1;
+                if ((x + 2 - kx) < 0 || ox >= wo) continue;
+                const float gv = gc[(long)oy * wo + ox];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (c0 + i < cin) acc[i] = fmaf(gv, wc[i * 25 + ky * 5 + kx], acc[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (c0 + i < cin) dx[(long)(c0 + i) * hin * win + p] = acc[i];
+}
+}  // namespace
+
+extern "C" int effi_conv2d_k5s2_dgrad_f32(const float* grad_out, const float* weight, int cin, int cout, int hin, int win, float* grad_in,
+                                          effi_stream_t stream) {
+    if (!grad_out || !weight || !grad_in || cin < 1 || cout < 1 || hin < 1 || win < 1) return EFFI_ERR_BADARG;
+    const int ho = (hin - 1) / 2 + 1, wo = (win - 1) / 2 + 1;
+    hipLaunchKernelGGL(conv2d_k5s2_dgrad_kernel, dim3(effi_cdiv((long)hin * win, 256), (cin + 7) / 8), dim3(256), 0, effi_s(stream), grad_out,
+                       weight, cin, cout, hin, win, ho, wo, grad_in);
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
 }

@@ -605,7 +605,7 @@ extern "C" int effi_encoder_inputs_f32(const float* inv_depth, const float* disp
         return EFFI_ERR_BADARG;
     if (Dcur < 2 || Dreg < 2 || h < 1 || w < 1) return EFFI_ERR_BADARG;
     if (nq != 3 || (cout != 16 && cout != 32 && cout != 48)) return EFFI_ERR_UNSUPPORTED;
-    const int gx = effi_cdiv(w, 32), gy = effi_cdiv(h, 8), n7 = gx * gy * (cout / 16);
+    const int gx = effi_cdiv(w, EFFI_C1K7_TX), gy = effi_cdiv(h, EFFI_C1K7_TY), n7 = gx * gy * (cout / 16);
     const dim3 grid(n7 + effi_cdiv((long)h * w, TPB));
     hipStream_t st = effi_s(stream);
     const GetcostConvArgs g{inv_depth, disp_range, n_range, 0, interval, cur_vol, cds, cps, Dcur, reg_vol, rds, rps,

@@ -438,6 +438,11 @@ class Effi_MVS_plus(nn.Module):
         # the N + 1 pyramid passes are independent: with branches on, odd views and the context net go to the side stream (their coarse layers
         # do not fill the chip on their own)
         n_views = imgs.size(1)
+        if self.training:
+            # the reference's order (:432-435): BatchNorm running statistics are an exponential average, so the order of the N + 1
+            # pyramid passes is part of the result
+            features = [self.feature(imgs[:, v]) for v in range(n_views)]
+            return self.forward_hot(features, self.cnet_depth(imgs[:, 0]), proj_matrices, depth_values)
         features = [None] * n_views
         with ops.Branch() as br:
             for v in range(1, n_views, 2):

@@ -1028,6 +1028,17 @@ def conv_wgrad(a, b, dw, cb_off, kd, ks, stride=(1, 1)):
     return dw
 
 
+def conv2d_k5s2_dgrad(grad_out, weight, hin, win):
+    """Input gradient of a 5x5 / stride-2 / padding-2 convolution: grad_out [cout,ho,wo], weight [cout,cin,5,5] -> [cin,hin,win]."""
+    _t(grad_out, "grad_out"), _t(weight, "weight")
+    cout, cin = weight.shape[0], weight.shape[1]
+    if tuple(grad_out.shape) != (cout, (hin - 1) // 2 + 1, (win - 1) // 2 + 1):
+        raise ValueError("conv2d_k5s2_dgrad: grad_out shape does not match the input size")
+    gx = torch.empty(cin, hin, win, device=grad_out.device, dtype=torch.float32)
+    check(_lib.lib().effi_conv2d_k5s2_dgrad_f32(_p(grad_out), _p(weight), cin, cout, hin, win, _p(gx), _stream()), "effi_conv2d_k5s2_dgrad_f32")
+    return gx
+
+
 def channel_sum(g):
     """[B,C,...] -> [C] sums over batch and positions."""
     _t(g, "channel_sum input")

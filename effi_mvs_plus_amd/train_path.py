@@ -54,6 +54,41 @@ def cost_up_small(mod, x, prior):
     return deconv3d_block(mod.conv2, c1), c1
 
 
+# ---- feature / context pyramid (scope row n1 in training; models/module.py:32-75,346-412) -----------------------------------
+def fpn_block(blk, x):
+    """``Conv2d`` wrapper of the pyramid: conv (3x3 stride 1 or 5x5 stride 2, no bias) -> BatchNorm2d (batch statistics) -> ReLU."""
+    conv = blk.conv
+    if conv.bias is not None or blk.bn is None or not isinstance(blk.bn, torch.nn.BatchNorm2d):
+        raise NotImplementedError("feature pyramid (training): conv without bias + BatchNorm2d blocks, as P_1to8_FeatureNet_Fast builds them")
+    if conv.kernel_size == (5, 5) and conv.stride == (2, 2) and conv.padding == (2, 2):
+        y = A.conv2d_k5s2(x, conv.weight)
+    elif conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1):
+        y = A.conv2d([x], conv.weight, None, NONE)
+    else:
+        raise NotImplementedError("feature pyramid (training): 3x3/s1/p1 and 5x5/s2/p2 blocks")
+    return A.batch_norm_train(y, blk.bn, blk.relu)
+
+
+def feature_pyramid(fpn, x):
+    """P_1to8_FeatureNet_Fast.forward in training mode (models/module.py:392-412) on the differentiable HIP operators; the
+    nearest-neighbour upsampling + add of the top-down path is tensor glue (torch)."""
+    import torch.nn.functional as F
+    for blk in fpn.conv0:
+        x = fpn_block(blk, x)
+    levels = []
+    for seq in (fpn.conv1, fpn.conv2, fpn.conv3):
+        for blk in seq:
+            x = fpn_block(blk, x)
+        levels.append(x)
+    l1, l2, top = levels
+    out = {"stage1": A.conv2d([top], fpn.out1.weight, fpn.out1.bias, NONE)}
+    top = F.interpolate(top, scale_factor=2, mode="nearest") + A.conv2d([l2], fpn.inner1.weight, fpn.inner1.bias, NONE)
+    out["stage2"] = A.conv2d([top], fpn.out2.weight, fpn.out2.bias, NONE)
+    top = F.interpolate(top, scale_factor=2, mode="nearest") + A.conv2d([l1], fpn.inner2.weight, fpn.inner2.bias, NONE)
+    out["stage3"] = A.conv2d([top], fpn.out3.weight, fpn.out3.bias, NONE)
+    return out
+
+
 # ---- view-weight net (models/Effi_MVS_plus.py:361-362) ---------------------------------------------------------------
 def pixelwise_net(seq, entropy):
     x = entropy

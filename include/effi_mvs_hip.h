@@ -390,9 +390,13 @@ int effi_resize_linear_f32(const float* in_chw, int channels, int src_h, int src
  *   nn.Conv2d / nn.Conv3d (models/module.py:124-166, models/update.py:14-15,36-38,73-81,109-112): A = grad_out, B = input
  *     -> torch's [cout][cin][k..]; a concatenated input is handled per part (cb_off = its first channel).
  *   nn.ConvTranspose3d (models/module.py:168-209): A = input, B = grad_out -> torch's [cin][cout][k..].
- * (kd, ks) in {(1,1), (1,3), (1,7), (3,3)}; 2-D: Da = Db = 1. */
+ * (kd, ks) in {(1,1), (1,3), (1,5), (1,7), (3,3)}; 2-D: Da = Db = 1. */
 int effi_conv_wgrad_f32(const float* a, const float* b, int ca, int cb, int cb_total, int cb_off, int kd, int ks, int Da, int ha,
                         int wa, int Db, int hb, int wb, int sz, int sxy, float* dw, effi_stream_t stream);
+/* Input gradient of the feature pyramid's 5x5 / stride-2 / padding-2 convolutions (models/module.py:376-388; scope row n1 in
+ * training): grad_out planar [cout][ceil(hin/2)][ceil(win/2)], weight torch layout [cout][cin][5][5] -> grad_in planar [cin][hin][win]. */
+int effi_conv2d_k5s2_dgrad_f32(const float* grad_out, const float* weight, int cin, int cout, int hin, int win, float* grad_in,
+                               effi_stream_t stream);
 /* out[c] += sum over batch and positions of g [B][C][n]  (bias gradients). */
 int effi_channel_sum_f32(const float* g, int B, int C, long n, float* out, effi_stream_t stream);
 

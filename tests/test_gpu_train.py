@@ -97,6 +97,51 @@ def test_deconv3d_forward_backward(cin, cout, stride, D, h, w):
     assert rel(got, want) <= 2e-5 and rel(Wd.grad, Wc.grad) <= 2e-5 and rel(xd.grad, xc.grad) <= 2e-5
 
 
+@pytest.mark.parametrize("cin,cout,B,h,w", [(8, 16, 2, 32, 40), (3, 8, 1, 31, 45), (16, 32, 1, 16, 20)])
+def test_conv2d_k5s2_forward_backward(cin, cout, B, h, w):
+    """The feature pyramid's 5x5 / stride-2 / padding-2 down-sampling convolution (models/module.py:376-388), odd sizes included."""
+    from effi_mvs_plus_amd import autograd as A
+    g = torch.Generator().manual_seed(cin)
+    W = torch.randn(cout, cin, 5, 5, generator=g) / math.sqrt(cin * 25)
+    x = torch.randn(B, cin, h, w, generator=g)
+    Wc, xc = leaf(W), leaf(x)
+    want = F.conv2d(xc, Wc, None, stride=2, padding=2)
+    gy = torch.randn(want.shape, generator=g)
+    want.backward(gy)
+    Wd, xd = leaf(W, DEV), leaf(x, DEV)
+    got = A.conv2d_k5s2(xd, Wd)
+    got.backward(gy.to(DEV))
+    assert rel(got, want) <= 2e-5 and rel(Wd.grad, Wc.grad) <= 2e-5 and rel(xd.grad, xc.grad) <= 2e-5
+
+
+@pytest.mark.parametrize("name", ["feature", "cnet_depth"])
+def test_feature_pyramid_training_mode(name):
+    """Scope row n1 in training mode: P_1to8_FeatureNet_Fast.forward on the differentiable HIP operators (BatchNorm on batch
+    statistics) against the same module on the CPU -- outputs, every parameter gradient, the input gradient, running statistics.
+    (The stock PyTorch-ROCm composite, forward_torch, gets the context pyramid's conv3.2 weight gradient wrong by 7.7 % of its peak
+    through MIOpen on this 128x160 image: tools/diag_fpn.py.)"""
+    import copy
+    net, _ = build_model("8,8,8", seed=13)
+    # fp64 on the CPU is the yardstick: the CPU's own fp32 gradient of feature.conv1.0.conv.weight is 5.8e-3 of its peak away from
+    # it on this input (a ReLU flip under the BatchNorm cancellation), the HIP path 1e-5
+    cpu = copy.deepcopy(getattr(net, name)).double().train()
+    gpu = copy.deepcopy(getattr(net, name)).to(DEV).train()
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(2, 3, 128, 160, generator=g)
+    xc, xd = leaf(x.double()), leaf(x, DEV)
+    oc, og = cpu(xc), gpu(xd)
+    R = {k: torch.randn(v.shape, generator=g) for k, v in oc.items()}
+    sum((oc[k] * R[k].double()).sum() for k in oc).backward()
+    sum((og[k] * R[k].to(DEV)).sum() for k in og).backward()
+    for k in oc:
+        assert rel(og[k], oc[k]) <= 2e-5, k
+    worst = max((rel(pg.grad, pc.grad), k) for (k, pc), (_, pg) in zip(cpu.named_parameters(), gpu.named_parameters()))
+    print(f"[feature pyramid training | {name}] worst parameter gradient error relative to its peak: {worst[0]:.2e} ({worst[1]})")
+    assert worst[0] <= 2e-4 and rel(xd.grad, xc.grad) <= 2e-4
+    for (k, bc), (_, bg) in zip(cpu.named_buffers(), gpu.named_buffers()):
+        assert rel(bg.float(), bc.float()) <= 1e-5, k
+
+
 @pytest.mark.parametrize("shape,relu", [((2, 8, 6, 10, 12), True), ((3, 16, 14, 18), True), ((1, 8, 4, 6, 8), False), ((2, 1, 8, 10, 12), True)])
 def test_batch_norm_training_mode(shape, relu):
     """Batch statistics, running-statistic update (momentum 0.1, unbiased variance), fused ReLU, gradients of x / gamma / beta."""
@@ -313,19 +358,17 @@ def test_training_step_matches_autograd_through_the_oracle(B, N):
     parameters; (2) kinks -- a ReLU whose pre-activation is within rounding of zero flips between two fp32 evaluations, and ONE
     flipped element (|g| = 3.3e-4) moves the mask head's bias gradient (peak 0.03: 320 terms that largely cancel) by 1.1 %.
     So the gate is: loss equal to 2e-3 relative (measured 1e-7); the relative L2 distance over ALL gradients together <= 1e-3
-    (measured 7e-5 .. 1.2e-4); at least 70 % of the parameters within 1e-3 of their own peak (measured 92 % at B = 1, 77 % at B = 2:
+    (measured 8e-6 .. 9e-6); at least 80 % of the parameters within 1e-3 of their own peak (measured 92 % at B = 1, 88 % at B = 2:
     twice the elements, twice the flips); and no parameter further than 5e-2 -- or twice
     the reference's own fp32-vs-fp64 distance where that is larger: with ONE source view the view-weight net's gradient is the
     residue of w/(w + 1e-6) and the reference's fp32 gradient itself is 6e-2..2e-1 off -- (an indexing or scaling error in a
-    kernel shows up as O(1), MIOpen's defect below as 7.7e-2).  The offenders are printed with
+    kernel shows up as O(1)).  The offenders are printed with
     the reference's own fp32-vs-fp64 distance beside them.  The single-source-view case (N = 2; the reference trains with
-    N >= 3) is degenerate in that sense throughout -- there the 70 % clause is replaced by 40 %, the L2 and cap clauses stay.
+    N >= 3) is degenerate in that sense throughout -- there the 80 % clause is replaced by 40 %, the L2 and cap clauses stay.
 
     Dropout2d is set to p = 0 on both sides (its draws come from different generators; the operator itself is checked in
-    test_pointwise_gating_and_dropout).  The feature / context pyramids (scope row n1) train on stock PyTorch-ROCm operators
-    (P_1to8_FeatureNet_Fast.forward_torch); MIOpen is switched off for this test because its weight gradient of the context
-    pyramid's 32->32 3x3 convolution on the 16x20 map is off by 7.7 % of the peak against the CPU (tools/diag_fpn.py:
-    3.5e-6 with torch's native kernels) -- a property of the stock library, not of this path."""
+    test_pointwise_gating_and_dropout).  The feature / context pyramids (scope row n1) train on the same HIP operators
+    (train_path.feature_pyramid); no stock convolution or BatchNorm is involved anywhere in the step."""
     from effi_mvs_plus_amd.models import mvs_loss
     H, W, nd = 128, 160, (8, 8, 8)
     net, sd = build_model("8,8,8", seed=13, device=DEV)
@@ -341,14 +384,9 @@ def test_training_step_matches_autograd_through_the_oracle(B, N):
     want_out, want_loss, leaves32, sd2 = _oracle_training_pass(net, sd, imgs, pm, dv, gt, mask, nd)
     _, _, leaves64, _ = _oracle_training_pass(net, sd, imgs, pm, dv, gt, mask, nd, dtype=torch.float64)
 
-    miopen = torch.backends.cudnn.enabled
-    torch.backends.cudnn.enabled = False
-    try:
-        out = net(imgs.to(DEV), {k: v.to(DEV) for k, v in pm.items()}, dv.to(DEV))
-        loss, _ = mvs_loss(out["depth"], {k: v.to(DEV) for k, v in gt.items()}, {k: v.to(DEV) for k, v in mask.items()}, DLOSS)
-        loss.backward()
-    finally:
-        torch.backends.cudnn.enabled = miopen
+    out = net(imgs.to(DEV), {k: v.to(DEV) for k, v in pm.items()}, dv.to(DEV))
+    loss, _ = mvs_loss(out["depth"], {k: v.to(DEV) for k, v in gt.items()}, {k: v.to(DEV) for k, v in mask.items()}, DLOSS)
+    loss.backward()
     assert len(out["depth"]) == 13
     rng = synth.DEPTH_MAX_MM - synth.DEPTH_MIN_MM
     for i, (a, b) in enumerate(zip(out["depth"], want_out["depth"])):
@@ -374,9 +412,9 @@ def test_training_step_matches_autograd_through_the_oracle(B, N):
     print(f"[training gate | B={B} N={N}] {n} parameters, loss {float(loss.detach()):.4f} vs {float(want_loss.detach()):.4f}; "
           f"{n_plain} within 1e-3 of their peak outright; closest to its bound: {worst[0]} {worst[1]:.3e} (bound {worst[2]:.3e}); "
           f"relative L2 distance of all gradients {math.sqrt(num / den):.3e}")
-    assert n > 200 and n_plain >= (0.7 if N > 2 else 0.4) * n and math.sqrt(num / den) <= 1e-3
+    assert n > 200 and n_plain >= (0.8 if N > 2 else 0.4) * n and math.sqrt(num / den) <= 1e-3
     for k, v in net.state_dict().items():                     # BatchNorm running statistics moved the same way
-        if "running_" in k and not k.startswith(("feature.", "cnet_depth.")):
+        if "running_" in k:
             assert rel(v, sd2[k]) <= 1e-4, k
         if "num_batches_tracked" in k:
             assert int(v) == int(sd2[k]), k

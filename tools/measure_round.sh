@@ -23,9 +23,13 @@ for wl in cfg2 cfg3b cfg4; do
   echo "$wl done"
 done
 python bench.py --precision fp32 --no-cpu-baseline --torch-baseline-views 0 --no-whole-forward --no-other-precision > $O/${tag}_bench_cfg3_fp32.json 2>> $O/${tag}_bench.err
+python bench.py --precision bf16 --no-cpu-baseline --torch-baseline-views 0 --no-whole-forward --no-other-precision > $O/${tag}_bench_cfg3_bf16.json 2>> $O/${tag}_bench.err
+python bench.py --gpus 2 --backend gloo --workload cfg2 --steps 10 --no-cpu-baseline --torch-baseline-views 0 --no-whole-forward --no-other-precision > $O/${tag}_bench_2rank_gloo_rehearsal_cfg2.json 2>> $O/${tag}_bench.err
+python bench.py --fusion-torch-baseline --no-cpu-baseline --torch-baseline-views 0 --no-other-precision --steps 5 > $O/${tag}_bench_cfg3_fusion_torch_baseline.json 2>> $O/${tag}_bench.err
+bash tools/pmc_calibrate.sh > $O/${tag}_fetch_calibration.log 2>&1
 python - <<PY
 import json
-for wl in ("cfg3", "cfg2", "cfg3b", "cfg4", "cfg3_fp32", "cfg3_eager_serial"):
+for wl in ("cfg3", "cfg2", "cfg3b", "cfg4", "cfg3_fp32", "cfg3_bf16", "cfg3_eager_serial"):
     try:
         r = json.load(open("$O/${tag}_bench_%s.json" % wl))
         print(wl, round(r["value"], 1), r["unit"], round(r["ms_per_step"], 3), "ms", r.get("roofline", {}).get("kernel"), r.get("roofline", {}).get("frac"))

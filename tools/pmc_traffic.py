@@ -4,9 +4,17 @@
 usage: tools/pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv out.json
 
 FETCH_SIZE / WRITE_SIZE are reported in KB.  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE counts 128-B
-requests at 64 B, i.e. it reads exactly HALF of the bytes of a wide (16 B/lane) coalesced read stream; WRITE_SIZE is
-exact.  Kernels whose reads are float4 streams (conv2d staging, channel-last warp taps) are therefore corrected x2
-(`fetch_scale`); kernels with 4-B-per-lane reads (conv3d tile fill) are left uncorrected and marked uncalibrated.
+requests at 64 B, i.e. it reads exactly HALF of the bytes of a wide coalesced read stream; WRITE_SIZE is exact; other
+access shapes must be calibrated on a known byte count.  tools/microbench/fetch_calib.hip (tools/pmc_calibrate.sh,
+profiles/r02_fetch_calibration.txt) reads 1 GiB exactly once in the access shapes of this repository's kernels; true bytes /
+FETCH_SIZE came out as
+
+    16 B per lane, 1 KiB per wave-instruction ................ 2.00      4 B per lane, 256 B per wave-instruction .. 2.00
+    16 B per lane in 96-byte row segments (16-px tiles) ...... 1.00      160-byte segments ......................... 1.25
+    288-byte segments (the 4 x 64 "wide" tiles) .............. 1.50      scattered 32-byte pieces (C = 8 taps) ..... 0.50
+
+(the counter tallies 64 B per request whatever the request moved: 128-B requests read half, 32-B pieces read double).  The
+factor of each kernel family below is the one of its dominant read shape (`fetch_scale`); `calibrated` says so.
 Also prints the effective clock (GRBM_GUI_ACTIVE / 8 / time) when that counter is present.
 """
 import collections
@@ -20,18 +28,19 @@ def key_of(name):
     n = name.replace("(anonymous namespace)::", "").replace("void ", "")
     m = re.match(r"conv2d_mfma_v2_kernel<(\d+), (\d+), (\d+), (\d+)", n)
     if m:
-        return f"conv2d_k{m.group(1)}_nt{m.group(2)}_epi{m.group(4)}", 2.0
-    m = re.match(r"conv2d_k3_bf16x3_kernel<(\d+), (\d+), (\d+), (true|false)", n)
+        return f"conv2d_k{m.group(1)}_nt{m.group(2)}_epi{m.group(4)}", 1.0          # 16-px tiles: ~96-byte row segments
+    m = re.match(r"conv2d_k3_bf16x3_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)", n)
     if m:
-        return (f"conv2d_k3x3_nt{m.group(1)}_epi{m.group(3)}" if m.group(4) == "false" else f"conv3d_x3_nt{m.group(1)}"), 2.0
-    m = re.match(r"conv2d_k3_bf16x3_pair_kernel<(\d+)", n)
+        wide_scale = {1: 1.0, 2: 1.25, 4: 1.5}.get(int(m.group(2)), 1.0) if m.group(5) == "true" else 1.0   # (16 MR + 8) px segments
+        return (f"conv2d_k3x3_nt{m.group(1)}_epi{m.group(3)}" if m.group(4) == "false" else f"conv3d_x3_nt{m.group(1)}"), wide_scale
+    m = re.match(r"conv2d_k3_bf16x3_pair_kernel<(\d+), (\d+), (true|false)", n)
     if m:
-        return f"conv2d_k3x3_pair_nt{m.group(1)}", 2.0
+        return f"conv2d_k3x3_pair_nt{m.group(1)}", ({1: 1.0, 2: 1.25, 4: 1.5}.get(int(m.group(2)), 1.0) if m.group(3) == "true" else 1.0)
     if n.startswith("encoder_inputs_kernel"):
-        return "encoder_inputs", 1.0
+        return "encoder_inputs", 2.0                                                   # 4 B per lane, 256-byte runs of the cost volumes
     m = re.match(r"conv3d_roll_bf16x3_pair_kernel<(\d+)", n)
     if m:
-        return f"conv3d_roll_pair_oct{m.group(1)}", 2.0
+        return f"conv3d_roll_pair_oct{m.group(1)}", 1.0                                # 96-byte segments
     m = re.match(r"conv3d_k3_pair_kernel<(\d+), (\d+), (\d+)", n)
     if m:
         return f"conv3d_pair_c{m.group(1)}_s{m.group(2)}{m.group(3)}", 1.0
@@ -39,13 +48,13 @@ def key_of(name):
         return "deconv3d_pair_c1_s1", 1.0
     m = re.match(r"conv3d_roll_bf16x3_kernel<(\d+), (\d+)", n)
     if m:
-        return f"conv3d_roll_oct{m.group(1)}_nt{m.group(2)}", 2.0
+        return f"conv3d_roll_oct{m.group(1)}_nt{m.group(2)}", 1.0
     m = re.match(r"deconv3d_s2_bf16x3_kernel", n)
     if m:
-        return "deconv3d_x3", 2.0
+        return "deconv3d_x3", 1.0                                                      # 96-byte segments: counted exactly
     m = re.match(r"getcost_conv1x1_kernel", n)
     if m:
-        return "getcost_conv1x1", 1.0
+        return "getcost_conv1x1", 2.0
     m = re.match(r"conv2d_mfma_kernel<(\d+), (\d+), (\d+)", n)
     if m:
         return f"conv2d_k{m.group(1)}_nt{m.group(2)}_epi{m.group(3)}", 1.0
@@ -58,10 +67,17 @@ def key_of(name):
     m = re.match(r"deconv3d_k3_kernel<(\d+), (\d+)", n)
     if m:
         return f"deconv3d_c{1 if m.group(1) == '1' else 8}_s{m.group(2)}", 1.0
+    if n.startswith("warpcorr_views_win_kernel"):
+        return "warpcorr_views_c32", 2.0                                               # window rows: long contiguous runs
     m = re.match(r"warpcorr_(views|dyn)_kernel<(\d+)", n)
     if m:
-        return f"warpcorr_{m.group(1)}_c{m.group(2)}", 2.0
+        return f"warpcorr_{m.group(1)}_c{m.group(2)}", {32: 2.0, 16: 1.0, 8: 0.5}[int(m.group(2))]     # taps of 128 / 64 / 32 bytes
     return None, 1.0
+
+
+# families whose dominant read shape is one of the calibrated ones (see the module docstring)
+CALIBRATED = {"encoder_inputs", "deconv3d_x3", "getcost_conv1x1", "warpcorr_views_c32", "warpcorr_dyn_c8", "warpcorr_dyn_c16"}
+CALIBRATED_PREFIXES = ("conv2d_k3x3", "conv3d_x3", "conv3d_roll", "conv2d_k3k1")
 
 
 def collect(path):
@@ -94,7 +110,7 @@ def main(fetch_csv, write_csv, out_json):
         hit = pw[k].get("TCC_HIT_sum", 0.0)
         miss = pw[k].get("TCC_MISS_sum", 0.0)
         out[k] = {"launches_profiled": n, "avg_launch_us_profiled": us, "fetch_bytes_raw": raw, "fetch_scale": scale,
-                  "fetch_bytes": raw * scale, "write_bytes": wr, "calibrated": scale == 2.0,
+                  "fetch_bytes": raw * scale, "write_bytes": wr, "calibrated": k in CALIBRATED or k.startswith(CALIBRATED_PREFIXES),
                   "l2_hit_rate": hit / (hit + miss) if hit + miss else None}
         print(f"{k:24s} n={n:3d} {us:8.1f} us  fetch {raw * scale / 1e6:8.1f} MB (raw {raw / 1e6:7.1f}) write {wr / 1e6:7.1f} MB"
               f"  L2 hit {100 * (hit / (hit + miss) if hit + miss else 0):5.1f}%  clk~{clk:4.2f} GHz")
