@@ -507,6 +507,154 @@ __global__ __launch_bounds__(WIN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Backward of the stage-1 warp + correlation with the scatter PRIVATISED in LDS (scope row n2): same tiles, chunks and windows as
+// warpcorr_views_win_kernel.  grad_src[tap][c] += g * w_tap * ref[c] is accumulated with LDS atomics (ds_add_f32) into a window of
+// the source-gradient map and flushed to global memory ONCE per (tile, chunk) -- 576 x 32 global atomics instead of
+// 128 pixels x 20 hypotheses x 4 taps x 32 channels, an 18-fold reduction of what bound the direct kernel (0.73 G global atomic adds
+// = 8.6 ms at 148x200, D = 48, S = 4, on par with PyTorch-ROCm's grid_sample backward).  grad_ref[p][c] = sum g * warp(src)[c] reads
+// its taps from global memory (L1 path) and is added atomically per view (grid.y = view; zero on entry).  A chunk whose window
+// does not fit falls back to global atomics for the scatter.
+// ------------------------------------------------------------------------------------------------
+struct WinTapsB {
+    float w[4];
+    int a[4];     // index of the tap pixel in the LDS window (or -1: fallback to global atomics)
+    int g[4];     // pixel index y*W + x in the source map
+};
+
+template <int J>
+__device__ __forceinline__ void wintapsb_bcast(const WinTapsB& mine, WinTapsB& out) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        out.w[k] = __int_as_float(quad_bcast_i<4, J>(__float_as_int(mine.w[k])));
+        out.a[k] = quad_bcast_i<4, J>(mine.a[k]);
+        out.g[k] = quad_bcast_i<4, J>(mine.g[k]);
+    }
+}
+
+template <int MAXPX>
+__global__ __launch_bounds__(WIN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void warpcorr_views_bwd_win_kernel(
+    const float* __restrict__ ref, EffiPtrList srcs, const float* __restrict__ rt_all, const float* __restrict__ depth, long dds, int h,
+    int w, int D, const float* __restrict__ grad_sim, float* __restrict__ grad_ref, EffiOutList grad_srcs, int lds_px) {
+    constexpr int C = 32, MAXD = 256;
+    // the gradient window, CHANNEL-PLANAR [32][npad] with npad = 2 (mod 8): the 64 lanes of a ds_add_f32 (16 neighbouring pixels x the
+    // 4 lanes of a pixel, channels 8 apart) hit 64 different banks.  Measured: the layout does not matter (pixel-major [pixel][32],
+    // where 8 of the 16 pixels share banks, runs in the same 4.0 ms) -- the kernel is bound by the LDS atomic unit itself, about
+    // 180 clocks per ds_add_f32 wave instruction; without the adds the whole kernel takes 0.25 ms, without the flush or without the
+    // global tap reads it is unchanged (tools/prof_warp_bwd.py)
+    __shared__ float4 win4[(MAXPX > 0 ? MAXPX : 1) * 8 + 64];
+    __shared__ float hyp[MAXD + 4];
+    __shared__ int wpar[2][8];
+    float* winf = reinterpret_cast<float*>(win4);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tiles_x = (w + WIN_TW - 1) / WIN_TW;
+    const int tl = effi_xcd_remap(blockIdx.x, gridDim.x);
+    const int tyi = tl / tiles_x, txi = tl - tyi * tiles_x;
+    const int gidx = tid >> 2, sub = tid & 3;
+    const int x = txi * WIN_TW + (gidx & (WIN_TW - 1)), y = tyi * WIN_TH + (gidx >> 4);
+    const bool valid = (x < w) & (y < h);
+    const int xs = min(x, w - 1), ys = min(y, h - 1);
+    const int view = blockIdx.y;
+    const float* __restrict__ src = pick_view(srcs, view);
+    float* gs = grad_srcs.p[0];
+#pragma unroll
+    for (int i = 1; i <= EFFI_MAX_VIEWS; ++i)
+        if (view == i) gs = grad_srcs.p[i];
+    const float* __restrict__ rt = rt_all + view * 12;
+    const int hw = h * w, pix = ys * w + xs;
+    for (int d = tid; d < ((D + 3) & ~3); d += WIN_THREADS) hyp[d] = depth[(long)min(d, D - 1) * dds];
+    const float4 rlo = *reinterpret_cast<const float4*>(ref + (long)pix * C + sub * 8);
+    const float4 rhi = *reinterpret_cast<const float4*>(ref + (long)pix * C + sub * 8 + 4);
+    const float rr[8] = {rlo.x, rlo.y, rlo.z, rlo.w, rhi.x, rhi.y, rhi.z, rhi.w};
+    WinProj P;
+    {
+        const float fx = (float)xs, fy = (float)ys;
+        P.rx = rt[0] * fx + rt[1] * fy + rt[2];
+        P.ry = rt[3] * fx + rt[4] * fy + rt[5];
+        P.rz = rt[6] * fx + rt[7] * fy + rt[8];
+        P.tx = rt[9]; P.ty = rt[10]; P.tz = rt[11];
+        P.wm1 = (float)(w - 1); P.hm1 = (float)(h - 1);
+        P.hw2 = P.wm1 / 2.0f; P.hh2 = P.hm1 / 2.0f;
+        P.rhw2 = 1.0f / P.hw2; P.rhh2 = 1.0f / P.hh2;
+    }
+    const float* gsim = grad_sim + (long)view * D * hw + pix;
+    float gr[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) gr[c] = 0.0f;
+    __syncthreads();
+    if (wv == 0) win_choose_chunk(rt, hyp, P, txi, tyi, 0, D, w, h, lds_px, lane, wpar[0]);
+    __syncthreads();
+    int da = 0, pb = 0;
+    while (da < D) {
+        const int x_lo = wpar[pb][0], y_lo = wpar[pb][1], ww = wpar[pb][2], wh = wpar[pb][3], db = wpar[pb][4], use_lds = wpar[pb][5];
+        const int npx = ww * wh;
+        const int npad = ((npx + 5) & ~7) + 2;             // >= npx, = 2 (mod 8); 32 * npad <= 32 * MAXPX + 256 floats
+        if (use_lds) {
+            for (int i = tid; i < 8 * npad; i += WIN_THREADS) win4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            __syncthreads();
+        }
+        if (wv == 0 && db < D) win_choose_chunk(rt, hyp, P, txi, tyi, db, D, w, h, lds_px, lane, wpar[pb ^ 1]);
+        for (int d0 = da; d0 < db; d0 += 4) {
+            const float dep = hyp[d0 + sub];
+            float ix, iy;
+            project_xy(P.rx * dep + P.tx, P.ry * dep + P.ty, P.rz * dep + P.tz, P.hw2, P.rhw2, P.hh2, P.rhh2, P.wm1, P.hm1, ix, iy);
+            WinTaps tw, tg;
+            make_taps_win<true>(ix, iy, w, h, x_lo, y_lo, ww, wh, tw);
+            make_taps_win<false>(ix, iy, w, h, 0, 0, w, h, tg);
+            WinTapsB mine, t;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { mine.w[k] = tw.w[k]; mine.a[k] = use_lds ? (tw.a[k] >> 7) : -1; mine.g[k] = tg.a[k]; }   // window pixel index
+            const float my_g = (valid && d0 + sub < D) ? gsim[(long)(d0 + sub) * hw] * (1.0f / 32.0f) : 0.0f;     // x 1/C
+#define EFFI_ONE(J)                                                                                                     \
+            {                                                                                                           \
+                wintapsb_bcast<J>(mine, t);                                                                             \
+                const float g = __int_as_float(quad_bcast_i<4, J>(__float_as_int(my_g)));                               \
+                _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                         \
+                    const float gw = g * t.w[k];                                                                        \
+                    if (gw == 0.0f) continue;              /* out-of-bounds taps, masked pixels: nothing to add */      \
+                    const float4* q = reinterpret_cast<const float4*>(src + (long)t.g[k] * 32 + sub * 8);               \
+                    const float4 s0 = q[0], s1 = q[1];                                                                  \
+                    gr[0] = fmaf(gw, s0.x, gr[0]); gr[1] = fmaf(gw, s0.y, gr[1]); gr[2] = fmaf(gw, s0.z, gr[2]); gr[3] = fmaf(gw, s0.w, gr[3]); \
+                    gr[4] = fmaf(gw, s1.x, gr[4]); gr[5] = fmaf(gw, s1.y, gr[5]); gr[6] = fmaf(gw, s1.z, gr[6]); gr[7] = fmaf(gw, s1.w, gr[7]); \
+                    if (t.a[k] >= 0) {                                                                                  \
+                        float* wp_ = winf + (sub * 8) * npad + t.a[k];                                                   \
+                        _Pragma("unroll") for (int c = 0; c < 8; ++c)                                                    \
+                            __hip_atomic_fetch_add(wp_ + c * npad, gw * rr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);     \
+                    } else {                                                                                             \
+                        float* o = gs + (long)t.g[k] * 32 + sub * 8;                                                     \
+                        _Pragma("unroll") for (int c = 0; c < 8; ++c) unsafeAtomicAdd(o + c, gw * rr[c]);                \
+                    }                                                                                                    \
+                }                                                                                                       \
+            }
+            EFFI_ONE(0) EFFI_ONE(1) EFFI_ONE(2) EFFI_ONE(3)
+#undef EFFI_ONE
+        }
+        __syncthreads();                   // every add of this chunk has landed in the window
+        if (use_lds) {
+            // flush: item i = (window pixel Pw, channel quad q); a wave covers 16 pixels x 4 quads -> 16-byte runs in the nhwc map
+            for (int i = tid; i < npx * 8; i += WIN_THREADS) {
+                const int Pw = i >> 3, q = i & 7;
+                const float* wp_ = winf + (q * 4) * npad + Pw;
+                const float v0 = wp_[0], v1 = wp_[npad], v2 = wp_[2 * npad], v3 = wp_[3 * npad];
+                if (v0 == 0.0f && v1 == 0.0f && v2 == 0.0f && v3 == 0.0f) continue;
+                const int wy = Pw / ww, wx = Pw - wy * ww;
+                float* o = gs + ((long)(y_lo + wy) * w + x_lo + wx) * 32 + q * 4;
+                unsafeAtomicAdd(o + 0, v0);
+                unsafeAtomicAdd(o + 1, v1);
+                unsafeAtomicAdd(o + 2, v2);
+                unsafeAtomicAdd(o + 3, v3);
+            }
+            __syncthreads();               // before the next chunk clears the window
+        }
+        da = db;
+        pb ^= 1;
+    }
+    if (!valid) return;
+    float* o = grad_ref + (long)pix * C + sub * 8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) unsafeAtomicAdd(o + c, gr[c]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // stages 2/3: hypotheses around the current depth, all views, view-weighted aggregate
 // ------------------------------------------------------------------------------------------------
 template <int C>
@@ -878,6 +1026,15 @@ extern "C" int effi_warpcorr_views_bwd_f32(const float* ref_nhwc, const float* c
     for (int i = 0; i < S; ++i)
         if (!g.p[i]) return EFFI_ERR_BADARG;
     hipStream_t s = effi_s(stream);
+    const int lds_px = warp_lds_px();
+    if (C == 32 && dps == 0 && lds_px >= 0 && D <= 256) {
+        // hypotheses shared by all pixels: scatter privatised in an LDS window; grad_ref is ACCUMULATED per view (zero on entry)
+        const int tiles = ((w + WIN_TW - 1) / WIN_TW) * ((h + WIN_TH - 1) / WIN_TH);
+        hipLaunchKernelGGL(warpcorr_views_bwd_win_kernel<WIN_MAXPX>, dim3(tiles, S), dim3(WIN_THREADS), 0, s, ref_nhwc, l, rt, depth, dds, h,
+                           w, D, grad_sim, grad_ref_nhwc, g, lds_px);
+        EFFI_LAUNCH_CHECK();
+        return EFFI_OK;
+    }
     switch (C) {
         case 32: hipLaunchKernelGGL(warpcorr_views_bwd_kernel<32>, dim3(grid_blocks<32>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, depth, dds, dps, h, w, D, grad_sim, grad_ref_nhwc, g); break;
         case 16: hipLaunchKernelGGL(warpcorr_views_bwd_kernel<16>, dim3(grid_blocks<16>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, depth, dds, dps, h, w, D, grad_sim, grad_ref_nhwc, g); break;

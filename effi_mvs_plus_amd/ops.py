@@ -384,7 +384,7 @@ def warpcorr_views_bwd(ref_nhwc, srcs_nhwc, rt, depth, D, grad_sim):
     if tuple(grad_sim.shape) != (S, D, h, w):
         raise ValueError(f"grad_sim {tuple(grad_sim.shape)} does not match (S, D, h, w) = {(S, D, h, w)}")
     depth, dds, dps = _depth_strides(depth, D, h, w)
-    g_ref = torch.empty_like(ref_nhwc)
+    g_ref = torch.zeros_like(ref_nhwc)          # accumulated per source view by the windowed kernel
     g_src = [torch.zeros_like(s_) for s_ in srcs_nhwc]
     check(_lib.lib().effi_warpcorr_views_bwd_f32(_p(ref_nhwc), _ptr_array(srcs_nhwc), S, _p(rt), _p(depth), dds, dps, Cc, h, w, D,
                                                   _p(grad_sim), _p(g_ref), _ptr_array(g_src), _stream()), "effi_warpcorr_views_bwd_f32")

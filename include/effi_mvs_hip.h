@@ -333,8 +333,9 @@ int effi_fusion_dynamic_filter_f32(const float* ref_depth, const float* src_dept
 /* ---- scope row n2, first piece: backward of effi_warpcorr_views_f32's similarity output ------------------------------------
  * sim[v][d][p] = mean_c ref[p][c] * bilinear(src_v)[c] at the warped position (models/module.py:303-344,
  * models/Effi_MVS_plus.py:38-40); the sampling grid carries no gradient (module.py:313).  Inputs as the forward entry;
- * grad_sim [S][D][h*w]; grad_ref_nhwc [h][w][C] is written; grad_src_nhwc[v] [h][w][C] must be ZERO on entry and receives the
- * scatter-add of the bilinear weights (fp32 atomics: summation order, hence the last bits, vary between runs). */
+ * grad_sim [S][D][h*w]; grad_ref_nhwc [h][w][C] and grad_src_nhwc[v] [h][w][C] must be ZERO on entry (fp32 atomic adds: summation order,
+ * hence the last bits, vary between runs).  C = 32 with shared hypotheses: the scatter into grad_src is privatised in an LDS window per
+ * (tile, chunk of hypotheses) and flushed once (warpcorr_views_bwd_win_kernel). */
 int effi_warpcorr_views_bwd_f32(const float* ref_nhwc, const float* const* src_nhwc, int S, const float* rt,
                                 const float* depth, long depth_dstride, long depth_pstride, int C, int h, int w, int D,
                                 const float* grad_sim, float* grad_ref_nhwc, float* const* grad_src_nhwc,

@@ -197,6 +197,32 @@ def test_warpcorr_views_window_kernel(O, kind, h, w, D, N):
     check_close(f"window vs direct-gather kernel sim [{kind}]", sim, sim_o, rtol=1e-5, atol=2e-5, frac_ok=0.999 if kind != "inside" else 0.97)
 
 
+@pytest.mark.parametrize("kind", ["rig", "rolled", "wide", "inside"])
+@pytest.mark.parametrize("h,w,D,N", [(37, 50, 48, 4), (9, 13, 6, 2), (20, 24, 1, 3)])
+def test_warp_correlate_backward_window_kernel(kind, h, w, D, N):
+    """The stage-1 backward whose scatter is privatised in an LDS window (C = 32, shared hypotheses) against the direct kernel with
+    global atomics (EFFI_WARP_LDS_KB=-1), against itself with every chunk forced onto global atomics (=0) and with windows so
+    small that chunks shrink (8 KB): the same gradients to summation-order rounding."""
+    from effi_mvs_plus_amd import ops
+    C = 32
+    feats = synth.smooth_features(N, C, h, w, seed=500 + h)
+    pm = synth.synth_cameras(h * 8, w * 8, N)["stage1"] if kind == "rig" else _edge_cameras(h, w, N, kind)
+    samples = (1.0 / torch.linspace(1 / 935.0, 1 / 425.0, D)) if D > 1 else torch.tensor([600.0])
+    g = torch.Generator().manual_seed(h)
+    G = torch.randn(N - 1, D, h, w, generator=g).to(DEV)
+    nhwc = ops.to_nhwc([t(f[0], DEV) for f in feats])
+    rt = ops.compose_rel_proj(t(pm[0], DEV))
+    run = lambda: ops.warpcorr_views_bwd(nhwc[0], nhwc[1:], rt, t(samples, DEV), D, G)       # noqa: E731
+    g_ref, g_src = _with_env("EFFI_WARP_LDS_KB", None, run)
+    for mode in ("-1", "0", "8"):
+        o_ref, o_src = _with_env("EFFI_WARP_LDS_KB", mode, run)
+        tol_ = dict(rtol=1e-4, atol=2e-5 * float(o_ref.abs().max()) + 1e-7)
+        check_close(f"bwd window vs mode {mode}: grad_ref [{kind}]", g_ref, o_ref, **tol_)
+        for v in range(N - 1):
+            check_close(f"bwd window vs mode {mode}: grad_src{v} [{kind}]", g_src[v], o_src[v], rtol=1e-4,
+                        atol=2e-5 * float(o_src[v].abs().max()) + 1e-7)
+
+
 @pytest.mark.parametrize("C,h,w,D,N", [(32, 16, 20, 8, 4), (16, 18, 30, 5, 3), (8, 21, 27, 6, 3)])
 def test_warp_correlate_backward_matches_torch_autograd(O, C, h, w, D, N):
     """Scope row n2, first piece: gradients of the stage-1 warp + correlation w.r.t. reference and source features from the HIP
