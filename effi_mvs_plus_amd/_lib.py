@@ -65,6 +65,7 @@ SIGNATURES = {
     "effi_depth_to_inv_f32": [_vp, _vp, _i, _i, _vp, _vp],
     "effi_stage1_hypotheses_f32": [_vp, _i, _i, _vp, _vp, _vp],
     "effi_upsample_nearest_f32": [_vp, _i, _i, _i, _i, _vp, _vp],
+    "effi_head_update_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     # scope row n2: training kernels
     "effi_conv_wgrad_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "effi_channel_sum_f32": [_vp, _i, _i, _l, _vp, _vp],

@@ -791,10 +791,11 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
         }
         if constexpr (EPI == EFFI_EPI_K1UP) {
             // Mask head + convex upsampling (models/update.py:109-112,136-138 + upsample_depth, models/Effi_MVS_plus.py:167-178 +
-            // scale_inv_depth): the 36 mask values of a pixel never reach HBM.  Channel c = 16 t + 4 lk + r of the 1x1 result is mask
-            // entry (tap k = c / 4 = 4 t + lk, sub-pixel r = c % 4): a lane holds the taps k = lk, 4 + lk, 8 + lk of ITS pixel for all
-            // four sub-pixels, the softmax over the 9 taps and the weighted sum of the 3x3 inverse-depth neighbourhood are reductions
-            // over the four lanes li + 16 lk (two xor-shuffles each).  aux0 = inverse depth [h][w], out0 / out1 = depth /
+            // scale_inv_depth): the 36 mask values of a pixel never reach HBM.  The host orders the rows of the 1x1 convolution so that
+            // row 16 t + 4 lk + r is mask entry (tap k = 4 t + r, sub-pixel lk) (packing.pack_mask_taps_per_lane; rows with k > 8 are
+            // zero): a lane holds all nine taps of ONE sub-pixel of its pixel, so the softmax over the taps and the weighted sum of the
+            // 3x3 inverse-depth neighbourhood need no cross-lane traffic, and every lane stores one output value (the 16 pixels x 2
+            // columns of a sub-pixel row are 32 consecutive floats).  aux0 = inverse depth [h][w], out0 / out1 = depth /
             // depth_to_disp(depth) [2h][2w], xptr0 / zin = the hypotheses' range.
             f32x4 om[MR][3];
 #pragma unroll
@@ -826,36 +827,33 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
             const int W2 = 2 * w;
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
+                if (!inside[m]) continue;
                 const int x = x0 + li + (WIDE ? 16 * m : 0);
                 const int y = y0 + (WIDE ? wv : wv * MR + m);
-                float nbv[3];
+                float v[9], nbv[9];
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const int k = 4 * t + lk;
+                for (int k = 0; k < 9; ++k) {
+                    v[k] = om[m][k >> 2][k & 3];
                     const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
-                    const bool ok = (k < 9) & inside[m] & (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w);
-                    nbv[t] = ok ? a.aux0[ok ? (long)yy * w + xx : 0] : 0.0f;         // F.unfold zero padding
+                    const bool ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w);
+                    nbv[k] = ok ? a.aux0[ok ? (long)yy * w + xx : 0] : 0.0f;         // F.unfold zero padding
                 }
+                float mx = v[0];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v0 = om[m][0][r], v1 = om[m][1][r], v2 = (lk == 0) ? om[m][2][r] : -INFINITY;
-                    float mx = fmaxf(v0, fmaxf(v1, v2));
-                    mx = fmaxf(mx, __shfl_xor(mx, 16));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32));
-                    const float e0 = expf(v0 - mx), e1 = expf(v1 - mx), e2 = (lk == 0) ? expf(v2 - mx) : 0.0f;
-                    float sm = (e0 + e1) + e2;
-                    sm = sm + __shfl_xor(sm, 16);
-                    sm = sm + __shfl_xor(sm, 32);
-                    float ac = ((e0 / sm) * nbv[0] + (e1 / sm) * nbv[1]) + (e2 / sm) * nbv[2];
-                    ac = ac + __shfl_xor(ac, 16);
-                    ac = ac + __shfl_xor(ac, 32);
-                    if (lk == 0 && inside[m]) {
-                        const long o = (long)(2 * y + (r >> 1)) * W2 + 2 * x + (r & 1);
-                        const float dep = effi_inv_to_depth(ac, lo, hi);
-                        a.out0[o] = dep;
-                        if (a.out1) a.out1[o] = effi_depth_to_inv(dep, lo, hi);
-                    }
+                for (int k = 1; k < 9; ++k) mx = fmaxf(mx, v[k]);
+                float e[9], sm = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    e[k] = expf(v[k] - mx);
+                    sm = sm + e[k];
                 }
+                float ac = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) ac = ac + (e[k] / sm) * nbv[k];
+                const long o = (long)(2 * y + (lk >> 1)) * W2 + 2 * x + (lk & 1);
+                const float dep = effi_inv_to_depth(ac, lo, hi);
+                a.out0[o] = dep;
+                if (a.out1) a.out1[o] = effi_depth_to_inv(dep, lo, hi);
             }
             return;
         }

@@ -60,6 +60,7 @@ struct SplitStages {
     float* inp[4];
     long nh[4], n[4];          // elements of the hidden part / of the whole map
     int first[5];              // first block of each map
+    int vec4;                  // all maps movable as float4
 };
 __global__ __launch_bounds__(TPB) void split_tanh_relu_stages_kernel(SplitStages a) {
     int k = 0;
@@ -74,6 +75,13 @@ __global__ __launch_bounds__(TPB) void split_tanh_relu_stages_kernel(SplitStages
     for (int j = 1; j < 4; ++j)
         if (k == j) { ctx = a.ctx[j]; hidden = a.hidden[j]; inp = a.inp[j]; nh = a.nh[j]; n = a.n[j]; b0 = a.first[j]; }
     const long i = 4 * ((long)(blockIdx.x - b0) * TPB + threadIdx.x);          // 4 consecutive values per thread
+    if (a.vec4) {               // every map: element counts multiples of 4, pointers 16-byte aligned -> one quad never straddles
+        if (i >= n) return;     // the hidden / input boundary and moves as one 16-byte access
+        const float4 v = *reinterpret_cast<const float4*>(ctx + i);
+        if (i < nh) *reinterpret_cast<float4*>(hidden + i) = make_float4(tanhf(v.x), tanhf(v.y), tanhf(v.z), tanhf(v.w));
+        else *reinterpret_cast<float4*>(inp + (i - nh)) = make_float4(fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f), fmaxf(v.z, 0.0f), fmaxf(v.w, 0.0f));
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         if (i + e >= n) break;
@@ -126,6 +134,55 @@ __global__ void upsample_nearest_kernel(const float* __restrict__ in, int C, int
         const int c = (int)(t / H);
         out[i] = in[((long)c * h + y / f) * w + x / f];
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tail of the depth head (models/update.py:15,21 + the update of BasicUpdateBlock.forward, :125-127): conv2 is a 3x3
+// convolution with ONE output channel, so  conv2(hid)[p] = sum_tap s_tap[p + tap]  with  s_tap[q] = sum_c w2[c][tap] hid[q][c]
+// -- nine 1x1 projections of the hidden map, which the producer of ``hid`` (conv1 + ReLU) applies in its epilogue
+// (effi_conv2d_k3_k1_bf16x3_f32 with cout2 = 9): the hidden map itself (16-48 channels) never reaches HBM, this kernel reads the
+// nine partial-sum planes.  Zero padding of conv2 = partial sums of pixels outside the map count as zero.
+//   inv_new = inv + tanh(sum + b2);  depth = inv_to_depth(inv_new)          4 pixels along x per thread (w % 4 == 0)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void head_update_kernel(const float* __restrict__ s9, const float* __restrict__ bias2,
+                                                          const float* __restrict__ inv, const float* __restrict__ disp_range,
+                                                          int n_range, int h, int w, float* __restrict__ out_inv,
+                                                          float* __restrict__ out_depth) {
+    const int wq = w >> 2;
+    const long q = (long)blockIdx.x * TPB + threadIdx.x;
+    if (q >= (long)h * wq) return;
+    const int y = (int)(q / wq), x = (int)(q - (long)y * wq) * 4;
+    const long hw = (long)h * w;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yy = y + ky - 1;
+        if (yy < 0 || yy >= h) continue;
+        const float* row = s9 + (long)yy * w + x;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const float* pl = row + (long)(ky * 3 + kx) * hw;
+            const float4 c = *reinterpret_cast<const float4*>(pl);
+            if (kx == 0) {
+                const float l = (x > 0) ? pl[-1] : 0.0f;
+                acc[0] = acc[0] + l; acc[1] = acc[1] + c.x; acc[2] = acc[2] + c.y; acc[3] = acc[3] + c.z;
+            } else if (kx == 1) {
+                acc[0] = acc[0] + c.x; acc[1] = acc[1] + c.y; acc[2] = acc[2] + c.z; acc[3] = acc[3] + c.w;
+            } else {
+                const float r = (x + 4 < w) ? pl[4] : 0.0f;
+                acc[0] = acc[0] + c.y; acc[1] = acc[1] + c.z; acc[2] = acc[2] + c.w; acc[3] = acc[3] + r;
+            }
+        }
+    }
+    const float b = bias2[0], lo = disp_range[0], hi = disp_range[n_range - 1];
+    const long pix = (long)y * w + x;
+    const float4 iv = *reinterpret_cast<const float4*>(inv + pix);
+    float4 o, d;
+    o.x = iv.x + tanhf(acc[0] + b); o.y = iv.y + tanhf(acc[1] + b); o.z = iv.z + tanhf(acc[2] + b); o.w = iv.w + tanhf(acc[3] + b);
+    d.x = effi_inv_to_depth(o.x, lo, hi); d.y = effi_inv_to_depth(o.y, lo, hi);
+    d.z = effi_inv_to_depth(o.z, lo, hi); d.w = effi_inv_to_depth(o.w, lo, hi);
+    *reinterpret_cast<float4*>(out_inv + pix) = o;
+    *reinterpret_cast<float4*>(out_depth + pix) = d;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -467,6 +524,11 @@ extern "C" int effi_split_tanh_relu_stages_f32(const float* const* ctx, const in
     }
     for (int k = n_stages; k < 4; ++k) a.first[k] = blocks;      // unused maps own no blocks
     a.first[4] = blocks;
+    a.vec4 = 1;
+    for (int k = 0; k < n_stages; ++k)
+        if ((a.nh[k] & 3) || (a.n[k] & 3) ||
+            ((reinterpret_cast<uintptr_t>(ctx[k]) | reinterpret_cast<uintptr_t>(hidden[k]) | reinterpret_cast<uintptr_t>(inp[k])) & 15))
+            a.vec4 = 0;
     hipLaunchKernelGGL(split_tanh_relu_stages_kernel, dim3(blocks), dim3(TPB), 0, effi_s(stream), a);
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
@@ -496,6 +558,18 @@ extern "C" int effi_upsample_nearest_f32(const float* in, int C, int h, int w, i
     const long n = (long)C * h * f * w * f;
     hipLaunchKernelGGL(upsample_nearest_kernel, dim3(min(effi_cdiv(n, TPB), 8192)), dim3(TPB), 0, effi_s(stream),
                        in, C, h, w, f, out);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_head_update_f32(const float* partial9, const float* bias2, const float* inv_depth, const float* disp_range,
+                                    int n_range, int h, int w, float* out_inv, float* out_depth, effi_stream_t stream) {
+    if (!partial9 || !bias2 || !inv_depth || !disp_range || n_range < 2 || !out_inv || !out_depth || h < 1 || w < 1)
+        return EFFI_ERR_BADARG;
+    if (w & 3) return EFFI_ERR_UNSUPPORTED;
+    const long n = (long)h * (w >> 2);
+    hipLaunchKernelGGL(head_update_kernel, dim3((unsigned)effi_cdiv(n, TPB)), dim3(TPB), 0, effi_s(stream), partial9, bias2, inv_depth,
+                       disp_range, n_range, h, w, out_inv, out_depth);
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
 }

@@ -9,6 +9,7 @@ Inference only.
 from __future__ import annotations
 
 import functools
+import os
 
 import torch
 import torch.nn as nn
@@ -41,7 +42,7 @@ class DepthHead(nn.Module):
         self.conv2 = nn.Conv2d(hidden_dim, 1, 3, padding=1)
         self.relu = nn.ReLU(inplace=True)
         self.dropout = nn.Dropout2d(p=0.1)
-        self._c1, self._c2 = packing.PackCache(), packing.PackCache()
+        self._c1, self._c2, self._c2t = packing.PackCache(), packing.PackCache(), packing.PackCache()
 
     def run_hidden(self, net, out=None):
         w, b = _pack(self._c1, self.conv1)
@@ -51,6 +52,25 @@ class DepthHead(nn.Module):
         """Fused tail: inv_new = inv_depth + tanh(conv2(hidden)); also the depth it scales to."""
         w, b = _pack(self._c2, self.conv2)
         return ops.conv2d([hidden], w, b, 1, 3, epilogue=ops.EPI_HEAD, aux0=inv_depth, disp_range=disp_range)
+
+    def taps_fusable(self, net):
+        """conv1 + ReLU + the nine tap projections of conv2 in one kernel (``run_taps``): split / bf16 precision, hidden sizes the
+        fused 3x3 -> 1x1 kernel is built for."""
+        c1 = self.conv1.out_channels
+        if os.environ.get("EFFI_HEAD_TAPS", "1") == "0":      # A/B switch: the two-kernel form
+            return False
+        return (ops.uses_split() and net.shape[-1] % 4 == 0 and c1 % 16 == 0 and c1 // 16 in (1, 2, 3, 4, 6)
+                and self.conv1.in_channels % 8 == 0 and self.conv2.out_channels == 1)
+
+    def run_taps(self, net, inv_depth, disp_range, out=None):
+        """inv_new = inv_depth + tanh(conv2(relu(conv1(net)))) and its depth without the hidden map in HBM: conv2 has one output
+        channel, so it is nine 1x1 projections of the hidden map (applied in conv1's epilogue) summed over the 3x3 neighbourhood."""
+        w, b = _pack(self._c1, self.conv1)
+        c1 = self.conv1.out_channels
+        w2, b2 = self._c2t.get([self.conv2.weight], lambda: packing.pack_head_taps(self.conv2.weight, c1))
+        part = ops.conv2d_k3_k1_x3([net], w.wx, b, c1, None, w2, b2, 9, relu=False, relu1=True,
+                                   out=None if out is None else out[:9])
+        return ops.head_update(part, self.conv2.bias, inv_depth, disp_range)
 
     @ops.on_tensor_device
 
@@ -203,7 +223,7 @@ class BasicUpdateBlock(nn.Module):
         self.Inverse = Inverse
         self.mask = nn.Sequential(nn.Conv2d(hidden_dim, hidden_dim * 2, 3, padding=1), nn.ReLU(inplace=True),
                                   nn.Conv2d(hidden_dim * 2, ratio * ratio * 9, 1, padding=0))
-        self._m0, self._m2, self._m2x = packing.PackCache(), packing.PackCache(), packing.PackCache()
+        self._m0, self._m2, self._m2x, self._m2u = (packing.PackCache() for _ in range(4))
         self.last_depths = None     # depths of the last forward's iterations (filled on the fused path)
 
     def run_mask(self, net):
@@ -230,8 +250,8 @@ class BasicUpdateBlock(nn.Module):
         -> (depth [2h,2w], depth_to_inv(depth) [2h,2w])."""
         w, b = _pack(self._m0, self.mask[0])
         c1 = self.mask[0].out_channels
-        w2, b2 = self._m2x.get([self.mask[2].weight, self.mask[2].bias],
-                               lambda: packing.pack_conv1x1_after(self.mask[2].weight, self.mask[2].bias, c1, 0, scale=0.25))
+        w2, b2 = self._m2u.get([self.mask[2].weight, self.mask[2].bias],
+                               lambda: packing.pack_mask_taps_per_lane(self.mask[2].weight, self.mask[2].bias, c1, scale=0.25))
         return ops.conv2d_k3_k1_up2x([net], w.wx, b, c1, w2, b2, inv_depth, disp_range)
 
     # -- fused path: the cost lookup is our GetCost and scale_inv_depth is the global-range rescale ------
@@ -274,8 +294,11 @@ class BasicUpdateBlock(nn.Module):
             if want_mask and not fused_up:     # the mask head only needs the new hidden state (side stream when branches are on)
                 with ops.Branch() as br:
                     mask = self.run_mask(net)
-            hid = self.depth_head.run_hidden(net, head_buf)
-            inv_depth, depth = self.depth_head.run_update(hid, inv_depth, disp_range)
+            if self.depth_head.taps_fusable(net):
+                inv_depth, depth = self.depth_head.run_taps(net, inv_depth, disp_range, head_buf)
+            else:
+                hid = self.depth_head.run_hidden(net, head_buf)
+                inv_depth, depth = self.depth_head.run_update(hid, inv_depth, disp_range)
             if fused_up:                       # needs the NEW inverse depth: after the head
                 mask = self.run_mask_upsample(net, inv_depth, disp_range)
             elif want_mask:

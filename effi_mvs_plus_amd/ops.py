@@ -1003,6 +1003,23 @@ def upsample_nearest(x, f):
     return out
 
 
+def head_update(partial9, bias2, inv_depth, disp_range):
+    """Tail of the depth head when conv2's nine tap projections were applied by conv1's kernel (``conv2d_k3_k1_x3`` with
+    ``packing.pack_head_taps``): partial9 [9,h,w], inv_depth [1,h,w] -> (inv_depth + tanh(conv2), its depth), both [1,h,w]."""
+    _t(partial9, "partial sums"), _t(bias2, "bias"), _t(inv_depth, "inv_depth"), _t(disp_range, "disp_range")
+    if partial9.dim() != 3 or partial9.shape[0] != 9:
+        raise ValueError("head_update: partial sums must be [9,h,w]")
+    h, w = partial9.shape[-2:]
+    if inv_depth.numel() != h * w:
+        raise ValueError("head_update: inv_depth must hold h*w values")
+    out_inv = torch.empty(1, h, w, device=partial9.device, dtype=torch.float32)
+    out_depth = torch.empty(1, h, w, device=partial9.device, dtype=torch.float32)
+    work = lambda: {"flops": 30.0 * h * w, "bytes": 4.0 * h * w * 12}
+    check(_call("head_update", work, _lib.lib().effi_head_update_f32, _p(partial9), _p(bias2), _p(inv_depth), _p(disp_range),
+                disp_range.numel(), h, w, _p(out_inv), _p(out_depth), _stream()), "effi_head_update_f32")
+    return out_inv, out_depth
+
+
 # =============================================================================================
 # scope row n2: training kernels (csrc/train_ops.hip, warpcorr_dyn backward); thin wrappers, shapes checked here
 # =============================================================================================

@@ -236,6 +236,33 @@ def pack_conv1x1_after(weight, bias, cout1, c_extra, scale=1.0):
     return wp, b
 
 
+def pack_mask_taps_per_lane(weight, bias, cout1, scale=1.0):
+    """The 1x1 convolution of the x2 mask head, [36, cout1, 1, 1] with channel 4*k + s = (tap k, sub-pixel s)
+    (models/Effi_MVS_plus.py:170), for ``effi_conv2d_k3_k1_up2x_bf16x3_f32``: rows reordered so that MFMA row 16 t + 4 q + r is
+    (tap 4 t + r, sub-pixel q) -- the lane quarter q then owns all nine taps of one sub-pixel; rows of taps 9..11 are zero."""
+    assert weight.shape[0] == 36 and weight.shape[1] == cout1
+    w = weight.reshape(36, cout1).float()
+    wp = torch.zeros(48, cout1, device=w.device, dtype=torch.float32)
+    bp = torch.zeros(48, device=w.device, dtype=torch.float32)
+    for t in range(3):
+        for q in range(4):
+            for r in range(4):
+                k = 4 * t + r
+                if k < 9:
+                    wp[16 * t + 4 * q + r] = w[4 * k + q]
+                    if bias is not None:
+                        bp[16 * t + 4 * q + r] = bias[4 * k + q].float()
+    return pack_conv1x1_after(wp.view(48, cout1, 1, 1), bp, cout1, 0, scale)
+
+
+def pack_head_taps(weight, cin):
+    """conv2 of the depth head, [1, cin, 3, 3], as the 1x1 convolution [9, cin] of its nine taps (plane ky*3+kx), in the form
+    ``pack_conv1x1_after`` gives the fused 3x3 -> 1x1 kernel; its bias is applied by ``ops.head_update``."""
+    assert tuple(weight.shape) == (1, cin, 3, 3)
+    taps = weight[0].reshape(cin, 9).t().contiguous().view(9, cin, 1, 1)
+    return pack_conv1x1_after(taps, None, cin, 0)
+
+
 class Conv2dWeights:
     """Both operand orders of one 2-D convolution: ``w32`` for the exact-fp32 MFMA kernel and, for 3x3 kernels with more
     than one output channel, ``wx`` for the split-bf16 kernel.  ``ops.conv2d`` picks per call (precision mode, shape)."""

@@ -164,8 +164,9 @@ int effi_conv2d_k3_bf16x3_pair_f32(const float* const* srcs_a, const int* src_ch
 /* Mask head + convex upsampling of the last GRU iteration in one kernel (models/update.py:109-112,136-138: 3x3 conv, ReLU, 1x1
  * conv to 36 channels, x0.25 folded into w2pack / bias2; upsample_depth, models/Effi_MVS_plus.py:167-178; scale_inv_depth
  * :138-148): the 36 mask values of a pixel stay in registers.  inv_depth [h][w]; out_depth [2h][2w]; out_depth_inv [2h][2w] or
- * NULL = depth_to_disp(out_depth) (what the next stage starts from); cout1 in {32, 64, 96}; w % 4 == 0.  The softmax over the 9
- * taps is summed across four lanes, i.e. in a different order than effi_convex_upsample2x_f32 sums it (last-bit differences). */
+ * NULL = depth_to_disp(out_depth) (what the next stage starts from); cout1 in {32, 64, 96}; w % 4 == 0.  w2pack / bias2 hold 48
+ * rows: row 16 t + 4 q + r = mask channel 4 (4 t + r) + q, i.e. (tap 4 t + r, sub-pixel q), zero for taps 9..11
+ * (packing.pack_mask_taps_per_lane): one lane owns the nine taps of one sub-pixel, softmax and weighted sum in tap order. */
 int effi_conv2d_k3_k1_up2x_bf16x3_f32(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
                                       const float* bias, int cout1, const void* w2pack_bf16, const float* bias2,
                                       const float* inv_depth, const float* disp_range, int n_range, int h, int w,
@@ -313,6 +314,13 @@ int effi_stage1_hypotheses_f32(const float* disp_range, int n_range, int D, floa
 /* nearest-neighbour integer upsampling of a planar map (F.interpolate nearest, :479,497):
  * in [C][h][w] -> out [C][h*f][w*f]. */
 int effi_upsample_nearest_f32(const float* in, int C, int h, int w, int f, float* out, effi_stream_t stream);
+/* Tail of DepthHead + the update of BasicUpdateBlock.forward (models/update.py:15,21,125-127) when conv2's nine 1x1 tap
+ * projections of the hidden map were applied by the producer (effi_conv2d_k3_k1_bf16x3_f32 with cout2 = 9, relu1 = 1):
+ * partial9 [9][h][w] (plane ky*3+kx = sum_c conv2.weight[0][c][ky][kx] * hid[c]) ->
+ * out_inv = inv_depth + tanh(sum_tap partial9[tap][p + tap - 1] + bias2[0]) (zero outside the map = conv2's padding),
+ * out_depth = 1 / clamp(lo + (hi - lo) * out_inv, 1e-4) as EFFI_EPI_HEAD.  w % 4 == 0. */
+int effi_head_update_f32(const float* partial9, const float* bias2, const float* inv_depth, const float* disp_range,
+                         int n_range, int h, int w, float* out_inv, float* out_depth, effi_stream_t stream);
 
 /* ---- n3: dynamic geometric-consistency filter + depth averaging of the Tanks-and-Temples driver,
  * misc/fusion.py:117-181 (get_reproj_dynamic, vis_filter_dynamic) and the tensor part of test_tank.py:466-512, one reference

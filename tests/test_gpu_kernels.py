@@ -754,6 +754,19 @@ def test_split_tanh_relu(h, w):
     assert torch.equal(inp.cpu(), torch.relu(ctx[16:]))
 
 
+@pytest.mark.parametrize("sizes", [[(8, 12), (16, 24), (32, 48)], [(9, 7), (18, 14), (36, 28)], [(5, 4)], [(4, 6), (7, 9), (8, 8), (3, 3)]])
+def test_split_tanh_relu_stages(sizes):
+    """All stages in one launch: float4 form (every h*w a multiple of 4) and scalar form (odd sizes), 1 to 4 maps."""
+    from effi_mvs_plus_amd import ops
+    hds, cds = [48, 32, 16, 8][:len(sizes)], [12, 8, 4, 3][:len(sizes)]
+    g = torch.Generator().manual_seed(len(sizes) * 100 + sizes[0][0])
+    ctxs = [torch.randn(hd + cd, h, w, generator=g) * 2 for (h, w), hd, cd in zip(sizes, hds, cds)]
+    outs = ops.split_tanh_relu_stages([t(c, DEV) for c in ctxs], hds, cds)
+    for k, (c, hd, (hid, inp)) in enumerate(zip(ctxs, hds, outs)):
+        check_close(f"tanh half of map {k}", hid, torch.tanh(c[:hd]), rtol=1e-5, atol=1e-6)
+        assert torch.equal(inp.cpu(), torch.relu(c[hd:])), k
+
+
 @pytest.mark.parametrize("h,w", [(36, 60), (148, 200), (72, 520)])
 @pytest.mark.parametrize("hd", [16, 32, 48])
 def test_mask_head_fused_with_convex_upsampling(h, w, hd):
@@ -782,6 +795,44 @@ def test_mask_head_fused_with_convex_upsampling(h, w, hd):
         ops.set_precision(before)
     check_close(f"fused mask+upsample depth hd={hd} {h}x{w}", depth_f, depth_c.cpu(), rtol=2e-6, atol=1e-3)
     check_close(f"fused mask+upsample inverse depth hd={hd} {h}x{w}", dinv_f, dinv_c.cpu(), rtol=0.0, atol=2e-6)
+
+
+@pytest.mark.parametrize("h,w", [(36, 60), (37, 52), (148, 200), (72, 520)])
+@pytest.mark.parametrize("hd", [16, 32, 48])
+def test_depth_head_as_tap_projections(O, h, w, hd):
+    """DepthHead.run_taps (conv1 + ReLU + the nine 1x1 tap projections of conv2 in one kernel, then effi_head_update_f32) against the
+    oracle's depth head and against the two-kernel form (conv1 -> hidden map -> one-channel 3x3 conv); map edges = conv2's padding."""
+    import contextlib
+    import io
+    from effi_mvs_plus_amd import ops
+    from effi_mvs_plus_amd.models.update import BasicUpdateBlock
+    g = torch.Generator().manual_seed(hd * 7 + h)
+    with contextlib.redirect_stdout(io.StringIO()):
+        blk = BasicUpdateBlock(hidden_dim=hd, cost_dim=3, ratio=2, context_dim=hd // 4, UpMask=True, Inverse=True, cost_num=2).eval()
+    sd = synth.randomize_state_dict(blk.state_dict(), seed=11)
+    blk.load_state_dict(sd)
+    sd = {"b." + k: v for k, v in sd.items()}
+    blk = blk.to(DEV)
+    net_h = torch.tanh(torch.randn(1, hd, h, w, generator=g))
+    inv = torch.rand(1, 1, h, w, generator=g)
+    dv = torch.linspace(1 / 935.0, 1 / 425.0, 384)
+    net, inv_d, dv_d = t(net_h[0], DEV), t(inv[0], DEV), t(dv, DEV)
+    before = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        assert blk.depth_head.taps_fusable(net)
+        scratch = torch.full((hd, h, w), float("nan"), device=DEV)
+        inv_f, depth_f = blk.depth_head.run_taps(net, inv_d, dv_d, scratch)
+        hid = blk.depth_head.run_hidden(net)
+        inv_c, depth_c = blk.depth_head.run_update(hid, inv_d, dv_d)
+    finally:
+        ops.set_precision(before)
+    want_inv = inv + O.depth_head(sd, "b.depth_head", net_h)
+    tol = conv_tol("split", want_inv, 1e-4, 2e-5, 2)
+    check_close(f"tap-projected head vs oracle hd={hd} {h}x{w}", inv_f, want_inv[0], **tol)
+    check_close(f"tap-projected head vs two kernels hd={hd} {h}x{w}", inv_f, inv_c.cpu(), **tol)
+    want_depth = O.disp_to_depth(want_inv, torch.tensor(425.0), torch.tensor(935.0))[1]
+    check_close(f"tap-projected head depth hd={hd} {h}x{w}", depth_f, want_depth[0], rtol=1e-4, atol=2e-2)
 
 
 def test_cpu_tensor_fails_loudly():
