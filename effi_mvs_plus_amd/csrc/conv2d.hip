@@ -918,6 +918,303 @@ __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_pair_kernel(const Conv2d
 }
 
 // ------------------------------------------------------------------------------------------------
+// TWO chained 3x3 layers in one kernel, the intermediate map in LDS only ("tail" of the update block's encoder,
+// models/update.py:87-96: cor = relu(convc2(cor1)), dfm = relu(convd2(dfm1)), out = relu(convc(cat(convd(cat(cor, dfm)), context)))).
+// At 592x800 the two intermediate 16-channel maps cost 120 MB of HBM traffic per GRU iteration (written by one launch, read with
+// halo by the next) around layers whose MFMA work is a few microseconds; here they never leave the CU:
+//   * a workgroup owns 12 rows x 16 columns of the output.  Phase A computes the first layer on the tile grown by one pixel
+//     (14 x 18 = 252 pixels = 16 MFMA pixel groups, 4 per wave; 1.31x the pixels of the tile) from an input tile grown by two
+//     (16 rows x 24 columns staged as in the single-layer kernel).  A lane group's 16 pixels are 16 consecutive LINEAR indices of the
+//     14 x 18 region, so a group may wrap a row: the fragment address is per (lane, group) base + per (lane, K-step) tap offset.
+//   * its result (bias, ReLU, zero outside the map = the second layer's zero padding) is split to hi/lo bf16 and written in the
+//     A-tile layout [octet][pixel][8 ch] (one ds_write_b64 per lane, N-tile and group): "mid", 32 KB for 2 x 16 channels.
+//   * phase B is the single-layer kernel's loop reading its A fragments from mid (row pitch 18) with all its weight chunks resident,
+//     followed by the fused 1x1 epilogue of conv2d_k3_bf16x3_tile (EFFI_EPI_K1).
+// Same split-precision arithmetic as the two launches it replaces; the first layer's values are identical, the second layer sees
+// them as hi + lo exactly as its own staging would have split them, so the results are bitwise those of the two-launch form.
+// ------------------------------------------------------------------------------------------------
+struct EncTailArgs {
+    const float* src_a;      // cor1 [hd][h][w]
+    const float* src_b;      // dfm1 [hd][h][w]
+    const float* w_a;        // convc2, bf16x3 fragments (packing.pack_conv2d_bf16x3)
+    const float* bias_a;     // padded to 16*NTH
+    const float* w_b;        // convd2
+    const float* bias_b;
+    const float* w_d;        // convd [2 hd -> cmix]
+    const float* bias_d;     // padded to 16*NTB
+    const float* extra;      // context [c_extra][h][w]
+    int c_extra;
+    const float* w2;         // convc as 1x1 fragments (packing.pack_conv1x1_after)
+    const float* bias2;      // padded to 16*NT2
+    int cout2;
+    int h, w;
+    float* out;              // [cout2][h][w]
+    const float* zeros;
+};
+
+template <int NTH, int NTB>
+__global__ __launch_bounds__(256) void encoder_tail_bf16x3_kernel(const EncTailArgs a, int tiles_x, int ntiles) {
+    constexpr int TR = 12, TW = 16, RW = TW + 2, RH = TR + 2, NPM = RW * RH;          // 252 mid pixels
+    static_assert((NPM + 15) / 16 == 16, "16 pixel groups, 4 per wave (the last group has 12 real pixels)");
+    constexpr int AR = TR + 4, AW = TW + 8, AQ = AW / 4, APIX = AR * AW, CCH = 16, NKS = 5;
+    constexpr int NITEMS = (APIX / 4) * 2;                                           // 192 staging items
+    constexpr int NOCT = 4 * NTH;                                                    // mid octets: cor (2 NTH), dfm (2 NTH)
+    constexpr int NBFA = NKS * NTH * 2 * 64, NBFB = NKS * NTB * 2 * 64;              // 16-byte units of B per chunk
+    constexpr int NCHB = 2 * NTH;                                                    // phase-B chunks
+    constexpr int NBU = (NBFA > NCHB * NBFB) ? NBFA : NCHB * NBFB;
+    constexpr int NB4A = (NBFA + 255) / 256, NB4B = (NCHB * NBFB + 255) / 256;
+    constexpr int NBP = ((NB4A > NB4B) ? NB4A : NB4B) * 256;
+    static_assert(NBP >= NBU, "weight buffer");
+    __shared__ __attribute__((aligned(16))) unsigned short lds_ah[APIX * CCH];
+    __shared__ __attribute__((aligned(16))) unsigned short lds_al[APIX * CCH];
+    __shared__ __attribute__((aligned(16))) unsigned short mid_h[NOCT * NPM * 8];
+    __shared__ __attribute__((aligned(16))) unsigned short mid_l[NOCT * NPM * 8];
+    __shared__ __attribute__((aligned(16))) unsigned short lds_b[NBP * 8];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int h = a.h, w = a.w;
+    const long hw = (long)h * w;
+    const int tile = effi_xcd_remap(blockIdx.x, gridDim.x);
+    if (tile >= ntiles) return;
+    const int ty_ = tile / tiles_x;
+    const int x0 = (tile - ty_ * tiles_x) * TW, y0 = ty_ * TR;
+
+    // staging item of this thread: (pixel quad, octet) of the 16 x 24 input tile whose origin is (y0 - 2, x0 - 4)
+    const bool stager = tid < NITEMS;
+    const int pq = stager ? tid % (APIX / 4) : 0, soct = stager ? tid / (APIX / 4) : 0;
+    const int srow = pq / AQ, sqx = pq - srow * AQ;
+    const int sgy = y0 - 2 + srow, sgx = x0 - 4 + 4 * sqx;
+    const bool s_in = stager & (sgy >= 0) & (sgy < h) & (sgx >= 0) & (sgx < w);
+    const int s_off = sgy * w + sgx;
+    const int s_lds = (soct * APIX + srow * AW + 4 * sqx) * 8;
+
+    // with one chunk per first-layer convolution (NTH == 1) both convolutions' input octets are requested up front: the second
+    // one's latency then hides behind the first one's MFMA phase instead of being paid with two workgroups per CU
+    f32x4 pa[8], pa2[8];
+    auto prefetch_into = [&](f32x4 (&dst)[8], const float* src, int ch) {
+        const int cb = ch * CCH + soct * 8;
+        const float* q = s_in ? src + ((long)cb * hw + s_off) : a.zeros;
+        const long step = s_in ? hw : 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            dst[e] = *reinterpret_cast<const f32x4*>(q);
+            q += step;
+        }
+    };
+    auto prefetch = [&](const float* src, int ch) { prefetch_into(pa, src, ch); };
+    auto stash = [&](const float* wpk, int ch) {
+        const unsigned short* wbf = reinterpret_cast<const unsigned short*>(wpk);
+        f32x4 tb[NB4A];
+#pragma unroll
+        for (int j = 0; j < NB4A; ++j) {
+            const int u = min(tid + j * 256, NBFA - 1);
+            tb[j] = *reinterpret_cast<const f32x4*>(wbf + ((long)ch * NBFA + u) * 8);
+        }
+        if (stager) {
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                bf16x8 hi, lo;
+                split_octet(pa, px, hi, lo);
+                *reinterpret_cast<bf16x8*>(&lds_ah[s_lds + px * 8]) = hi;
+                if (!kHiOnly) *reinterpret_cast<bf16x8*>(&lds_al[s_lds + px * 8]) = lo;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB4A; ++j) *reinterpret_cast<f32x4*>(&lds_b[(tid + j * 256) * 8]) = tb[j];
+    };
+
+    // phase A addressing: group g = 4 wv + m, linear pixel p = 16 g + li of the 14 x 18 region whose origin is (y0 - 1, x0 - 1)
+    int gbase[4], pmid[4];
+    bool pin[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int p_ = min(16 * (4 * wv + m) + li, NPM - 1);  // lanes past the region repeat its last pixel (same value, same slot)
+        const int pr = p_ / RW, pc = p_ - pr * RW;
+        pmid[m] = p_;
+        gbase[m] = (pr * AW + pc + 2) * 8;                    // staged row pr + dy, staged column pc + dx + 2
+        const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
+        pin[m] = (gy >= 0) & (gy < h) & (gx >= 0) & (gx < w);
+    }
+    int koffa[NKS], koffb[NKS];
+#pragma unroll
+    for (int s_ = 0; s_ < NKS; ++s_) {
+        const int item = 4 * s_ + lk;
+        const int tap = min(item >> 1, 8), oct = item & 1;    // items 18, 19 are padding (B is zero there)
+        koffa[s_] = ((tap / 3) * AW + tap % 3 + oct * APIX) * 8;
+        koffb[s_] = ((3 * wv + tap / 3) * RW + li + tap % 3 + oct * NPM) * 8;
+    }
+
+    // ---- phase A: the two first-layer convolutions, one after the other ---------------------------------------
+    prefetch(a.src_a, 0);
+    if (NTH == 1) prefetch_into(pa2, a.src_b, 0);
+#pragma unroll 1
+    for (int job = 0; job < 2; ++job) {
+        const float* src = job ? a.src_b : a.src_a;
+        const float* wpk = job ? a.w_b : a.w_a;
+        const float* bias = job ? a.bias_b : a.bias_a;
+        f32x4 acc[4][NTH];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < NTH; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+        for (int ch = 0; ch < NTH; ++ch) {
+            __syncthreads();                                  // the previous chunk's fragments are no longer read
+            stash(wpk, ch);
+            __syncthreads();
+            if (ch + 1 < NTH) prefetch(src, ch + 1);
+            else if (job == 0) {
+                if (NTH == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pa[e] = pa2[e];
+                } else {
+                    prefetch(a.src_b, 0);
+                }
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < NKS; ++s_) {
+                bf16x8 ah[4], al[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    ah[m] = *reinterpret_cast<const bf16x8*>(&lds_ah[gbase[m] + koffa[s_]]);
+                    if (!kHiOnly) al[m] = *reinterpret_cast<const bf16x8*>(&lds_al[gbase[m] + koffa[s_]]);
+                }
+#pragma unroll
+                for (int n = 0; n < NTH; ++n) {
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&lds_b[(((s_ * NTH + n) * 2 + 0) * 64 + lane) * 8]);
+                    bf16x8 bl = bh;
+                    if (!kHiOnly) bl = *reinterpret_cast<const bf16x8*>(&lds_b[(((s_ * NTH + n) * 2 + 1) * 64 + lane) * 8]);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[m], acc[m][n], 0, 0, 0);
+                        if (!kHiOnly) {
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[m], acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[m], acc[m][n], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        // bias + ReLU, zero outside the map, split, into mid: lane = (pixel, channels 16 n + 4 lk .. + 3) -> half an octet slot
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < NTH; ++n) {
+                f32x4 vf;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vf[r] = pin[m] ? fmaxf(acc[m][n][r] + bias[n * 16 + 4 * lk + r], 0.0f) : 0.0f;
+                const bf16x4 vh = __builtin_convertvector(vf, bf16x4);
+                const bf16x4 vl = __builtin_convertvector(vf - __builtin_convertvector(vh, f32x4), bf16x4);
+                const int o = ((job * 2 * NTH + 2 * n + (lk >> 1)) * NPM + pmid[m]) * 8 + 4 * (lk & 1);
+                *reinterpret_cast<bf16x4*>(&mid_h[o]) = vh;
+                if (!kHiOnly) *reinterpret_cast<bf16x4*>(&mid_l[o]) = vl;
+            }
+    }
+    __syncthreads();                                          // mid complete, phase A's weight chunk no longer read
+
+    // ---- phase B: convd over mid (all its weight chunks resident), then the fused 1x1 ---------------------------
+    {
+        const unsigned short* wbf = reinterpret_cast<const unsigned short*>(a.w_d);
+#pragma unroll
+        for (int j = 0; j < NB4B; ++j) {
+            const int u = min(tid + j * 256, NCHB * NBFB - 1);
+            *reinterpret_cast<f32x4*>(&lds_b[(tid + j * 256) * 8]) = *reinterpret_cast<const f32x4*>(wbf + (long)u * 8);
+        }
+    }
+    __syncthreads();
+    constexpr int MR = 3;
+    f32x4 acc[MR][NTB];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < NTB; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int ch = 0; ch < NCHB; ++ch) {
+#pragma unroll
+        for (int s_ = 0; s_ < NKS; ++s_) {
+            bf16x8 ah[MR], al[MR];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                ah[m] = *reinterpret_cast<const bf16x8*>(&mid_h[ch * 2 * NPM * 8 + koffb[s_] + m * RW * 8]);
+                if (!kHiOnly) al[m] = *reinterpret_cast<const bf16x8*>(&mid_l[ch * 2 * NPM * 8 + koffb[s_] + m * RW * 8]);
+            }
+#pragma unroll
+            for (int n = 0; n < NTB; ++n) {
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&lds_b[(ch * NBFB + ((s_ * NTB + n) * 2 + 0) * 64 + lane) * 8]);
+                bf16x8 bl = bh;
+                if (!kHiOnly) bl = *reinterpret_cast<const bf16x8*>(&lds_b[(ch * NBFB + ((s_ * NTB + n) * 2 + 1) * 64 + lane) * 8]);
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[m], acc[m][n], 0, 0, 0);
+                    if (!kHiOnly) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[m], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[m], acc[m][n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // fused 1x1 over cat(convd + bias, context), ReLU: as the EFFI_EPI_K1 epilogue of conv2d_k3_bf16x3_tile
+    const unsigned short* w2 = reinterpret_cast<const unsigned short*>(a.w2);
+    const int nt2 = (a.cout2 + 15) >> 4;
+    bf16x4 xh[MR][NTB + 1], xl[MR][NTB + 1];
+    bool inside[MR];
+    long pixm[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        const int x = x0 + li, y = y0 + 3 * wv + m;
+        inside[m] = (y < h) & (x < w);
+        pixm[m] = inside[m] ? (long)y * w + x : 0;
+        f32x4 ex;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 4 * lk + r;
+            ex[r] = (inside[m] && c < a.c_extra) ? a.extra[(long)c * hw + pixm[m]] : 0.0f;
+        }
+#pragma unroll
+        for (int n = 0; n <= NTB; ++n) {
+            f32x4 vf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vf[r] = (n < NTB) ? acc[m][n < NTB ? n : 0][r] + a.bias_d[(n < NTB ? n : 0) * 16 + 4 * lk + r] : ex[r];
+            xh[m][n] = __builtin_convertvector(vf, bf16x4);
+            xl[m][n] = __builtin_convertvector(vf - __builtin_convertvector(xh[m][n], f32x4), bf16x4);
+        }
+    }
+    for (int t = 0; t < nt2; ++t) {
+        bf16x4 wh[NTB + 1], wl[NTB + 1];
+#pragma unroll
+        for (int n = 0; n <= NTB; ++n) {
+            const long f = ((long)(t * (NTB + 1) + n) * 2) * 64 + lane;
+            wh[n] = *reinterpret_cast<const bf16x4*>(w2 + f * 4);
+            wl[n] = *reinterpret_cast<const bf16x4*>(w2 + (f + 64) * 4);
+        }
+        const int co = t * 16 + 4 * lk;
+        float b2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b2[r] = a.bias2[co + r];
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int n = 0; n <= NTB; ++n) {
+                o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[n], xh[m][n], o, 0, 0, 0);
+                if (!kHiOnly) {
+                    o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wl[n], xh[m][n], o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[n], xl[m][n], o, 0, 0, 0);
+                }
+            }
+            if (inside[m]) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co + r < a.cout2) a.out[(long)(co + r) * hw + pixm[m]] = fmaxf(o[r] + b2[r], 0.0f);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Stride-1 3-D convolution with a ROLLING window of input planes (split precision, same MFMA scheme as above).
 // The z-batched form above re-reads every input plane for each of the three output planes it contributes to; here a
 // workgroup owns an (x, y) tile and a run of ZT consecutive output planes, keeps planes z-1, z, z+1 of all input channels in
@@ -1934,6 +2231,29 @@ extern "C" int EFFI_FN(effi_conv2d_k3_k1_bf16x3_f32)(const float* const* srcs, c
         case 6: return launch_bf16x3<6, EFFI_EPI_K1>(a, st);
         default: return EFFI_ERR_UNSUPPORTED;
     }
+}
+
+extern "C" int EFFI_FN(effi_encoder_tail_bf16x3_f32)(const float* cor1, const float* dfm1, int hd, const void* wc2_bf16, const float* bias_c2,
+                                            const void* wd2_bf16, const float* bias_d2, const void* wd_bf16, const float* bias_d,
+                                            int cmix, const float* extra, int c_extra, const void* w2pack_bf16, const float* bias2,
+                                            int cout2, int h, int w, float* out, effi_stream_t stream) {
+    if (!cor1 || !dfm1 || !wc2_bf16 || !bias_c2 || !wd2_bf16 || !bias_d2 || !wd_bf16 || !bias_d || !w2pack_bf16 || !bias2 || !out)
+        return EFFI_ERR_BADARG;
+    if (hd < 1 || cmix < 1 || cout2 < 1 || h < 1 || w < 1 || c_extra < 0 || (c_extra > 0 && !extra)) return EFFI_ERR_BADARG;
+    if ((w & 3) || hd != 16 || cmix > 16 || c_extra > 16 || cout2 > 96) return EFFI_ERR_UNSUPPORTED;
+    EncTailArgs a;
+    a.src_a = cor1; a.src_b = dfm1;
+    a.w_a = reinterpret_cast<const float*>(wc2_bf16); a.bias_a = bias_c2;
+    a.w_b = reinterpret_cast<const float*>(wd2_bf16); a.bias_b = bias_d2;
+    a.w_d = reinterpret_cast<const float*>(wd_bf16); a.bias_d = bias_d;
+    a.extra = c_extra ? extra : bias2; a.c_extra = c_extra;
+    a.w2 = reinterpret_cast<const float*>(w2pack_bf16); a.bias2 = bias2; a.cout2 = cout2;
+    a.h = h; a.w = w; a.out = out;
+    a.zeros = effi_zero_page();
+    if (!a.zeros) return EFFI_ERR_WORKSPACE;
+    const int tiles_x = effi_cdiv(w, 16), ntiles = tiles_x * effi_cdiv(h, 12);
+    hipLaunchKernelGGL((encoder_tail_bf16x3_kernel<1, 1>), dim3(ntiles), dim3(256), 0, effi_s(stream), a, tiles_x, ntiles);
+    return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
 
 extern "C" int EFFI_FN(effi_conv2d_k3_k1_up2x_bf16x3_f32)(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,

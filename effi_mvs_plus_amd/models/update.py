@@ -171,6 +171,17 @@ class ProjectionInput(nn.Module):
             # the cost chain (lookup + 1x1 -> 3x3) and the depth chain (7x7 -> 3x3) are independent: each level of the two
             # chains is ONE launch whose workgroups are shared between them (no second stream, no fork / join bubbles)
             cor1, dfm = inputs()
+            w, b = _pack(self._caches["d"], self.convd)
+            cmix, cd = self.convd.out_channels, context.shape[0]
+            if (hd == 16 and cmix <= 16 and cd <= 16 and w.wx is not None and self.convc.in_channels == cmix + cd
+                    and os.environ.get("EFFI_ENC_TAIL", "0") == "1"):
+                # the rest of the encoder in one kernel: the two 3x3 maps of this level never reach HBM.  Opt-in (EFFI_ENC_TAIL=1):
+                # measured at 592x800 the kernel takes 69.1 us, exactly the 31.5 + 37.3 us of the two launches it replaces (the
+                # 120 MB it saves are paid back by 1.31x first-layer work at two workgroups per CU), and a view gets 0.8 % slower
+                w2, b2 = self._caches["c_after"].get([self.convc.weight, self.convc.bias],
+                                                     lambda: packing.pack_conv1x1_after(self.convc.weight, self.convc.bias, cmix, cd))
+                # (its output must not alias its inputs: other workgroups still read their halos -> "enc_tail", not "enc")
+                return ops.encoder_tail(cor1, dfm, wc2.wx, bc2, wd2.wx, bd2, w.wx, b, cmix, context, w2, b2, hd, out=g("enc_tail"))
             cor, dfm = ops.conv2d_k3_bf16x3_pair([cor1], wc2.wx, bc2, [dfm], wd2.wx, bd2, hd, act=ops.ACT_RELU,
                                                  out_a=g("cor2"), out_b=g("dfm2"))
         else:
@@ -271,6 +282,8 @@ class BasicUpdateBlock(nn.Module):
         # predecessor's last reader, on both streams), and the hidden state ping-pongs between two buffers (only the last state
         # is returned).
         bufs["enc"] = bufs["cor1"]                # the encoder's output overwrites its first intermediate (dead after convc2)
+        bufs["enc_tail"] = bufs["dfm2"]           # one-kernel encoder tail: reads cor1 / dfm1 with halos, so it writes elsewhere
+                                                  # (dfm2 is free until the depth head, which runs after the last reader of x)
         z_buf, rh_buf, head_buf, cost_buf = bufs["dfm1"], bufs["cor2"], bufs["dfm2"], None
         h_bufs = [mk(hd), mk(hd)]
         inv_list, mask_list, depth_list = [], [], []

@@ -891,6 +891,24 @@ def conv2d_k3_k1_x3(srcs, wpack, bias, cout1, extra, w2pack, bias2, cout2, relu=
     return out
 
 
+def encoder_tail(cor1, dfm1, wc2, bc2, wd2, bd2, wd, bd, cmix, extra, w2pack, bias2, cout2, out=None):
+    """relu(convc2(cor1)), relu(convd2(dfm1)) -> convd over their concatenation -> 1x1 convc over cat(., extra) + ReLU in ONE kernel
+    (the two intermediate maps stay in LDS): ``conv2d_k3_bf16x3_pair`` followed by ``conv2d_k3_k1_x3``.  hd == 16 only."""
+    _t(cor1, "cor1"), _t(dfm1, "dfm1"), _t(extra, "extra channels")
+    hd, h, w = cor1.shape
+    if dfm1.shape != cor1.shape or extra.shape[-2:] != cor1.shape[-2:]:
+        raise ValueError("encoder_tail: cor1, dfm1 and the extra channels must share one map size")
+    if out is None:
+        out = torch.empty(cout2, h, w, device=cor1.device, dtype=torch.float32)
+    c_extra = extra.shape[0]
+    work = lambda: {"flops": 2.0 * h * w * (2 * hd * hd * 9 + 2 * hd * cmix * 9 + (cmix + c_extra) * cout2),
+                    "bytes": 4.0 * h * w * (2 * hd + c_extra + cout2)}
+    check(_call("encoder_tail", work, _x3("effi_encoder_tail_bf16x3_f32"), _p(cor1), _p(dfm1), hd, _p(wc2), _p(bc2), _p(wd2), _p(bd2),
+                _p(wd), _p(bd), cmix, _p(extra), c_extra, _p(w2pack), _p(bias2), cout2, h, w, _p(out), _stream()),
+          "effi_encoder_tail_bf16x3_f32")
+    return out
+
+
 def conv2d_k3_k1_up2x(srcs, wpack, bias, cout1, w2pack, bias2, inv_depth, disp_range, want_depth_inv=True):
     """Mask head (3x3 + ReLU + 1x1 to 36 channels) and the convex x2 upsampling it feeds in one kernel: inv_depth [1,h,w] or [h,w]
     -> (depth [2h,2w], depth_to_inv(depth) [2h,2w] or None).  cout1 in {32, 64, 96}."""

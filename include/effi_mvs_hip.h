@@ -161,6 +161,16 @@ int effi_conv2d_k3_bf16x3_pair_f32(const float* const* srcs_a, const int* src_ch
                                    const float* bias_a, float* out_a, const float* const* srcs_b,
                                    const int* src_channels_b, int n_src_b, const void* wpack_b, const float* bias_b,
                                    float* out_b, int cout, int h, int w, int act, effi_stream_t stream);
+/* Tail of the update block's encoder in one kernel (models/update.py:87-96): cor = relu(convc2(cor1)), dfm = relu(convd2(dfm1)),
+ * out = relu(convc(cat(convd(cat(cor, dfm)), extra))) with extra = the context map -- the launches
+ * effi_conv2d_k3_bf16x3_pair_f32 + effi_conv2d_k3_k1_bf16x3_f32 with the two intermediate maps kept in LDS (12 x 16 output tiles,
+ * first layers computed on the tile grown by one pixel).  Same arithmetic, bitwise the result of the two launches.
+ * wc2 / wd2 [hd -> hd] and wd [2 hd -> cmix] as packing.pack_conv2d_bf16x3, biases padded to multiples of 16; w2pack / bias2 as
+ * packing.pack_conv1x1_after(convc, cmix, c_extra).  hd == 16, cmix <= 16, c_extra <= 16, w % 4 == 0, else EFFI_ERR_UNSUPPORTED. */
+int effi_encoder_tail_bf16x3_f32(const float* cor1, const float* dfm1, int hd, const void* wc2_bf16, const float* bias_c2,
+                                 const void* wd2_bf16, const float* bias_d2, const void* wd_bf16, const float* bias_d, int cmix,
+                                 const float* extra, int c_extra, const void* w2pack_bf16, const float* bias2, int cout2, int h,
+                                 int w, float* out, effi_stream_t stream);
 /* Mask head + convex upsampling of the last GRU iteration in one kernel (models/update.py:109-112,136-138: 3x3 conv, ReLU, 1x1
  * conv to 36 channels, x0.25 folded into w2pack / bias2; upsample_depth, models/Effi_MVS_plus.py:167-178; scale_inv_depth
  * :138-148): the 36 mask values of a pixel stay in registers.  inv_depth [h][w]; out_depth [2h][2w]; out_depth_inv [2h][2w] or
@@ -485,6 +495,10 @@ int effi_conv2d_k3_k1_bf16x3_f32_bf16(const float* const* srcs, const int* src_c
                                  const float* bias, int cout1, int relu1, const float* extra, int c_extra,
                                  const void* w2pack_bf16, const float* bias2, int cout2, int relu, int h, int w, float* out,
                                  effi_stream_t stream);
+int effi_encoder_tail_bf16x3_f32_bf16(const float* cor1, const float* dfm1, int hd, const void* wc2_bf16, const float* bias_c2,
+                                 const void* wd2_bf16, const float* bias_d2, const void* wd_bf16, const float* bias_d, int cmix,
+                                 const float* extra, int c_extra, const void* w2pack_bf16, const float* bias2, int cout2, int h,
+                                 int w, float* out, effi_stream_t stream);
 int effi_conv2d_k3_k1_up2x_bf16x3_f32_bf16(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
                                       const float* bias, int cout1, const void* w2pack_bf16, const float* bias2,
                                       const float* inv_depth, const float* disp_range, int n_range, int h, int w,

@@ -835,6 +835,41 @@ def test_depth_head_as_tap_projections(O, h, w, hd):
     check_close(f"tap-projected head depth hd={hd} {h}x{w}", depth_f, want_depth[0], rtol=1e-4, atol=2e-2)
 
 
+@pytest.mark.parametrize("h,w", [(12, 16), (36, 60), (37, 52), (148, 200), (50, 520)])
+@pytest.mark.parametrize("cd", [4, 8])
+def test_encoder_tail_equals_the_two_launches(h, w, cd):
+    """effi_encoder_tail_bf16x3_f32 (convc2 | convd2 -> convd -> convc with the two intermediate maps in LDS) against the pair launch
+    followed by the fused 3x3 -> 1x1 launch: same operands, same products, same order -> bitwise equal; tiles cut by the map's
+    border on every side, maps smaller than a tile."""
+    from effi_mvs_plus_amd import ops, packing
+    hd, cmix = 16, 16 - cd
+    g = torch.Generator().manual_seed(h * 31 + cd)
+    rnd = lambda *shape, s=1.0: torch.randn(*shape, generator=g) * s  # noqa: E731
+    cor1, dfm1 = torch.relu(rnd(hd, h, w)), torch.relu(rnd(hd, h, w))
+    ctx = torch.relu(rnd(cd, h, w))
+    wc2, bc2, wd2, bd2 = rnd(hd, hd, 3, 3, s=0.1), rnd(hd, s=0.1), rnd(hd, hd, 3, 3, s=0.1), rnd(hd, s=0.1)
+    wd, bd = rnd(cmix, 2 * hd, 3, 3, s=0.08), rnd(cmix, s=0.1)
+    wc, bc = rnd(hd, hd, 1, 1, s=0.2), rnd(hd, s=0.1)
+    d = lambda x: t(x, DEV)  # noqa: E731
+    pc2, pbc2 = packing.pack_conv2d_bf16x3(d(wc2), d(bc2))
+    pd2, pbd2 = packing.pack_conv2d_bf16x3(d(wd2), d(bd2))
+    pd, pbd = packing.pack_conv2d_bf16x3(d(wd), d(bd))
+    p2, pb2 = packing.pack_conv1x1_after(d(wc), d(bc), cmix, cd)
+    before = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        got = ops.encoder_tail(d(cor1), d(dfm1), pc2, pbc2, pd2, pbd2, pd, pbd, cmix, d(ctx), p2, pb2, hd)
+        cor, dfm = ops.conv2d_k3_bf16x3_pair([d(cor1)], pc2, pbc2, [d(dfm1)], pd2, pbd2, hd, act=ops.ACT_RELU)
+        want = ops.conv2d_k3_k1_x3([cor, dfm], pd, pbd, cmix, d(ctx), p2, pb2, hd, relu=True)
+    finally:
+        ops.set_precision(before)
+    assert torch.equal(got, want), float((got - want).abs().max())
+    ref = F.relu(F.conv2d(torch.cat([F.conv2d(torch.cat([F.relu(F.conv2d(cor1[None], wc2, bc2, padding=1)),
+                                                             F.relu(F.conv2d(dfm1[None], wd2, bd2, padding=1))], 1), wd, bd, padding=1),
+                                     ctx[None]], 1), wc, bc))[0]
+    check_close(f"encoder tail vs torch {h}x{w} cd={cd}", got, ref, **conv_tol("split", ref, 1e-4, 2e-5, 3))
+
+
 def test_cpu_tensor_fails_loudly():
     from effi_mvs_plus_amd import ops
     from effi_mvs_plus_amd._lib import EffiLibraryError

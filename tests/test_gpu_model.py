@@ -98,6 +98,40 @@ def test_cascade_vs_oracle_large_tiles(precision):
     assert (out["photometric_confidence"].cpu() - want["photometric_confidence"]).abs().mean() <= 1e-3
 
 
+def test_switchable_kernel_forms_agree():
+    """The A/B switches of the update block select other kernels for the same arithmetic: EFFI_ENC_TAIL=1 (encoder tail in one
+    kernel, intermediate maps in LDS) is bitwise the default two launches; EFFI_HEAD_TAPS=0 (depth head as conv1 -> hidden map ->
+    one-channel 3x3) differs from the default tap-projected head only by the summation order of conv2 (mean <= 1e-5 normalised)."""
+    import os
+    net, sd = build_model("16,8,8", seed=4, device=DEV)
+    imgs, pm, dv = synth.synth_sample(256, 320, 3, seed=5)
+    feats, ctx = _features_on_cpu(sd, imgs)
+    args = ([{k: t(v, DEV) for k, v in f.items()} for f in feats], {k: t(v, DEV) for k, v in ctx.items()},
+            {k: t(v, DEV) for k, v in pm.items()}, t(dv, DEV))
+
+    def run(**env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            with torch.no_grad():
+                return [d.clone() for d in net.forward_hot(*args)["depth"]]
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    base = run()
+    tail = run(EFFI_ENC_TAIL="1")
+    for i, (a, b) in enumerate(zip(base, tail)):
+        assert torch.equal(a, b), f"depth[{i}] differs with the one-kernel encoder tail"
+    two = run(EFFI_HEAD_TAPS="0")
+    for i, (a, b) in enumerate(zip(base, two)):
+        mean, p99, mx = _norm_err(a, b.cpu())
+        assert mx <= 1e-3 and mean <= 1e-5, (i, mean, p99, mx)
+
+
 # ---- the configurations BASELINE.json names, at their own sizes (SURVEY.md section 8(d) "Configs restated") -----------------------
 FULL_SIZE = {
     "cfg2 800x576 S=4 48,8,8": (576, 800, 5, "48,8,8"),
