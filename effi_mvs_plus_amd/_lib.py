@@ -66,6 +66,7 @@ SIGNATURES = {
     "effi_stage1_hypotheses_f32": [_vp, _i, _i, _vp, _vp, _vp],
     "effi_upsample_nearest_f32": [_vp, _i, _i, _i, _i, _vp, _vp],
     "effi_head_update_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "effi_conv2d_k3_twice_bf16x3_f32": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "effi_encoder_tail_bf16x3_f32": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp],
     # scope row n2: training kernels
     "effi_conv_wgrad_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
@@ -86,7 +87,7 @@ SIGNATURES = {
 # plain-bf16-operand variants (hi*hi only) of the split-precision convolution entries: same signatures, suffix _bf16
 BF16X3_ENTRIES = ("effi_conv2d_k3_bf16x3_pair_f32", "effi_conv2d_k3_bf16x3_f32", "effi_conv2d_k3_k1_bf16x3_f32",
                   "effi_conv2d_k3_k1_up2x_bf16x3_f32", "effi_conv3d_k3s1_bf16x3_f32", "effi_conv3d_k3s1_roll_bf16x3_f32",
-                  "effi_conv3d_k3s1_roll_bf16x3_pair_f32", "effi_deconv3d_k3s2_bf16x3_f32", "effi_encoder_tail_bf16x3_f32")
+                  "effi_conv3d_k3s1_roll_bf16x3_pair_f32", "effi_deconv3d_k3s2_bf16x3_f32", "effi_encoder_tail_bf16x3_f32", "effi_conv2d_k3_twice_bf16x3_f32")
 for _n in BF16X3_ENTRIES:
     SIGNATURES[_n + "_bf16"] = SIGNATURES[_n]
 

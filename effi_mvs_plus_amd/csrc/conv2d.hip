@@ -291,10 +291,13 @@ __device__ __forceinline__ void conv_epilogue_store(const Conv2dArgs& a, float (
 template <int EPI>
 __device__ __forceinline__ void conv_epilogue_store_t(const Conv2dArgs& a, const f32x4& acc, int co0, long pix, long hw,
                                                       int zpl) {
+    constexpr bool kShuf = (EPI == EFFI_EPI_ADD_SHUF2 || EPI == EFFI_EPI_NHWC_ADD_SHUF2);
+    constexpr bool kNhwc = (EPI == EFFI_EPI_NHWC || EPI == EFFI_EPI_NHWC_ADD_SHUF2);
+    constexpr bool kPlain = (EPI == EFFI_EPI_PLAIN || EPI == EFFI_EPI_ADD_SHUF2);
     float v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = acc[r] + a.bias[co0 + r];       // bias is padded to 16*NT entries
-    if (EPI == EFFI_EPI_NHWC || EPI == EFFI_EPI_PLAIN) {               // activation: one uniform branch for the 4 values
+    if (kNhwc || kPlain) {                                             // activation: one uniform branch for the 4 values
         if (a.act == EFFI_ACT_RELU) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
@@ -303,7 +306,18 @@ __device__ __forceinline__ void conv_epilogue_store_t(const Conv2dArgs& a, const
             for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], a.act);
         }
     }
-    if (EPI == EFFI_EPI_NHWC) {
+    if (kShuf) {
+        // + a coarser map with the four sub-pixel parities as channel groups (pixel shuffle): aux0 planar [4*cout][h/2][w/2],
+        // channel ((y & 1) * 2 + (x & 1)) * cout + co at (y >> 1, x >> 1) -- the nearest-upsampled branch of the pyramid's last
+        // head, evaluated at half resolution (models/module.py:407-408, see packing.pack_fpn_head_split)
+        const int y = (int)(pix / a.w), x = (int)(pix - (long)y * a.w);
+        const long hw4 = (long)(a.h >> 1) * (a.w >> 1);
+        const float* up = a.aux0 + (long)(((y & 1) * 2 + (x & 1)) * a.cout + co0) * hw4 + (long)(y >> 1) * (a.w >> 1) + (x >> 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (co0 + r < a.cout) v[r] = v[r] + up[(long)r * hw4];
+    }
+    if (kNhwc) {
         if (co0 + 3 < a.cout) {
             *reinterpret_cast<float4*>(a.out0 + pix * a.cout + co0) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
@@ -315,7 +329,7 @@ __device__ __forceinline__ void conv_epilogue_store_t(const Conv2dArgs& a, const
     }
     // channel guard: one test per group of 4 when cout is a multiple of 4 (every layer of the model), else per channel
     const int nvalid = ((a.cout & 3) == 0) ? (co0 < a.cout ? 4 : 0) : a.cout - co0;
-    if (EPI == EFFI_EPI_PLAIN) {
+    if (kPlain) {
         float* dst = a.out0 + (long)co0 * a.ostride + (long)zpl * hw + pix;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -2170,6 +2184,14 @@ extern "C" int EFFI_FN(effi_conv2d_k3_bf16x3_f32)(const float* const* srcs, cons
         case EFFI_EPI_NHWC:
             if (act < EFFI_ACT_NONE || act > EFFI_ACT_TANH) return EFFI_ERR_BADARG;
             return dispatch_bf16x3<EFFI_EPI_NHWC>(a, nt, st);
+        case EFFI_EPI_ADD_SHUF2:
+        case EFFI_EPI_NHWC_ADD_SHUF2:
+            if (!aux0 || (h & 1) || (w & 1) || act != EFFI_ACT_NONE) return EFFI_ERR_BADARG;
+            if (nt == 1) return epilogue == EFFI_EPI_ADD_SHUF2 ? launch_bf16x3<1, EFFI_EPI_ADD_SHUF2>(a, st)
+                                                               : launch_bf16x3<1, EFFI_EPI_NHWC_ADD_SHUF2>(a, st);
+            if (nt == 2) return epilogue == EFFI_EPI_ADD_SHUF2 ? launch_bf16x3<2, EFFI_EPI_ADD_SHUF2>(a, st)
+                                                               : launch_bf16x3<2, EFFI_EPI_NHWC_ADD_SHUF2>(a, st);
+            return EFFI_ERR_UNSUPPORTED;
         case EFFI_EPI_GRU_ZR:
             if (!aux0 || !out1 || (cout % 32) != 0) return EFFI_ERR_BADARG;
             if (nt == 2) return launch_bf16x3<2, EFFI_EPI_GRU_ZR>(a, st);
@@ -2231,6 +2253,213 @@ extern "C" int EFFI_FN(effi_conv2d_k3_k1_bf16x3_f32)(const float* const* srcs, c
         case 6: return launch_bf16x3<6, EFFI_EPI_K1>(a, st);
         default: return EFFI_ERR_UNSUPPORTED;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The pyramid's first block at full resolution (models/module.py:353-356, conv0 = Conv2d(3, 8) -> Conv2d(8, 8), BN folded, ReLU
+// after each) as ONE kernel: both layers have at most 8 input channels, i.e. ONE octet, so a layer is 9 K-items (taps) = 3 K-steps
+// instead of the 5 of a 16-channel chunk, and the 8-channel intermediate (61 MB at 1184x1600, written and re-read by the two-launch
+// form) stays in LDS.  Same construction as encoder_tail_bf16x3_kernel (12 x 16 output tile, first layer on the tile grown by
+// one pixel = 16 linearised pixel groups, its result split to hi/lo in the A-tile layout), but these layers are memory-bound and
+// the LDS footprint is 33 KB, so the halo recompute is cheap and the occupancy stays high.
+// Weights: [3 K-steps][hi|lo][64 lanes][8] bf16 per layer (packing.pack_conv2d_bf16x3_oct), lane = q*16 + j holds
+// W[j][e][tap = 4 s + q] (zero for taps 9..11, channels >= cin, couts >= cout).
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct ConvTwiceArgs {
+    const float* src;        // [cin][h][w], cin <= 8
+    int cin;
+    const float* w_a;        // first layer fragments
+    const float* bias_a;     // padded to 16
+    const float* w_b;        // second layer
+    const float* bias_b;     // padded to 16
+    int cout;                // second layer's output channels (<= 16); the first layer's are 8
+    int h, w;
+    float* out;              // [cout][h][w]
+    const float* zeros;
+};
+
+__global__ __launch_bounds__(256) void conv2d_k3_twice_oct_kernel(const ConvTwiceArgs a, int tiles_x, int ntiles) {
+    constexpr int TR = 12, TW = 16, RW = TW + 2, RH = TR + 2, NPM = RW * RH;          // 252 mid pixels
+    constexpr int AR = TR + 4, AW = TW + 8, AQ = AW / 4, APIX = AR * AW, NKS = 3;
+    constexpr int NITEMS = APIX / 4;                                                 // 96 staging items (one octet)
+    constexpr int NBF = NKS * 2 * 64;                                                // 16-byte units of B per layer
+    __shared__ __attribute__((aligned(16))) unsigned short lds_ah[APIX * 8];
+    __shared__ __attribute__((aligned(16))) unsigned short lds_al[APIX * 8];
+    __shared__ __attribute__((aligned(16))) unsigned short mid_h[NPM * 8];
+    __shared__ __attribute__((aligned(16))) unsigned short mid_l[NPM * 8];
+    __shared__ __attribute__((aligned(16))) unsigned short lds_b[2 * 512 * 8];      // both layers' fragments (2 x 384 units, padded)
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int h = a.h, w = a.w;
+    const long hw = (long)h * w;
+    // persistent workgroups: a contiguous run of tiles each (neighbouring tiles share their halos in the same XCD's L2); the next
+    // tile's input is requested before the current tile is multiplied, the weights are fetched once
+    const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int t0 = effi_xcd_remap(blockIdx.x, gridDim.x) * per, t1 = min(t0 + per, ntiles);
+    if (t0 >= t1) return;
+
+    {
+        const unsigned short* wa = reinterpret_cast<const unsigned short*>(a.w_a);
+        const unsigned short* wb = reinterpret_cast<const unsigned short*>(a.w_b);
+        for (int u = tid; u < NBF; u += 256) {
+            *reinterpret_cast<f32x4*>(&lds_b[u * 8]) = *reinterpret_cast<const f32x4*>(wa + (long)u * 8);
+            *reinterpret_cast<f32x4*>(&lds_b[(512 + u) * 8]) = *reinterpret_cast<const f32x4*>(wb + (long)u * 8);
+        }
+    }
+    // input tile 16 x 24 with origin (y0 - 2, x0 - 4): threads 0..95 own a pixel quad each
+    const bool stager = tid < NITEMS;
+    const int srow = stager ? tid / AQ : 0, sqx = stager ? tid - srow * AQ : 0;
+    const int s_lds = (srow * AW + 4 * sqx) * 8;
+    const int emax = a.cin - 1;
+    f32x4 pa[8];
+    auto prefetch = [&](int tile) {
+        const int ty_ = tile / tiles_x;
+        const int x0 = (tile - ty_ * tiles_x) * TW, y0 = ty_ * TR;
+        const int sgy = y0 - 2 + srow, sgx = x0 - 4 + 4 * sqx;
+        const bool s_in = (sgy >= 0) & (sgy < h) & (sgx >= 0) & (sgx < w);
+        const float* q = s_in ? a.src + ((long)sgy * w + sgx) : a.zeros;
+        const long step = s_in ? hw : 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            pa[e] = *reinterpret_cast<const f32x4*>(q);
+            q += (e < emax) ? step : 0;                    // channels past the last real one re-read it (their weights are zero)
+        }
+    };
+
+    // K-step s: lane quarter lk owns tap 4 s + lk (taps 9..11: B is zero, the address repeats tap 8)
+    int koffa[NKS], koffb[NKS];
+#pragma unroll
+    for (int s_ = 0; s_ < NKS; ++s_) {
+        const int tap = min(4 * s_ + lk, 8);
+        koffa[s_] = ((tap / 3) * AW + tap % 3) * 8;
+        koffb[s_] = ((3 * wv + tap / 3) * RW + li + tap % 3) * 8;
+    }
+    int gbase[4], pmid[4], prow[4], pcol[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int p_ = min(16 * (4 * wv + m) + li, NPM - 1);
+        prow[m] = p_ / RW;
+        pcol[m] = p_ - prow[m] * RW;
+        pmid[m] = p_;
+        gbase[m] = (prow[m] * AW + pcol[m] + 2) * 8;
+    }
+    float ba[4], bb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        ba[r] = a.bias_a[(4 * lk + r) & 15];
+        bb[r] = a.bias_b[(4 * lk + r) & 15];
+    }
+
+    if (stager) prefetch(t0);
+#pragma unroll 1
+    for (int tile = t0; tile < t1; ++tile) {
+        const int ty_ = tile / tiles_x;
+        const int x0 = (tile - ty_ * tiles_x) * TW, y0 = ty_ * TR;
+        if (stager) {
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                bf16x8 hi, lo;
+                split_octet(pa, px, hi, lo);
+                *reinterpret_cast<bf16x8*>(&lds_ah[s_lds + px * 8]) = hi;
+                if (!kHiOnly) *reinterpret_cast<bf16x8*>(&lds_al[s_lds + px * 8]) = lo;
+            }
+            if (tile + 1 < t1) prefetch(tile + 1);
+        }
+        __syncthreads();                                   // input tile complete (and the previous tile's second layer done with mid)
+
+        // ---- first layer on the 14 x 18 region (origin (y0 - 1, x0 - 1)), 16 pixel groups, 4 per wave ----
+        {
+            f32x4 acc[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int s_ = 0; s_ < NKS; ++s_) {
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&lds_b[((s_ * 2 + 0) * 64 + lane) * 8]);
+                bf16x8 bl = bh;
+                if (!kHiOnly) bl = *reinterpret_cast<const bf16x8*>(&lds_b[((s_ * 2 + 1) * 64 + lane) * 8]);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&lds_ah[gbase[m] + koffa[s_]]);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, acc[m], 0, 0, 0);
+                    if (!kHiOnly) {
+                        const bf16x8 al = *reinterpret_cast<const bf16x8*>(&lds_al[gbase[m] + koffa[s_]]);
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, acc[m], 0, 0, 0);
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, acc[m], 0, 0, 0);
+                    }
+                }
+            }
+            if (lk < 2) {                                 // channels 0..7 only
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int gy = y0 - 1 + prow[m], gx = x0 - 1 + pcol[m];
+                    const bool pin = (gy >= 0) & (gy < h) & (gx >= 0) & (gx < w);
+                    f32x4 vf;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vf[r] = pin ? fmaxf(acc[m][r] + ba[r], 0.0f) : 0.0f;
+                    const bf16x4 vh = __builtin_convertvector(vf, bf16x4);
+                    const bf16x4 vl = __builtin_convertvector(vf - __builtin_convertvector(vh, f32x4), bf16x4);
+                    *reinterpret_cast<bf16x4*>(&mid_h[pmid[m] * 8 + 4 * lk]) = vh;
+                    if (!kHiOnly) *reinterpret_cast<bf16x4*>(&mid_l[pmid[m] * 8 + 4 * lk]) = vl;
+                }
+            }
+        }
+        __syncthreads();                                   // mid complete; the input tile may be overwritten
+
+        // ---- second layer on the 12 x 16 tile: wave wv owns rows 3 wv .. 3 wv + 2 ----
+        f32x4 acc[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s_ = 0; s_ < NKS; ++s_) {
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&lds_b[(512 + (s_ * 2 + 0) * 64 + lane) * 8]);
+            bf16x8 bl = bh;
+            if (!kHiOnly) bl = *reinterpret_cast<const bf16x8*>(&lds_b[(512 + (s_ * 2 + 1) * 64 + lane) * 8]);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&mid_h[koffb[s_] + m * RW * 8]);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, acc[m], 0, 0, 0);
+                if (!kHiOnly) {
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&mid_l[koffb[s_] + m * RW * 8]);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, acc[m], 0, 0, 0);
+                }
+            }
+        }
+        const int x = x0 + li;
+        if (x < w && 4 * lk < a.cout) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                const int y = y0 + 3 * wv + m;
+                if (y >= h) continue;
+                const long pix = (long)y * w + x;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * lk + r < a.cout) a.out[(long)(4 * lk + r) * hw + pix] = fmaxf(acc[m][r] + bb[r], 0.0f);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int EFFI_FN(effi_conv2d_k3_twice_bf16x3_f32)(const float* in, int cin, const void* w1_bf16, const float* bias1,
+                                               const void* w2_bf16, const float* bias2, int cout, int h, int w, float* out,
+                                               effi_stream_t stream) {
+    if (!in || !w1_bf16 || !bias1 || !w2_bf16 || !bias2 || !out || cin < 1 || cout < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    if ((w & 3) || cin > 8 || cout > 16) return EFFI_ERR_UNSUPPORTED;
+    ConvTwiceArgs a;
+    a.src = in; a.cin = cin;
+    a.w_a = reinterpret_cast<const float*>(w1_bf16); a.bias_a = bias1;
+    a.w_b = reinterpret_cast<const float*>(w2_bf16); a.bias_b = bias2;
+    a.cout = cout; a.h = h; a.w = w; a.out = out;
+    a.zeros = effi_zero_page();
+    if (!a.zeros) return EFFI_ERR_WORKSPACE;
+    const int tiles_x = effi_cdiv(w, 16), ntiles = tiles_x * effi_cdiv(h, 12);
+    const int nwg = ntiles < 1024 ? ntiles : 1024;         // 4 persistent workgroups per CU (36 KB of LDS each)
+    hipLaunchKernelGGL(conv2d_k3_twice_oct_kernel, dim3(nwg), dim3(256), 0, effi_s(stream), a, tiles_x, ntiles);
+    return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
 
 extern "C" int EFFI_FN(effi_encoder_tail_bf16x3_f32)(const float* cor1, const float* dfm1, int hd, const void* wc2_bf16, const float* bias_c2,

@@ -8,6 +8,8 @@ there is no eager fallback on this path.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -230,6 +232,7 @@ class P_1to8_FeatureNet_Fast(nn.Module):
         self.out3 = nn.Conv2d(c3, o3, 3, padding=1, bias=False)
         self.out_channels = [c3, c1, c0]
         self._caches = {}
+        self._ones = {}             # constant ones maps (the bias channel of the split last head), per (device, h, w)
 
     # ---- packed weights (BN folded), cached per layer ------------------------------------------------
     def _pk(self, name, conv, bn=None):
@@ -248,6 +251,25 @@ class P_1to8_FeatureNet_Fast(nn.Module):
 
         return cache.get(t, build)
 
+    @staticmethod
+    def _is_k3s1(blk):
+        return blk.conv.kernel_size == (3, 3) and blk.conv.stride == (1, 1) and blk.conv.padding == (1, 1)
+
+    def _pk_oct(self, name, conv, bn):
+        """BatchNorm-folded weights of a one-octet 3x3 layer for ``ops.conv2d_k3_twice``."""
+        cache = self._caches.setdefault(name + ".oct", packing.PackCache())
+        t = [conv.weight, conv.bias] + ([bn.weight, bn.bias, bn.running_mean, bn.running_var] if bn is not None else [])
+
+        def build():
+            w, b = conv.weight, conv.bias
+            if bn is not None:
+                scale, shift = packing.bn_scale_shift(bn)
+                w = w * scale.view(-1, 1, 1, 1)
+                b = shift if b is None else b * scale + shift
+            return packing.pack_conv2d_bf16x3_oct(w, b)
+
+        return cache.get(t, build)
+
     def _block(self, name, blk, x):
         """Conv2d wrapper (conv + BN + ReLU) on the HIP path; 3x3 stride 1 or 5x5 stride 2."""
         w, b = self._pk(name, blk.conv, blk.bn)
@@ -262,8 +284,16 @@ class P_1to8_FeatureNet_Fast(nn.Module):
         """img planar [3,H,W] (H, W multiples of 8, W/2 multiple of 4) -> {stageK: [C,h,w]}."""
         _require_eval(self)
         x = img
-        for i, blk in enumerate(self.conv0):
-            x = self._block(f"conv0.{i}", blk, x)
+        c0 = list(self.conv0)
+        if (ops.uses_split() and len(c0) == 2 and all(self._is_k3s1(b) and b.relu for b in c0) and c0[0].conv.in_channels <= 8
+                and c0[0].conv.out_channels == 8 and c0[1].conv.out_channels <= 16 and img.shape[-1] % 4 == 0
+                and os.environ.get("EFFI_FPN_CONV0_FUSED", "1") != "0"):
+            # the two full-resolution layers in one kernel: their 8-channel intermediate (61 MB at 1184x1600) stays in LDS
+            (w1, b1), (w2, b2) = (self._pk_oct(f"conv0.{i}", b.conv, b.bn) for i, b in enumerate(c0))
+            x = ops.conv2d_k3_twice(x, w1, b1, w2, b2, c0[1].conv.out_channels)
+        else:
+            for i, blk in enumerate(c0):
+                x = self._block(f"conv0.{i}", blk, x)
         levels = []
         for lname in ("conv1", "conv2", "conv3"):
             for i, blk in enumerate(getattr(self, lname)):
@@ -282,6 +312,23 @@ class P_1to8_FeatureNet_Fast(nn.Module):
         w, b = self._pk("inner1", self.inner1)       # lateral 1x1 + nearest-upsampled coarser map, one kernel
         top = ops.conv2d([l2], w, b, self.inner1.out_channels, 1, epilogue=ops.EPI_ADD_UP2, aux0=top)
         out["stage2"] = head("out2", self.out2, top, 3)
+        co3 = self.out3.out_channels
+        if (ops.uses_split() and self.out3.bias is None and self.out3.kernel_size == (3, 3) and co3 <= 16 and l1.shape[0] % 8 == 0
+                and top.shape[0] % 8 == 0 and l1.shape[-1] % 4 == 0 and top.shape[-1] % 4 == 0 and l1.shape[-2] % 2 == 0
+                and os.environ.get("EFFI_FPN_SPLIT_HEAD", "1") != "0"):
+            # the last head without its 64-channel full-resolution input: the upsampled branch is evaluated at half resolution
+            # (4 parity groups of output channels), the lateral branch with out3 o inner2 composed (packing.pack_fpn_head_split)
+            t = [self.out3.weight, self.inner2.weight, self.inner2.bias]
+            (wu, bu), (wl, bl) = self._caches.setdefault("out3.split", packing.PackCache()).get(
+                t, lambda: packing.pack_fpn_head_split(self.out3.weight, self.inner2.weight, self.inner2.bias))
+            ones = self._ones.get((top.device, top.shape[-2], top.shape[-1]))
+            if ones is None:
+                ones = self._ones.setdefault((top.device, top.shape[-2], top.shape[-1]),
+                                             torch.ones(1, top.shape[-2], top.shape[-1], device=top.device, dtype=torch.float32))
+            u = ops.conv2d_k3_bf16x3([top, ones], wu, bu, 4 * co3)
+            o3 = ops.conv2d_k3_bf16x3([l1], wl, bl, co3, epilogue=ops.EPI_NHWC_ADD_SHUF2 if cl else ops.EPI_ADD_SHUF2, aux0=u)
+            out["stage3"] = o3.permute(2, 0, 1) if cl else o3
+            return out
         w, b = self._pk("inner2", self.inner2)
         top = ops.conv2d([l1], w, b, self.inner2.out_channels, 1, epilogue=ops.EPI_ADD_UP2, aux0=top)
         out["stage3"] = head("out3", self.out3, top, 3)

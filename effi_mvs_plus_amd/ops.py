@@ -17,6 +17,7 @@ from ._lib import EffiLibraryError, check
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 EPI_PLAIN, EPI_GRU_ZR, EPI_GRU_Q, EPI_HEAD, EPI_ADD_UP2, EPI_NHWC = 0, 1, 2, 3, 4, 5
+EPI_ADD_SHUF2, EPI_NHWC_ADD_SHUF2 = 9, 10      # split-precision 3x3 entry only: + pixel-shuffled coarser map (aux0 [4*cout,h/2,w/2])
 MAX_VIEWS = 12
 
 
@@ -856,12 +857,16 @@ def conv2d_k3_bf16x3(srcs, wpack, bias, cout, epilogue=EPI_PLAIN, act=ACT_NONE, 
     if out0 is None:
         if epilogue == EPI_GRU_ZR:
             out0 = torch.empty(cout // 2, h, w, device=dev, dtype=torch.float32)
-        elif epilogue == EPI_NHWC:
+        elif epilogue in (EPI_NHWC, EPI_NHWC_ADD_SHUF2):
             out0 = torch.empty(h, w, cout, device=dev, dtype=torch.float32)
         else:
             out0 = torch.empty(cout, h, w, device=dev, dtype=torch.float32)
     if out1 is None and epilogue == EPI_GRU_ZR:
         out1 = torch.empty(cout // 2, h, w, device=dev, dtype=torch.float32)
+    if epilogue in (EPI_ADD_SHUF2, EPI_NHWC_ADD_SHUF2):
+        _t(aux0, "coarser map")
+        if tuple(aux0.shape) != (4 * cout, h // 2, w // 2) or h % 2 or w % 2:
+            raise ValueError("conv2d_k3_bf16x3: the pixel-shuffled map must be [4*cout, h/2, w/2]")
     cin = sum(s.shape[0] for s in srcs)
     work = lambda: {"flops": 2.0 * h * w * cin * cout * 9, "bytes": 4.0 * h * w * (cin + cout)}
     check(_call(f"conv2d_k3x3_nt{(cout + 15) // 16}_epi{epilogue}", work, _x3("effi_conv2d_k3_bf16x3_f32"), _ptr_array(srcs),
@@ -888,6 +893,19 @@ def conv2d_k3_k1_x3(srcs, wpack, bias, cout1, extra, w2pack, bias2, cout2, relu=
     check(_call(f"conv2d_k3k1_nt{(cout1 + 15) // 16}", work, _x3("effi_conv2d_k3_k1_bf16x3_f32"), _ptr_array(srcs),
                 _int_array([s.shape[0] for s in srcs]), len(srcs), _p(wpack), _p(bias), cout1, int(relu1), _p(extra), c_extra,
                 _p(w2pack), _p(bias2), cout2, int(relu), h, w, _p(out), _stream()), "effi_conv2d_k3_k1_bf16x3_f32")
+    return out
+
+
+def conv2d_k3_twice(x, w1, b1, w2, b2, cout, out=None):
+    """relu(conv3x3(relu(conv3x3(x)))) with at most 8 channels into each layer (8 between them) in one kernel, the intermediate map
+    in LDS (``packing.pack_conv2d_bf16x3_oct`` weights): the pyramid's full-resolution block.  x [cin<=8,h,w] -> [cout<=16,h,w]."""
+    _t(x, "conv input")
+    cin, h, w = x.shape
+    if out is None:
+        out = torch.empty(cout, h, w, device=x.device, dtype=torch.float32)
+    work = lambda: {"flops": 2.0 * h * w * 9 * (cin * 8 + 8 * cout), "bytes": 4.0 * h * w * (cin + cout)}
+    check(_call("conv2d_k3_twice", work, _x3("effi_conv2d_k3_twice_bf16x3_f32"), _p(x), cin, _p(w1), _p(b1), _p(w2), _p(b2), cout, h, w,
+                _p(out), _stream()), "effi_conv2d_k3_twice_bf16x3_f32")
     return out
 
 

@@ -212,6 +212,24 @@ def pack_conv2d_bf16x3(weight, bias, scale=1.0):
     return wp, b
 
 
+def pack_conv2d_bf16x3_oct(weight, bias, scale=1.0):
+    """[cout <= 16, cin <= 8, 3, 3] (+bias) for the one-octet layers of ``effi_conv2d_k3_twice_bf16x3_f32``: K index = tap (one octet of
+    channels), K-step s takes taps 4s..4s+3; lane = q*16 + j holds W[j][e][tap = 4s + q] (zero for taps 9..11, e >= cin, j >= cout).
+    -> (bf16 [3, 2(hi|lo), 64, 8], bias fp32 [16])."""
+    cout, cin, ks, _ = weight.shape
+    assert ks == 3 and cout <= 16 and cin <= 8
+    w = torch.zeros(16, 8, 12, device=weight.device, dtype=torch.float32)       # [j, e, tap]
+    w[:cout, :cin, :9] = weight.reshape(cout, cin, 9).float() * scale
+    w = w.view(16, 8, 3, 4).permute(2, 3, 0, 1).contiguous()                    # [s, q, j, e]
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    wp = torch.stack([hi, lo], dim=1).contiguous().view(3, 2, 64, 8)
+    b = torch.zeros(16, device=weight.device, dtype=torch.float32)
+    if bias is not None:
+        b[:cout] = bias.float() * scale
+    return wp, b
+
+
 def pack_conv1x1_after(weight, bias, cout1, c_extra, scale=1.0):
     """1x1 conv [cout2, cout1 + c_extra, 1, 1] applied inside the epilogue of a 3x3 split-precision conv with cout1 outputs
     (``effi_conv2d_k3_k1_bf16x3_f32``): A fragments of v_mfma_f32_16x16x16_bf16 per (output tile t, input tile n):
@@ -234,6 +252,38 @@ def pack_conv1x1_after(weight, bias, cout1, c_extra, scale=1.0):
     if bias is not None:
         b[:cout2] = bias.float() * scale
     return wp, b
+
+
+def pack_fpn_head_split(w_out, w_inner, b_inner):
+    """Last head of the feature pyramid without its widest map (models/module.py:407-408):
+        out3 = conv3x3_W(up2(top) + inner(l1)),   inner = 1x1 (W_in, b_in),   up2 = nearest x2,   W = ``w_out`` [Co, F, 3, 3], no bias.
+    By linearity out3 = L + shuffle(U) with
+      * L = conv3x3 over l1 with the composed weights  Wc[co, c, t] = sum_f W[co, f, t] W_in[f, c]   (full resolution, Ci -> Co);
+      * U = conv3x3 over cat(top, ones) at HALF resolution with 4 Co outputs, channel (2 py + px) Co + co = output parity (py, px):
+        a 3x3 window on the nearest-upsampled map touches 2x2 coarse pixels per parity, so the taps of W that land on the same
+        coarse pixel are summed (py = 0: rows {-1} <- t0, {0} <- t1 + t2;  py = 1: {0} <- t0 + t1, {+1} <- t2; columns alike).
+        The ones channel carries inner's bias: sum_f W[co, f, t] b_in[f] per tap, merged the same way -- zero padding of the
+        coarse conv then reproduces exactly the taps that fall outside the map at full resolution.
+    The F-channel full-resolution map (121 MB at 592x800) is neither written nor read.  Composition in fp64, result fp32.
+    -> ((wU bf16x3 pack, bias), (wL bf16x3 pack, bias))"""
+    co, f = w_out.shape[0], w_out.shape[1]
+    ci = w_inner.shape[1]
+    W = w_out.double()
+    Win = w_inner.reshape(f, ci).double()
+    wl = torch.einsum("oftu,fc->octu", W, Win)                                  # [Co, Ci, 3, 3]
+    wb = torch.einsum("oftu,f->otu", W, b_inner.double()).unsqueeze(1)           # [Co, 1, 3, 3]: the bias as a ones channel
+    wcat = torch.cat([W, wb], dim=1)                                            # [Co, F + 1, 3, 3] acting on up2(cat(top, ones))
+    rows = {0: ((0,), (1, 2), ()), 1: ((), (0, 1), (2,))}                       # parity -> fine taps merged into coarse tap -1, 0, +1
+    wu = torch.zeros(4 * co, f + 1, 3, 3, dtype=torch.float64, device=w_out.device)
+    for py in (0, 1):
+        for px in (0, 1):
+            blk = wu[(2 * py + px) * co:(2 * py + px + 1) * co]
+            for dy in range(3):
+                for dx in range(3):
+                    for ty in rows[py][dy]:
+                        for tx in rows[px][dx]:
+                            blk[:, :, dy, dx] += wcat[:, :, ty, tx]
+    return pack_conv2d_bf16x3(wu.float(), None), pack_conv2d_bf16x3(wl.float(), None)
 
 
 def pack_mask_taps_per_lane(weight, bias, cout1, scale=1.0):

@@ -42,6 +42,9 @@ typedef void* effi_stream_t;
 #define EFFI_EPI_GRU_Q   2   /* q = tanh(.);  out0 = (1 - aux1) * aux0 + aux1 * q   (aux0 = h, aux1 = z) */
 #define EFFI_EPI_HEAD    3   /* 1 channel: out0 = aux0 + tanh(.) (inverse depth);  out1 = 1/clamp(lo+(hi-lo)*out0, 1e-4) */
 #define EFFI_EPI_NHWC    5   /* out0 = act(conv + bias) written channel-last [h][w][cout] (what the warp kernels read) */
+#define EFFI_EPI_ADD_SHUF2 9        /* out0 = conv + bias + pixel_shuffle(aux0): aux0 planar [4*cout][h/2][w/2], channel
+                                      ((y&1)*2 + (x&1))*cout + co at (y>>1, x>>1); split-precision 3x3 entry only, cout <= 32 */
+#define EFFI_EPI_NHWC_ADD_SHUF2 10  /* the same, written channel-last [h][w][cout] */
 #define EFFI_EPI_ADD_UP2 4   /* out0 = act(conv + bias) + nearest_upsample_x2(aux0), aux0 planar [cout][h/2][w/2]
                               * (feature pyramid top-down path, models/module.py:403,407) */
 
@@ -161,6 +164,12 @@ int effi_conv2d_k3_bf16x3_pair_f32(const float* const* srcs_a, const int* src_ch
                                    const float* bias_a, float* out_a, const float* const* srcs_b,
                                    const int* src_channels_b, int n_src_b, const void* wpack_b, const float* bias_b,
                                    float* out_b, int cout, int h, int w, int act, effi_stream_t stream);
+/* Two chained 3x3 convolutions with ReLU after each, at most 8 channels into each (the pyramid's full-resolution block conv0 =
+ * Conv2d(3, 8) -> Conv2d(8, 8) with BatchNorm folded, models/module.py:353-356), in one kernel: the 8-channel intermediate map
+ * stays in LDS (first layer computed on each 12 x 16 tile grown by one pixel).  in [cin][h][w], cin <= 8; the first layer has 8
+ * outputs; out [cout][h][w], cout <= 16; w1 / w2 as packing.pack_conv2d_bf16x3_oct, biases padded to 16; w % 4 == 0. */
+int effi_conv2d_k3_twice_bf16x3_f32(const float* in, int cin, const void* w1_bf16, const float* bias1, const void* w2_bf16,
+                                    const float* bias2, int cout, int h, int w, float* out, effi_stream_t stream);
 /* Tail of the update block's encoder in one kernel (models/update.py:87-96): cor = relu(convc2(cor1)), dfm = relu(convd2(dfm1)),
  * out = relu(convc(cat(convd(cat(cor, dfm)), extra))) with extra = the context map -- the launches
  * effi_conv2d_k3_bf16x3_pair_f32 + effi_conv2d_k3_k1_bf16x3_f32 with the two intermediate maps kept in LDS (12 x 16 output tiles,
@@ -495,6 +504,8 @@ int effi_conv2d_k3_k1_bf16x3_f32_bf16(const float* const* srcs, const int* src_c
                                  const float* bias, int cout1, int relu1, const float* extra, int c_extra,
                                  const void* w2pack_bf16, const float* bias2, int cout2, int relu, int h, int w, float* out,
                                  effi_stream_t stream);
+int effi_conv2d_k3_twice_bf16x3_f32_bf16(const float* in, int cin, const void* w1_bf16, const float* bias1, const void* w2_bf16,
+                                    const float* bias2, int cout, int h, int w, float* out, effi_stream_t stream);
 int effi_encoder_tail_bf16x3_f32_bf16(const float* cor1, const float* dfm1, int hd, const void* wc2_bf16, const float* bias_c2,
                                  const void* wd2_bf16, const float* bias_d2, const void* wd_bf16, const float* bias_d, int cmix,
                                  const float* extra, int c_extra, const void* w2pack_bf16, const float* bias2, int cout2, int h,

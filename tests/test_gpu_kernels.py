@@ -870,6 +870,63 @@ def test_encoder_tail_equals_the_two_launches(h, w, cd):
     check_close(f"encoder tail vs torch {h}x{w} cd={cd}", got, ref, **conv_tol("split", ref, 1e-4, 2e-5, 3))
 
 
+@pytest.mark.parametrize("h2,w2", [(6, 8), (37, 52), (74, 100)])
+@pytest.mark.parametrize("co,f,ci", [(8, 64, 16), (16, 32, 8)])
+@pytest.mark.parametrize("nhwc", [False, True])
+def test_fpn_last_head_split_by_linearity(h2, w2, co, f, ci, nhwc):
+    """packing.pack_fpn_head_split + the pixel-shuffle-add epilogues: conv3x3(up2(top) + inner(l1)) evaluated as a half-resolution
+    conv with four parity groups plus a composed full-resolution conv, against torch on the CPU (borders included: the bias of the
+    lateral 1x1 must vanish exactly where the 3x3 window leaves the map)."""
+    from effi_mvs_plus_amd import ops, packing
+    g = torch.Generator().manual_seed(h2 * 13 + co)
+    top = torch.randn(f, h2, w2, generator=g)
+    l1 = torch.randn(ci, 2 * h2, 2 * w2, generator=g)
+    w_out = torch.randn(co, f, 3, 3, generator=g) * 0.05
+    w_in, b_in = torch.randn(f, ci, 1, 1, generator=g) * 0.2, torch.randn(f, generator=g)
+    want = F.conv2d(F.interpolate(top[None], scale_factor=2, mode="nearest") + F.conv2d(l1[None], w_in, b_in), w_out, padding=1)[0]
+    (wu, bu), (wl, bl) = packing.pack_fpn_head_split(w_out.to(DEV), w_in.to(DEV), b_in.to(DEV))
+    before = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        ones = torch.ones(1, h2, w2, device=DEV)
+        u = ops.conv2d_k3_bf16x3([t(top, DEV), ones], wu, bu, 4 * co)
+        got = ops.conv2d_k3_bf16x3([t(l1, DEV)], wl, bl, co, epilogue=ops.EPI_NHWC_ADD_SHUF2 if nhwc else ops.EPI_ADD_SHUF2, aux0=u)
+    finally:
+        ops.set_precision(before)
+    if nhwc:
+        got = got.permute(2, 0, 1)
+    check_close(f"split FPN head co={co} f={f} {2 * h2}x{2 * w2} nhwc={nhwc}", got, want, **conv_tol("split", want, 1e-4, 2e-5, 2))
+
+
+@pytest.mark.parametrize("h,w", [(12, 16), (37, 52), (96, 128), (50, 520)])
+@pytest.mark.parametrize("cin,cout", [(3, 8), (8, 8), (5, 16)])
+def test_conv3x3_twice_in_one_kernel(h, w, cin, cout):
+    """effi_conv2d_k3_twice_bf16x3_f32 (two one-octet 3x3 layers + ReLU, the intermediate map in LDS) against torch on the CPU and
+    against two single-layer launches (same operands and products, another grouping of the K index: rounding-level differences);
+    tiles cut by the border, maps smaller than a tile."""
+    from effi_mvs_plus_amd import ops, packing
+    g = torch.Generator().manual_seed(h * 7 + cin)
+    x = torch.randn(cin, h, w, generator=g)
+    w1, b1 = torch.randn(8, cin, 3, 3, generator=g) * 0.3, torch.randn(8, generator=g) * 0.1
+    w2, b2 = torch.randn(cout, 8, 3, 3, generator=g) * 0.2, torch.randn(cout, generator=g) * 0.1
+    want = F.relu(F.conv2d(F.relu(F.conv2d(x[None], w1, b1, padding=1)), w2, b2, padding=1))[0]
+    d = lambda v: t(v, DEV)  # noqa: E731
+    p1, pb1 = packing.pack_conv2d_bf16x3_oct(d(w1), d(b1))
+    p2, pb2 = packing.pack_conv2d_bf16x3_oct(d(w2), d(b2))
+    q1, qb1 = packing.pack_conv2d_bf16x3(d(w1), d(b1))
+    q2, qb2 = packing.pack_conv2d_bf16x3(d(w2), d(b2))
+    before = ops.get_precision()
+    ops.set_precision("split")
+    try:
+        got = ops.conv2d_k3_twice(d(x), p1, pb1, p2, pb2, cout)
+        mid = ops.conv2d_k3_bf16x3([d(x)], q1, qb1, 8, act=ops.ACT_RELU)
+        two = ops.conv2d_k3_bf16x3([mid], q2, qb2, cout, act=ops.ACT_RELU)
+    finally:
+        ops.set_precision(before)
+    check_close(f"3x3 twice vs torch {cin}->8->{cout} {h}x{w}", got, want, **conv_tol("split", want, 1e-4, 2e-5, 2))
+    check_close(f"3x3 twice vs two launches {cin}->8->{cout} {h}x{w}", got, two.cpu(), rtol=0.0, atol=2e-5 * float(want.abs().max()))
+
+
 def test_cpu_tensor_fails_loudly():
     from effi_mvs_plus_amd import ops
     from effi_mvs_plus_amd._lib import EffiLibraryError
