@@ -899,7 +899,7 @@ def test_fpn_last_head_split_by_linearity(h2, w2, co, f, ci, nhwc):
 
 
 @pytest.mark.parametrize("h,w", [(12, 16), (37, 52), (96, 128), (50, 520)])
-@pytest.mark.parametrize("cin,cout", [(3, 8), (8, 8), (5, 16)])
+@pytest.mark.parametrize("cin,cout", [(3, 8), (8, 8), (5, 16), (3, 4)])
 def test_conv3x3_twice_in_one_kernel(h, w, cin, cout):
     """effi_conv2d_k3_twice_bf16x3_f32 (two one-octet 3x3 layers + ReLU, the intermediate map in LDS) against torch on the CPU and
     against two single-layer launches (same operands and products, another grouping of the K index: rounding-level differences);
@@ -907,8 +907,9 @@ def test_conv3x3_twice_in_one_kernel(h, w, cin, cout):
     from effi_mvs_plus_amd import ops, packing
     g = torch.Generator().manual_seed(h * 7 + cin)
     x = torch.randn(cin, h, w, generator=g)
-    w1, b1 = torch.randn(8, cin, 3, 3, generator=g) * 0.3, torch.randn(8, generator=g) * 0.1
-    w2, b2 = torch.randn(cout, 8, 3, 3, generator=g) * 0.2, torch.randn(cout, generator=g) * 0.1
+    cmid = 4 if cout == 4 else 8                       # the context pyramid's block is 3 -> 4 -> 4
+    w1, b1 = torch.randn(cmid, cin, 3, 3, generator=g) * 0.3, torch.randn(cmid, generator=g) * 0.1
+    w2, b2 = torch.randn(cout, cmid, 3, 3, generator=g) * 0.2, torch.randn(cout, generator=g) * 0.1
     want = F.relu(F.conv2d(F.relu(F.conv2d(x[None], w1, b1, padding=1)), w2, b2, padding=1))[0]
     d = lambda v: t(v, DEV)  # noqa: E731
     p1, pb1 = packing.pack_conv2d_bf16x3_oct(d(w1), d(b1))
@@ -919,12 +920,12 @@ def test_conv3x3_twice_in_one_kernel(h, w, cin, cout):
     ops.set_precision("split")
     try:
         got = ops.conv2d_k3_twice(d(x), p1, pb1, p2, pb2, cout)
-        mid = ops.conv2d_k3_bf16x3([d(x)], q1, qb1, 8, act=ops.ACT_RELU)
+        mid = ops.conv2d_k3_bf16x3([d(x)], q1, qb1, cmid, act=ops.ACT_RELU)
         two = ops.conv2d_k3_bf16x3([mid], q2, qb2, cout, act=ops.ACT_RELU)
     finally:
         ops.set_precision(before)
-    check_close(f"3x3 twice vs torch {cin}->8->{cout} {h}x{w}", got, want, **conv_tol("split", want, 1e-4, 2e-5, 2))
-    check_close(f"3x3 twice vs two launches {cin}->8->{cout} {h}x{w}", got, two.cpu(), rtol=0.0, atol=2e-5 * float(want.abs().max()))
+    check_close(f"3x3 twice vs torch {cin}->{cmid}->{cout} {h}x{w}", got, want, **conv_tol("split", want, 1e-4, 2e-5, 2))
+    check_close(f"3x3 twice vs two launches {cin}->{cmid}->{cout} {h}x{w}", got, two.cpu(), rtol=0.0, atol=2e-5 * float(want.abs().max()))
 
 
 def test_cpu_tensor_fails_loudly():
