@@ -1381,6 +1381,160 @@ __device__ __forceinline__ void conv3d_roll_bf16x3_body(const Conv2dArgs a, int 
     }
 }
 
+// cout <= 8: the upper half of the 16-row MFMA tile would multiply zero weights.  ROW-PAIR form: rows 0-7 of the tile are the output
+// channels of image row y, rows 8-15 the same channels of row y + 1, and the K index runs over the 4 x 3 window of taps both rows see:
+// K = (dz, dy in 0..3, dx, octet), 36 NOCT items = 9 NOCT K-steps for TWO rows instead of 2 x 7 NOCT (the weights of row y are
+// zero at dy = 3, those of row y + 1 at dy = 0; packing.pack_conv3d_roll_bf16x3 emits this operand when cout <= 8): 36 % fewer
+// MFMAs and A-fragment reads.  The B operand is 9 NOCT x 2 KB, so with 16 input channels the plane slots are stored 20 pixels wide
+// (columns x0 - 2 .. x0 + 17 of the 24 fetched) to keep two workgroups per CU.
+template <int NOCT, int MR>
+__device__ __forceinline__ void conv3d_roll_rp_bf16x3_body(const Conv2dArgs a, int tiles_x, int ntiles, int zt) {
+    static_assert(MR % 2 == 0, "rows go in pairs");
+    constexpr int TR = 4 * MR, AR = TR + 2, AW = (NOCT == 2) ? 20 : 24, AQ = 6, XOFF = (NOCT == 2) ? 1 : 3, XLEFT = 4;
+    constexpr int CSH = (NOCT == 2) ? 2 : 0;                           // columns dropped on the left of the fetched 24
+    constexpr int APIX = AR * AW, NQ = AR * AQ, NITEMS = NQ * NOCT;
+    constexpr int NIT = 36 * NOCT, NKS = NIT / 4;
+    constexpr int NBF = NKS * 2 * 64;                                  // 16-byte units of B (one N-tile)
+    constexpr int SLOT = NOCT * APIX * 8;                              // bf16 elements per plane slot
+    constexpr int MP = MR / 2;
+    static_assert(NITEMS <= 256, "one staging item per thread");
+    __shared__ __attribute__((aligned(16))) unsigned short lds_ah[3 * SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned short lds_al[3 * SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned short lds_b[NBF * 8];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int h = a.h, w = a.w, D = a.zcount;
+    const long hw = (long)h * w;
+    const int tile = effi_xcd_remap(blockIdx.x, gridDim.x);
+    if (tile >= ntiles) return;
+    const int ty_ = tile / tiles_x;
+    const int x0 = (tile - ty_ * tiles_x) * 16, y0 = ty_ * TR;
+    const int z0 = blockIdx.y * zt, z1 = min(z0 + zt, D);
+
+    const bool stager = tid < NITEMS;
+    const int pq = stager ? tid % NQ : 0, soct = stager ? tid / NQ : 0;
+    const int srow = pq / AQ, sqx = pq - srow * AQ;
+    const int sgy = y0 - 1 + srow, sgx = x0 - XLEFT + 4 * sqx;
+    const int s_off = (stager & (sgy >= 0) & (sgy < h) & (sgx >= 0) & (sgx < w)) ? sgy * w + sgx : -1;
+    const int s_col = 4 * sqx - CSH;                                   // slot column of the quad's first pixel (may be -2 / 18)
+    const int s_lds = (soct * APIX + srow * AW + s_col) * 8;
+    const float* s_src = (soct * 8 < a.ch[0]) ? a.src[0] + (long)(soct * 8) * a.cstride
+                                              : a.src[1] + (long)(soct * 8 - a.ch[0]) * a.cstride;
+
+    f32x4 pa[2][8];
+    auto prefetch = [&](auto buf_t, int z) {
+        constexpr int bf = decltype(buf_t)::value;
+        const bool ok = (s_off >= 0) & (z >= 0) & (z < D);
+        const float* base = ok ? s_src + ((long)z * hw + s_off) : a.zeros;
+        const long step = ok ? a.cstride : 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pa[bf][e] = *reinterpret_cast<const f32x4*>(base + (long)e * step);
+    };
+    auto stash = [&](auto buf_t, int slot) {
+        constexpr int bf = decltype(buf_t)::value;
+        if (stager) {
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                if (CSH && (s_col + px < 0 || s_col + px >= AW)) continue;     // columns outside the 20 kept
+                bf16x8 hi, lo;
+                split_octet(pa[bf], px, hi, lo);
+                *reinterpret_cast<bf16x8*>(&lds_ah[slot * SLOT + s_lds + px * 8]) = hi;
+                if (!kHiOnly) *reinterpret_cast<bf16x8*>(&lds_al[slot * SLOT + s_lds + px * 8]) = lo;
+            }
+        }
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    {
+        const unsigned short* wbf = reinterpret_cast<const unsigned short*>(a.wpack);
+        for (int u = tid; u < NBF; u += 256)
+            *reinterpret_cast<float4*>(&lds_b[u * 8]) = *reinterpret_cast<const float4*>(wbf + (long)u * 8);
+    }
+    // item 4 s + lk = (dz, dy, dx, oct): element offset inside a slot, dz in the low bits
+    int kconst[NKS];
+#pragma unroll
+    for (int s_ = 0; s_ < NKS; ++s_) {
+        const int item = 4 * s_ + lk;
+        const int oct = item % NOCT, dt = item / NOCT;
+        const int dz = dt / 12, rem = dt - dz * 12;
+        kconst[s_] = ((oct * APIX + (rem / 3) * AW + rem % 3) * 8) * 4 + dz;
+    }
+    const int lane_base = ((wv * MR) * AW + li + XOFF) * 8;
+
+    f32x4 acc[MP];
+    prefetch(B0{}, z0 - 1);
+    prefetch(B1{}, z0);
+    stash(B0{}, 0);
+    prefetch(B0{}, z0 + 1);
+    stash(B1{}, 1);
+    prefetch(B1{}, z0 + 2);
+    int rot = 0;
+    auto plane = [&](auto bt, int z) {
+        int s2 = rot + 2;
+        s2 -= (s2 >= 3) ? 3 : 0;
+        stash(bt, s2);
+        __syncthreads();
+        if (z + 2 < z1) prefetch(bt, z + 3);
+        int s1 = rot + 1;
+        s1 -= (s1 >= 3) ? 3 : 0;
+        const int rb0 = rot * SLOT, rb1 = s1 * SLOT, rb2 = s2 * SLOT;
+#pragma unroll
+        for (int m = 0; m < MP; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s_ = 0; s_ < NKS; ++s_) {
+            const int dz = kconst[s_] & 3;
+            const int off = lane_base + (kconst[s_] >> 2) + (dz == 0 ? rb0 : (dz == 1 ? rb1 : rb2));
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&lds_b[((s_ * 2 + 0) * 64 + lane) * 8]);
+            bf16x8 bl = bh;
+            if (!kHiOnly) bl = *reinterpret_cast<const bf16x8*>(&lds_b[((s_ * 2 + 1) * 64 + lane) * 8]);
+#pragma unroll
+            for (int m = 0; m < MP; ++m) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&lds_ah[off + m * 2 * AW * 8]);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, acc[m], 0, 0, 0);
+                if (!kHiOnly) {
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&lds_al[off + m * 2 * AW * 8]);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, acc[m], 0, 0, 0);
+                }
+            }
+        }
+        // lane (li, lk): lk < 2 -> row y, channels 4 lk ..; lk >= 2 -> row y + 1, channels 4 (lk - 2) ..
+        const int x = x0 + li;
+#pragma unroll
+        for (int m = 0; m < MP; ++m) {
+            const int y = y0 + wv * MR + 2 * m + (lk >> 1);
+            if (y >= h || x >= w) continue;
+            conv_epilogue_store_t<EFFI_EPI_PLAIN>(a, acc[m], 4 * (lk & 1), (long)y * w + x, hw, z);
+        }
+        __syncthreads();
+        rot = s1;
+    };
+    for (int z = z0; z < z1; z += 2) {
+        plane(B0{}, z);
+        if (z + 1 < z1) plane(B1{}, z + 1);
+    }
+}
+
+template <int NOCT, int MR>
+__global__ __launch_bounds__(256) void conv3d_roll_rp_bf16x3_kernel(const Conv2dArgs a, int tiles_x, int ntiles, int zt) {
+    conv3d_roll_rp_bf16x3_body<NOCT, MR>(a, tiles_x, ntiles, zt);
+}
+
+template <int NOCT, int MR>
+__global__ __launch_bounds__(256) void conv3d_roll_rp_bf16x3_pair_kernel(const Conv2dArgs a, const Conv2dArgs b, int tiles_x, int ntiles,
+                                                                         int zt) {
+    Conv2dArgs c = a;
+    if (blockIdx.z) {
+#pragma unroll
+        for (int i = 0; i < EFFI_MAX_SRC; ++i) c.src[i] = b.src[i];
+        c.wpack = b.wpack;
+        c.bias = b.bias;
+        c.out0 = b.out0;
+    }
+    conv3d_roll_rp_bf16x3_body<NOCT, MR>(c, tiles_x, ntiles, zt);
+}
+
 template <int NOCT, int NT, int MR>
 __global__ __launch_bounds__(256) void conv3d_roll_bf16x3_kernel(const Conv2dArgs a, int tiles_x, int ntiles, int zt) {
     conv3d_roll_bf16x3_body<NOCT, NT, MR>(a, tiles_x, ntiles, zt);
@@ -2598,6 +2752,16 @@ static int launch_roll(const Conv2dArgs& a, hipStream_t st, const Conv2dArgs* pa
     if (fz) zt = atoi(fz);
     const long tiles = (long)cols * effi_cdiv(a.h, 4 * mr);
     const dim3 grid((unsigned)tiles, (unsigned)effi_cdiv(D, zt), pair ? 2 : 1);
+    if (NT == 1 && a.cout <= 8) {              // row-pair operand (see conv3d_roll_rp_bf16x3_body)
+        if (pair) {
+            if (mr == 4) hipLaunchKernelGGL((conv3d_roll_rp_bf16x3_pair_kernel<NOCT, 4>), grid, dim3(256), 0, st, a, *pair, cols, (int)tiles, zt);
+            else hipLaunchKernelGGL((conv3d_roll_rp_bf16x3_pair_kernel<NOCT, 2>), grid, dim3(256), 0, st, a, *pair, cols, (int)tiles, zt);
+        } else {
+            if (mr == 4) hipLaunchKernelGGL((conv3d_roll_rp_bf16x3_kernel<NOCT, 4>), grid, dim3(256), 0, st, a, cols, (int)tiles, zt);
+            else hipLaunchKernelGGL((conv3d_roll_rp_bf16x3_kernel<NOCT, 2>), grid, dim3(256), 0, st, a, cols, (int)tiles, zt);
+        }
+        return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+    }
     if (pair) {
         if (mr == 4) hipLaunchKernelGGL((conv3d_roll_bf16x3_pair_kernel<NOCT, NT, 4>), grid, dim3(256), 0, st, a, *pair, cols, (int)tiles, zt);
         else hipLaunchKernelGGL((conv3d_roll_bf16x3_pair_kernel<NOCT, NT, 2>), grid, dim3(256), 0, st, a, *pair, cols, (int)tiles, zt);

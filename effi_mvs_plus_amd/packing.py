@@ -89,6 +89,8 @@ def pack_conv3d_roll_bf16x3(conv, bn):
         bias = shift if bias is None else bias * scale + shift
     cout, cin = w.shape[0], w.shape[1]
     assert cin in (8, 16)
+    if cout <= 8:
+        return _pack_conv3d_roll_rowpair(w, bias)
     noct, nt = cin // 8, (cout + 15) // 16
     nit = 27 * noct
     nks = (nit + 3) // 4
@@ -100,6 +102,29 @@ def pack_conv3d_roll_bf16x3(conv, bn):
     lo = (wz - hi.float()).to(torch.bfloat16)
     wp = torch.stack([hi, lo], dim=2).contiguous().view(nks, nt, 2, 64, 8)
     b = torch.zeros(nt * 16, device=w.device, dtype=torch.float32)
+    if bias is not None:
+        b[:cout] = bias.float()
+    return wp, b
+
+
+def _pack_conv3d_roll_rowpair(w, bias):
+    """cout <= 8: the ROW-PAIR operand of the rolling-window kernel (csrc/conv2d.hip, conv3d_roll_rp_bf16x3_body): MFMA rows 0-7 are
+    the output channels of image row y, rows 8-15 the same channels of row y + 1; K index = (kd, dy in 0..3, kx, octet, e) over the
+    4 x 3 window both rows see: W[j][c][kd][dy][kx] for rows j < 8 (zero at dy = 3), W[j - 8][c][kd][dy - 1][kx] for rows j >= 8
+    (zero at dy = 0).  -> (bf16 [9 * cin / 8, 1, 2, 64, 8], bias fp32 [16])."""
+    cout, cin = w.shape[0], w.shape[1]
+    noct = cin // 8
+    nks = 9 * noct
+    wf = w.float().reshape(cout, noct, 8, 3, 3, 3)                                       # [co, oct, e, kd, ky, kx]
+    wz = torch.zeros(16, 3, 4, 3, noct, 8, device=w.device, dtype=torch.float32)         # [row, kd, dy, kx, oct, e]
+    src = wf.permute(0, 3, 4, 5, 1, 2)                                                   # [co, kd, ky, kx, oct, e]
+    wz[:cout, :, 0:3] = src
+    wz[8:8 + cout, :, 1:4] = src
+    wz = wz.reshape(16, nks, 4, 8).permute(1, 2, 0, 3).contiguous()                      # [s, q, j, e]
+    hi = wz.to(torch.bfloat16)
+    lo = (wz - hi.float()).to(torch.bfloat16)
+    wp = torch.stack([hi, lo], dim=1).contiguous().view(nks, 1, 2, 64, 8)
+    b = torch.zeros(16, device=w.device, dtype=torch.float32)
     if bias is not None:
         b[:cout] = bias.float()
     return wp, b

@@ -200,7 +200,10 @@ int effi_conv3d_k3s1_bf16x3_f32(const float* const* srcs, const int* src_channel
 /* Same operator for cin in {8, 16} (one or two sources, the first with a multiple of 8 channels), cout <= 32, w % 4 == 0,
  * with a rolling window of input planes: a workgroup walks a run of output planes and fetches each input plane once
  * instead of three times.  wpack_bf16 = [ceil(27*cin/32)][ceil(cout/16)][hi|lo][64][8] bf16 with K index
- * ((kd*9 + ky*3 + kx) * cin/8 + ci/8) * 8 + ci%8 (packing.pack_conv3d_roll_bf16x3); bias [16*ceil(cout/16)]. */
+ * ((kd*9 + ky*3 + kx) * cin/8 + ci/8) * 8 + ci%8 (packing.pack_conv3d_roll_bf16x3); bias [16*ceil(cout/16)].
+ * cout <= 8 takes the ROW-PAIR operand instead (the same packing function emits it): [9*cin/8][1][hi|lo][64][8] with K index
+ * (((kd*4 + dy)*3 + kx) * cin/8 + ci/8) * 8 + ci%8 over a 4 x 3 window of taps, MFMA rows 0-7 = W[co][ci][kd][dy][kx] (zero at dy = 3)
+ * for image row y, rows 8-15 = W[co][ci][kd][dy-1][kx] (zero at dy = 0) for row y + 1: two output rows per tile, 36 % fewer MFMAs. */
 int effi_conv3d_k3s1_roll_bf16x3_f32(const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
                                      const float* bias, int cout, int D, int h, int w, int relu, float* out,
                                      effi_stream_t stream);
