@@ -76,10 +76,11 @@ def main():
                          "and replays it (one launch); eager: ~100 launches enqueued from Python (about as long on the host as on the GPU)")
     ap.add_argument("--pipelined", type=int, default=3,
                     help="secondary measurement: throughput with this many independent views in flight (0/1 = skip)")
-    ap.add_argument("--in-flight", type=int, default=1,
-                    help="graph launch only: reference views in flight at once, each on its own stream and input slot (throughput "
-                         "metric: while one view is in its low-resolution stages, which cannot fill 256 CUs, the other uses them); "
-                         "1 = strictly one view after the other")
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="graph launch only: reference views in flight at once, each on its own stream and input slot, its graph "
+                         "captured with the pass's two internal streams (throughput metric: while one view is in its low-resolution "
+                         "stages, which cannot fill 256 CUs, the others use them); 1 = strictly one view after the other on a linear "
+                         "graph.  With more than one the single-stream figure is measured right after and reported as 'single_stream'")
     ap.add_argument("--no-other-precision", action="store_true", help="skip the secondary run in the other conv arithmetic (profiling runs)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1: nccl (= RCCL over xGMI, the real path) or gloo (rehearsal of the "
@@ -142,12 +143,15 @@ def main():
 
     graphed = None
     graph_fallback = None
+    graph_branches = False
     if args.launch == "graph":
         from effi_mvs_plus_amd.graph import HotPathGraph
         # double-buffered input slots (as a producer of features would fill them); the two synthetic views are loaded
         # into the slots before the timed region -- "inputs resident in HBM" -- and a step replays the slot's graph
         n_slots = max(n_scenes, args.in_flight)
         try:
+            if args.in_flight > 1:                # each view's graph keeps the pass's side stream: more to overlap across views
+                ops.set_branches(True)
             graphed = HotPathGraph(net, *inputs[0], slots=n_slots)
             for i in range(n_slots):
                 graphed.load(i, *inputs[i % n_scenes])
@@ -158,6 +162,9 @@ def main():
             graphed = None
             graph_fallback = f"{type(exc).__name__}: {exc}"
             torch.cuda.synchronize()
+        finally:
+            graph_branches = ops.get_branches()
+            ops.set_branches(False)               # everything eager below (discovery, per-kernel events, stage marks) is single-stream
         lanes = [torch.cuda.Stream() for _ in range(max(1, args.in_flight))]
 
     def step(i):
@@ -233,6 +240,31 @@ def main():
             ops.set_profile(None)
             ops.set_branches(br)
             torch.cuda.synchronize()
+        # the same K steps strictly one view after the other (a view's latency): linear graphs, one stream, outputs cloned per step
+        single_stream = None
+        if graphed is not None and args.in_flight > 1 and rank == 0:
+            from effi_mvs_plus_amd.graph import HotPathGraph
+            try:
+                sg = HotPathGraph(net, *inputs[0], slots=n_scenes)
+                for i in range(n_scenes):
+                    sg.load(i, *inputs[i % n_scenes])
+                for i in range(n_scenes):
+                    sg.replay(i)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(args.steps):
+                    o = sg.replay(i % n_scenes)
+                    keep = (o["depth"][-1].clone(), o["photometric_confidence"].clone())
+                torch.cuda.synchronize()
+                ds = time.perf_counter() - t1
+                same = all(bool(torch.equal(a_, b_)) for a_, b_ in zip(sg.replay(0)["depth"], graphed.replay(0)["depth"]))
+                single_stream = {"value": args.steps / ds, "unit": "views/s", "ms_per_view": ds / args.steps * 1e3, "steps": args.steps,
+                                 "bitwise_equal_to_the_in_flight_graphs": same,
+                                 "note": "one view after the other: linear hipGraph replay on one stream (a view's latency; rank 0)"}
+                del sg, keep
+            except Exception as exc:
+                single_stream = {"error": f"{type(exc).__name__}: {exc}"}
+            torch.cuda.empty_cache()
     # ms per cost-volume stage (the second half of BASELINE.json's metric): HIP events at the stage boundaries of eager
     # single-stream passes (stage k = its cost volume + regularisation / cross-scale blocks + its three GRU iterations + upsampling;
     # stage 1 also carries the preparation of all stages)
@@ -303,7 +335,7 @@ def main():
             "dtype": DTYPE[precision], "data": "synthetic",
             "config": {"workload": f"{args.workload}: DTU-shaped {W}x{H}, N={N} views (S={N - 1} sources), 3-stage cascade "
                                    f"ndepths={nd}, GRU iters 3,3,3, seeded-random weights, features of the stock FPN resident in HBM",
-                       "launch": ("hipGraph replay of the captured hot path (" + ("two streams" if ops.get_branches() else "one stream, linear graph")
+                       "launch": ("hipGraph replay of the captured hot path (" + ("two streams" if graph_branches else "one stream, linear graph")
                                   + ") on double-buffered static input slots that hold the "
                                   f"synthetic views; each step replays one slot and clones the outputs it keeps, inside the timed region; "
                                   f"{max(1, args.in_flight)} independent view(s) in flight, one stream each"
@@ -311,6 +343,7 @@ def main():
                        "parallelism": f"view-sharded x{world}, {'RCCL' if args.backend == 'nccl' else 'gloo (rehearsal)'} gather of "
                                       f"depth+confidence to rank 0 inside the timed region" if world > 1 else "single GPU"},
             "in_flight": (max(1, args.in_flight) if graphed is not None else 1),
+            **({"single_stream": single_stream} if single_stream is not None else {}),
             "ms_per_cost_volume_stage": stage_ms,
             **({"graph_fallback": graph_fallback} if graph_fallback else {}),
             "roofline": roof,
@@ -351,7 +384,7 @@ def main():
                     dt_og = time.perf_counter() - t0
                     same = bool(torch.equal(og.replay(0)["depth"][-1], alt_out))
                     other_graph = {"value": args.steps / dt_og, "unit": "views/s", "ms_per_step": dt_og / args.steps * 1e3,
-                                   "replay_bitwise_equal_to_eager": same}
+                                   "in_flight": 1, "replay_bitwise_equal_to_eager": same}
                     del og, keep
                 except Exception as exc:
                     other_graph = {"error": f"{type(exc).__name__}: {exc}"}
@@ -401,7 +434,7 @@ def main():
                 ops.set_precision(precision)
             torch.cuda.empty_cache()
         result["other_precision"] = {"mode": other, "dtype": DTYPE[other],
-                                     "graph_replay": other_graph,        # like-for-like with the headline line
+                                     "graph_replay": other_graph,        # one view after the other: like-for-like with 'single_stream' (or the headline when --in-flight 1)
                                      "eager": {"value": args.steps / dt_other, "unit": "views/s", "ms_per_step": dt_other / args.steps * 1e3},
                                      "final_depth_diff_between_modes": {"mean_norm": float(diff.mean()),
                                                                         "p99_norm": float(diff.flatten().kthvalue(int(0.99 * diff.numel())).values),
@@ -411,7 +444,7 @@ def main():
     # ---- secondary (rank 0, N = 1): throughput with several independent views in flight (their graphs on separate streams, the
     # second stream inside each graph enabled): bubbles of one view are filled by kernels of the others.  Not the headline: a
     # view's latency rises to ~in_flight x ms_per_view.
-    if rank == 0 and world == 1 and graphed is not None and args.pipelined > 1 and not args.no_whole_forward:
+    if rank == 0 and world == 1 and graphed is not None and args.pipelined > 1 and args.in_flight <= 1 and not args.no_whole_forward:
         from effi_mvs_plus_amd.graph import HotPathGraph
         br0 = ops.get_branches()
         ops.set_branches(True)
@@ -603,6 +636,8 @@ def main():
         from oracle import effi_oracle as O
         f, c, p, d = inputs[0]
         hip_ms = dt / args.steps * 1e3
+        if result.get("single_stream") and "ms_per_view" in result["single_stream"]:
+            hip_ms = result["single_stream"]["ms_per_view"]       # the baselines run one view at a time: compare with the HIP path doing the same
         if args.torch_baseline_views > 0:
             # reference-style composite path: the oracle's op-for-op torch sequence on this GPU, (a) sync-free (without the
             # reference's NaN probe and torch.unique assert) and (b) literal: with those 34 host synchronisations per view
