@@ -38,7 +38,7 @@ def key_of(name):
         return f"conv2d_k3x3_pair_nt{m.group(1)}", ({1: 1.0, 2: 1.25, 4: 1.5}.get(int(m.group(2)), 1.0) if m.group(3) == "true" else 1.0)
     if n.startswith("encoder_inputs_kernel"):
         return "encoder_inputs", 2.0                                                   # 4 B per lane, 256-byte runs of the cost volumes
-    m = re.match(r"conv3d_roll_bf16x3_pair_kernel<(\d+)", n)
+    m = re.match(r"conv3d_roll(?:_rp)?_bf16x3_pair_kernel<(\d+)", n)
     if m:
         return f"conv3d_roll_pair_oct{m.group(1)}", 1.0                                # 96-byte segments
     m = re.match(r"conv3d_k3_pair_kernel<(\d+), (\d+), (\d+)", n)
@@ -49,6 +49,11 @@ def key_of(name):
     m = re.match(r"conv3d_roll_bf16x3_kernel<(\d+), (\d+)", n)
     if m:
         return f"conv3d_roll_oct{m.group(1)}_nt{m.group(2)}", 1.0
+    m = re.match(r"conv3d_roll_rp_bf16x3_kernel<(\d+)", n)                             # row-pair form (cout <= 8): one N-tile
+    if m:
+        return f"conv3d_roll_oct{m.group(1)}_nt1", 1.0
+    if n.startswith("head_update_kernel"):
+        return "head_update", 2.0                                                      # float4 per lane streams
     m = re.match(r"deconv3d_s2_bf16x3_kernel", n)
     if m:
         return "deconv3d_x3", 1.0                                                      # 96-byte segments: counted exactly
@@ -76,7 +81,7 @@ def key_of(name):
 
 
 # families whose dominant read shape is one of the calibrated ones (see the module docstring)
-CALIBRATED = {"encoder_inputs", "deconv3d_x3", "getcost_conv1x1", "warpcorr_views_c32", "warpcorr_dyn_c8", "warpcorr_dyn_c16"}
+CALIBRATED = {"encoder_inputs", "deconv3d_x3", "getcost_conv1x1", "warpcorr_views_c32", "warpcorr_dyn_c8", "warpcorr_dyn_c16", "head_update"}
 CALIBRATED_PREFIXES = ("conv2d_k3x3", "conv3d_x3", "conv3d_roll", "conv2d_k3k1")
 
 
