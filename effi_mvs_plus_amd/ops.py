@@ -30,10 +30,25 @@ class KernelProfile:
         self.keys = None if keys is None else set(keys)
         self.records = []
 
+    def busy_ms_per_mark(self):
+        """Sum of the launches' own durations between consecutive ``ops.mark`` calls (name of the mark that ENDS the span -> ms):
+        what the span costs when its kernels run back to back, as in a graph replay -- independent of how fast the host enqueues."""
+        torch.cuda.synchronize()
+        out, acc = {}, 0.0
+        for key, _, e0, e1 in self.records:
+            if e0 is None:
+                out[key] = out.get(key, 0.0) + acc
+                acc = 0.0
+            else:
+                acc += e0.elapsed_time(e1)
+        return out
+
     def summary(self):
         torch.cuda.synchronize()
         out = {}
         for key, work, e0, e1 in self.records:
+            if e0 is None:                      # a stage mark (see ``mark``), not a launch
+                continue
             d = out.setdefault(key, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
@@ -248,6 +263,8 @@ def set_marks(marks):
 
 
 def mark(name):
+    if _PROF is not None and _PROF.keys is None:
+        _PROF.records.append((name, {}, None, None))
     if _MARKS is not None:
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
