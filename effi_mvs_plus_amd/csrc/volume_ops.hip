@@ -192,6 +192,15 @@ __global__ void view_aggregate_kernel(const float* __restrict__ sim_views, const
                                       int S, int D, int hw, float* __restrict__ out) {
     const int p = blockIdx.x * TPB + threadIdx.x;
     if (p >= hw) return;
+    const int d0 = blockIdx.y * 8;
+    if (!weights) {                                     // pixel_wise_net = None (models/Effi_MVS_plus.py:55-58,70): sum / (N - 1)
+        for (int d = d0; d < min(D, d0 + 8); ++d) {
+            float acc = 0.0f;
+            for (int v = 0; v < S; ++v) acc = acc + sim_views[((long)v * D + d) * hw + p];
+            out[(long)d * hw + p] = acc / (float)S;
+        }
+        return;
+    }
     float wv[EFFI_MAX_VIEWS];
     float wsum = 0.0f;
 #pragma unroll
@@ -200,7 +209,6 @@ __global__ void view_aggregate_kernel(const float* __restrict__ sim_views, const
         if (v < S) wsum = wsum + wv[v];
     }
     const float den = wsum + 1e-6f;
-    const int d0 = blockIdx.y * 8;
     for (int d = d0; d < min(D, d0 + 8); ++d) {
         float acc = 0.0f;
 #pragma unroll
@@ -576,7 +584,7 @@ extern "C" int effi_head_update_f32(const float* partial9, const float* bias2, c
 
 extern "C" int effi_view_aggregate_f32(const float* sim_views, const float* weights, int S, int D, int hw,
                                        float* out, effi_stream_t stream) {
-    if (!sim_views || !weights || !out || S < 1 || S > EFFI_MAX_VIEWS || D < 1 || hw < 1) return EFFI_ERR_BADARG;
+    if (!sim_views || !out || S < 1 || S > EFFI_MAX_VIEWS || D < 1 || hw < 1) return EFFI_ERR_BADARG;
     hipLaunchKernelGGL(view_aggregate_kernel, dim3(effi_cdiv(hw, TPB), effi_cdiv(D, 8)), dim3(TPB), 0, effi_s(stream),
                        sim_views, weights, S, D, hw, out);
     EFFI_LAUNCH_CHECK();

@@ -106,13 +106,16 @@ class DepthNet(nn.Module):
         nhwc = ops.to_nhwc(feats)
         rt = ops.compose_rel_proj(pairs)
         sim_views, entropy = ops.warpcorr_views(nhwc[0], nhwc[1:], rt, depth, num_depth)
-        weights = pixel_wise_net.run(entropy) if hasattr(pixel_wise_net, "run") else \
-            pixel_wise_net(entropy.unsqueeze(1)).squeeze(1).contiguous()
+        if pixel_wise_net is None:              # unweighted average of the views (reference :55-58,70); view_weights stays the empty list
+            weights = None
+        else:
+            weights = pixel_wise_net.run(entropy) if hasattr(pixel_wise_net, "run") else \
+                pixel_wise_net(entropy.unsqueeze(1)).squeeze(1).contiguous()
         volume = ops.view_aggregate(sim_views, weights)
         reg, _ = cost_regularization.run(volume.unsqueeze(0))
         d, conf = ops.softmax_regress_conf(reg[0], depth)
-        return {"depth": d, "photometric_confidence": conf, "view_weights": weights, "reg_volume": reg[0],
-                "volume": volume.unsqueeze(0)}
+        return {"depth": d, "photometric_confidence": conf, **({"view_weights": weights} if weights is not None else {}),
+                "reg_volume": reg[0], "volume": volume.unsqueeze(0)}
 
     @ops.on_tensor_device
 
@@ -122,16 +125,20 @@ class DepthNet(nn.Module):
             depth_values.shape[1], num_depth)
         if G != 1:
             raise NotImplementedError("DepthNet: group-wise correlation is instantiated for G=1 (the shipped model)")
-        if pixel_wise_net is None:
-            raise NotImplementedError("DepthNet: the unweighted average (pixel_wise_net=None) is not on the HIP path")
         if self.training:
+            if pixel_wise_net is None:
+                raise NotImplementedError("DepthNet (training): the unweighted average (pixel_wise_net=None) has no backward on the "
+                                          "HIP path; the shipped model always passes its PixelwiseNet")
             from .. import train_path
             return train_path.depthnet(pixel_wise_net, cost_regularization, features, proj_matrices, depth_values)
         outs = []
         for b in range(features[0].shape[0]):
             outs.append(self.run([f[b] for f in features], proj_matrices[b].contiguous(), depth_values[b], num_depth,
                                  cost_regularization, pixel_wise_net))
-        return {k: _stack([o[k] for o in outs]) for k in outs[0]}
+        res = {k: _stack([o[k] for o in outs]) for k in outs[0]}
+        if pixel_wise_net is None:
+            res["view_weights"] = []            # what the reference returns in this branch (:20,89)
+        return res
 
 
 # =============================================================================================

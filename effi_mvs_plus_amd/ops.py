@@ -419,8 +419,11 @@ def pixelwise_net(entropy, params):
 
 
 def view_aggregate(sim_views, weights):
+    """sum_v sim_v w_v / (sum_v w_v + 1e-6); ``weights`` None = the plain mean over the views (pixel_wise_net = None)."""
     S, D, h, w = sim_views.shape
-    _t(sim_views, "sim_views"), _t(weights, "weights")
+    _t(sim_views, "sim_views")
+    if weights is not None:
+        _t(weights, "weights")
     out = torch.empty(D, h, w, device=sim_views.device, dtype=torch.float32)
     check(_lib.lib().effi_view_aggregate_f32(_p(sim_views), _p(weights), S, D, h * w, _p(out), _stream()),
           "effi_view_aggregate_f32")

@@ -112,7 +112,8 @@ int effi_pixelwise_net_f32(const float* entropy, const float* params, int n, int
                            effi_stream_t stream);
 
 /* ---- K3: view-weighted aggregation  sim = sum_v sim_v*w_v / (sum_v w_v + 1e-6).
- * models/Effi_MVS_plus.py:48-53,67.  sim_views [S][D][hw]; weights [S][hw]; out [D][hw]. */
+ * models/Effi_MVS_plus.py:48-53,67.  sim_views [S][D][hw]; weights [S][hw]; out [D][hw].
+ * weights == NULL: the unweighted branch (pixel_wise_net = None, :55-58,70): sim = sum_v sim_v / S. */
 int effi_view_aggregate_f32(const float* sim_views, const float* weights, int S, int D, int hw, float* out,
                             effi_stream_t stream);
 

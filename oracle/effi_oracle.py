@@ -311,7 +311,8 @@ def depth_regression(p, depth_values):
 # --------------------------------------------------------------------------------------------
 def depthnet(sd, features, proj_matrices, depth_values, num_depth, regnet_prefix="cost_regularization",
              pixelwise_prefix="PixelwiseNet", G=1):
-    """``DepthNet.forward`` (eval mode, view-weight net present).  models/Effi_MVS_plus.py:14-89."""
+    """``DepthNet.forward`` (eval mode).  models/Effi_MVS_plus.py:14-89.  ``pixelwise_prefix=None`` = the reference's
+    ``pixel_wise_net=None`` branch (:55-58,70): plain mean of the views' similarities, ``view_weights`` stays the empty list."""
     projs = torch.unbind(proj_matrices, 1)
     assert len(features) == len(projs)
     assert depth_values.shape[1] == num_depth
@@ -324,14 +325,20 @@ def depthnet(sd, features, proj_matrices, depth_values, num_depth, regnet_prefix
         warped = homo_warping_new(src, compose_projection(sp), ref_new, depth_values)
         warped = warped.view(B, G, C // G, num_depth, H, W)
         sim = (warped * ref_g.unsqueeze(3)).mean(2)                              # [B,G,D,H,W]
+        if pixelwise_prefix is None:
+            sim_sum = sim_sum + sim                                              # :55-58
+            continue
         p = F.softmax(sim.squeeze(1).detach(), dim=1)                            # :43 (detached: no gradient through the entropy)
         entropy = (-p * torch.log(p + 1e-7)).sum(dim=1, keepdim=True)
         vw = pixelwise_net(sd, pixelwise_prefix, entropy)                        # [B,1,H,W]
         view_weights.append(vw)
         sim_sum = sim_sum + sim * vw.unsqueeze(1)
         w_sum = w_sum + vw.unsqueeze(1)
-    view_weights = torch.cat(view_weights, dim=1)
-    similarity = sim_sum / (w_sum + 1e-6)
+    if pixelwise_prefix is None:
+        similarity = sim_sum / (len(features) - 1)                               # :70
+    else:
+        view_weights = torch.cat(view_weights, dim=1)
+        similarity = sim_sum / (w_sum + 1e-6)
     prob_pre, _ = cost_regnet(sd, regnet_prefix, similarity)
     prob_pre = prob_pre.squeeze(1)
     prob = F.softmax(prob_pre, dim=1)

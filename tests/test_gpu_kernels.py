@@ -312,6 +312,22 @@ def test_depthnet_module(model, O):
                     rtol=1e-4, atol=1e-4, frac_ok=0.98)
 
 
+def test_depthnet_without_view_weight_net(model, O):
+    """``pixel_wise_net=None`` (models/Effi_MVS_plus.py:55-58,70): plain mean over the source views, empty ``view_weights``."""
+    net, sd = model
+    feats = synth.smooth_features(4, 32, 16, 20, seed=2)
+    _, pm, _ = synth.synth_sample(128, 160, 4, seed=7)
+    proj = pm["stage1"]
+    samples = (1.0 / torch.linspace(1 / 935.0, 1 / 425.0, 8)).view(1, 8, 1, 1).expand(1, 8, 16, 20).contiguous()
+    out = net.depthnet([t(f, DEV) for f in feats], t(proj, DEV), depth_values=samples.to(DEV), num_depth=8,
+                       cost_regularization=net.cost_regularization, pixel_wise_net=None, G=1)
+    ora = O.depthnet(sd, feats, proj, samples, 8, pixelwise_prefix=None)
+    assert out["view_weights"] == []
+    for k in ("volume", "reg_volume", "depth"):
+        tol = dict(rtol=1e-4, atol=3e-4) if k != "depth" else dict(rtol=1e-5, atol=2e-2)
+        check_close(f"DepthNet(no view-weight net).{k}", out[k], ora[k], frac_ok=0.995, **tol)
+
+
 # ---------------------------------------------------------------------------------------------
 # 3-D convolutions
 # ---------------------------------------------------------------------------------------------

@@ -48,6 +48,26 @@ def test_shipped_checkpoint_bitwise():
     _compare(net, sd, 192, 256, 5, (48, 8, 8))
 
 
+def test_depthnet_without_view_weight_net_bitwise():
+    """The reference's ``pixel_wise_net=None`` branch of DepthNet (models/Effi_MVS_plus.py:55-58,70), which the shipped model never
+    takes: the oracle's restatement of it against the reference's DepthNet called that way."""
+    _, net = reference_model("8,8,8")
+    sd = synth.randomize_state_dict(net.state_dict(), seed=6)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    feats = [f for f in synth.smooth_features(4, 32, 16, 20, seed=2)]
+    _, pm, dv = synth.synth_sample(128, 160, 4, seed=7)
+    proj = pm["stage1"]
+    samples = (1.0 / torch.linspace(1 / 935.0, 1 / 425.0, 8)).view(1, 8, 1, 1).expand(1, 8, 16, 20).contiguous()
+    with torch.no_grad():
+        want = net.depthnet(feats, proj, depth_values=samples, num_depth=8, cost_regularization=net.cost_regularization,
+                            pixel_wise_net=None, G=1)
+        got = O.depthnet(sd, feats, proj, samples, 8, pixelwise_prefix=None)
+    assert want["view_weights"] == [] and got["view_weights"] == []
+    for k in ("volume", "reg_volume", "depth", "photometric_confidence"):
+        assert torch.equal(got[k], want[k]), k
+
+
 def test_our_modules_load_the_shipped_checkpoint_strictly():
     ckpt = os.path.join(REF_ROOT, "checkpoints", "Effi_MVS_plus", "model_tank.ckpt")
     if not os.path.exists(ckpt):
