@@ -2434,10 +2434,16 @@ struct ConvTwiceArgs {
 };
 
 __global__ __launch_bounds__(256) void conv2d_k3_twice_oct_kernel(const ConvTwiceArgs a, int tiles_x, int ntiles) {
-    constexpr int TR = 12, TW = 16, RW = TW + 2, RH = TR + 2, NPM = RW * RH;          // 252 mid pixels
+    // ROW-PAIR operands (both layers have at most 8 output channels): MFMA rows 0-7 = the channels of an image row, rows 8-15 = the
+    // same channels of the row below, K = (dy in 0..3, dx) over the 4 x 3 window both rows see = 12 taps = exactly 3 K-steps for TWO
+    // rows (packing.pack_conv2d_bf16x3_oct: W[j][e][dy][dx] for rows j < 8, zero at dy = 3; W[j-8][e][dy-1][dx] for j >= 8, zero at dy = 0)
+    constexpr int TR = 16, TW = 16, RW = TW + 2, RH = TR + 2, NPM = RW * RH;          // 324 mid pixels = 9 row pairs x 18 columns
+    constexpr int NPP = (RH / 2) * RW;                                               // 162 pair-pixels of the first layer
+    constexpr int NGA = 3;                                                           // 12 groups of 16 pair-pixels, 3 per wave
     constexpr int AR = TR + 4, AW = TW + 8, AQ = AW / 4, APIX = AR * AW, NKS = 3;
-    constexpr int NITEMS = APIX / 4;                                                 // 96 staging items (one octet)
+    constexpr int NITEMS = APIX / 4;                                                 // 120 staging items (one octet)
     constexpr int NBF = NKS * 2 * 64;                                                // 16-byte units of B per layer
+    static_assert(4 * NGA * 16 >= NPP, "groups cover the region");
     __shared__ __attribute__((aligned(16))) unsigned short lds_ah[APIX * 8];
     __shared__ __attribute__((aligned(16))) unsigned short lds_al[APIX * 8];
     __shared__ __attribute__((aligned(16))) unsigned short mid_h[NPM * 8];
@@ -2462,7 +2468,7 @@ __global__ __launch_bounds__(256) void conv2d_k3_twice_oct_kernel(const ConvTwic
             *reinterpret_cast<f32x4*>(&lds_b[(512 + u) * 8]) = *reinterpret_cast<const f32x4*>(wb + (long)u * 8);
         }
     }
-    // input tile 16 x 24 with origin (y0 - 2, x0 - 4): threads 0..95 own a pixel quad each
+    // input tile 20 x 24 with origin (y0 - 2, x0 - 4): threads 0..119 own a pixel quad each
     const bool stager = tid < NITEMS;
     const int srow = stager ? tid / AQ : 0, sqx = stager ? tid - srow * AQ : 0;
     const int s_lds = (srow * AW + 4 * sqx) * 8;
@@ -2482,28 +2488,30 @@ __global__ __launch_bounds__(256) void conv2d_k3_twice_oct_kernel(const ConvTwic
         }
     };
 
-    // K-step s: lane quarter lk owns tap 4 s + lk (taps 9..11: B is zero, the address repeats tap 8)
+    // K-step s: lane quarter lk owns tap 4 s + lk = (dy, dx) = ((4 s + lk) / 3, (4 s + lk) % 3) of the 4 x 3 window
     int koffa[NKS], koffb[NKS];
 #pragma unroll
     for (int s_ = 0; s_ < NKS; ++s_) {
-        const int tap = min(4 * s_ + lk, 8);
+        const int tap = 4 * s_ + lk;
         koffa[s_] = ((tap / 3) * AW + tap % 3) * 8;
-        koffb[s_] = ((3 * wv + tap / 3) * RW + li + tap % 3) * 8;
+        koffb[s_] = ((4 * wv + tap / 3) * RW + li + tap % 3) * 8;
     }
-    int gbase[4], pmid[4], prow[4], pcol[4];
+    // first layer: group g = 3 wv + m, pair-pixel pp = 16 g + li = (pair row pp / 18, column pp % 18) of the 18 x 18 region
+    int gbase[NGA], pmid[NGA], prow[NGA], pcol[NGA];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int p_ = min(16 * (4 * wv + m) + li, NPM - 1);
-        prow[m] = p_ / RW;
-        pcol[m] = p_ - prow[m] * RW;
-        pmid[m] = p_;
-        gbase[m] = (prow[m] * AW + pcol[m] + 2) * 8;
+    for (int m = 0; m < NGA; ++m) {
+        const int pp = min(16 * (NGA * wv + m) + li, NPP - 1);      // lanes past the region repeat its last pair (same values, same slots)
+        const int pr2 = pp / RW;
+        pcol[m] = pp - pr2 * RW;
+        prow[m] = 2 * pr2 + (lk >> 1);                              // the region row this lane's accumulator half belongs to
+        pmid[m] = prow[m] * RW + pcol[m];
+        gbase[m] = (2 * pr2 * AW + pcol[m] + 2) * 8;
     }
     float ba[4], bb[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        ba[r] = a.bias_a[(4 * lk + r) & 15];
-        bb[r] = a.bias_b[(4 * lk + r) & 15];
+        ba[r] = a.bias_a[4 * (lk & 1) + r];
+        bb[r] = a.bias_b[4 * (lk & 1) + r];
     }
 
     if (stager) prefetch(t0);
@@ -2523,18 +2531,18 @@ __global__ __launch_bounds__(256) void conv2d_k3_twice_oct_kernel(const ConvTwic
         }
         __syncthreads();                                   // input tile complete (and the previous tile's second layer done with mid)
 
-        // ---- first layer on the 14 x 18 region (origin (y0 - 1, x0 - 1)), 16 pixel groups, 4 per wave ----
+        // ---- first layer on the 18 x 18 region (origin (y0 - 1, x0 - 1)): 12 groups of 16 pair-pixels, 3 per wave ----
         {
-            f32x4 acc[4];
+            f32x4 acc[NGA];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int m = 0; m < NGA; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int s_ = 0; s_ < NKS; ++s_) {
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&lds_b[((s_ * 2 + 0) * 64 + lane) * 8]);
                 bf16x8 bl = bh;
                 if (!kHiOnly) bl = *reinterpret_cast<const bf16x8*>(&lds_b[((s_ * 2 + 1) * 64 + lane) * 8]);
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
+                for (int m = 0; m < NGA; ++m) {
                     const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&lds_ah[gbase[m] + koffa[s_]]);
                     acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, acc[m], 0, 0, 0);
                     if (!kHiOnly) {
@@ -2544,53 +2552,52 @@ __global__ __launch_bounds__(256) void conv2d_k3_twice_oct_kernel(const ConvTwic
                     }
                 }
             }
-            if (lk < 2) {                                 // channels 0..7 only
+            // lane (li, lk): region row prow (upper / lower of the pair by lk >> 1), channels 4 (lk & 1) .. + 3
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int gy = y0 - 1 + prow[m], gx = x0 - 1 + pcol[m];
-                    const bool pin = (gy >= 0) & (gy < h) & (gx >= 0) & (gx < w);
-                    f32x4 vf;
+            for (int m = 0; m < NGA; ++m) {
+                const int gy = y0 - 1 + prow[m], gx = x0 - 1 + pcol[m];
+                const bool pin = (gy >= 0) & (gy < h) & (gx >= 0) & (gx < w);
+                f32x4 vf;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) vf[r] = pin ? fmaxf(acc[m][r] + ba[r], 0.0f) : 0.0f;
-                    const bf16x4 vh = __builtin_convertvector(vf, bf16x4);
-                    const bf16x4 vl = __builtin_convertvector(vf - __builtin_convertvector(vh, f32x4), bf16x4);
-                    *reinterpret_cast<bf16x4*>(&mid_h[pmid[m] * 8 + 4 * lk]) = vh;
-                    if (!kHiOnly) *reinterpret_cast<bf16x4*>(&mid_l[pmid[m] * 8 + 4 * lk]) = vl;
-                }
+                for (int r = 0; r < 4; ++r) vf[r] = pin ? fmaxf(acc[m][r] + ba[r], 0.0f) : 0.0f;
+                const bf16x4 vh = __builtin_convertvector(vf, bf16x4);
+                const bf16x4 vl = __builtin_convertvector(vf - __builtin_convertvector(vh, f32x4), bf16x4);
+                *reinterpret_cast<bf16x4*>(&mid_h[pmid[m] * 8 + 4 * (lk & 1)]) = vh;
+                if (!kHiOnly) *reinterpret_cast<bf16x4*>(&mid_l[pmid[m] * 8 + 4 * (lk & 1)]) = vl;
             }
         }
         __syncthreads();                                   // mid complete; the input tile may be overwritten
 
-        // ---- second layer on the 12 x 16 tile: wave wv owns rows 3 wv .. 3 wv + 2 ----
-        f32x4 acc[3];
+        // ---- second layer on the 16 x 16 tile: wave wv owns rows 4 wv .. 4 wv + 3 as two row pairs ----
+        f32x4 acc[2];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int m = 0; m < 2; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int s_ = 0; s_ < NKS; ++s_) {
             const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&lds_b[(512 + (s_ * 2 + 0) * 64 + lane) * 8]);
             bf16x8 bl = bh;
             if (!kHiOnly) bl = *reinterpret_cast<const bf16x8*>(&lds_b[(512 + (s_ * 2 + 1) * 64 + lane) * 8]);
 #pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&mid_h[koffb[s_] + m * RW * 8]);
+            for (int m = 0; m < 2; ++m) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&mid_h[koffb[s_] + m * 2 * RW * 8]);
                 acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, acc[m], 0, 0, 0);
                 if (!kHiOnly) {
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&mid_l[koffb[s_] + m * RW * 8]);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&mid_l[koffb[s_] + m * 2 * RW * 8]);
                     acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, acc[m], 0, 0, 0);
                     acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, acc[m], 0, 0, 0);
                 }
             }
         }
-        const int x = x0 + li;
-        if (x < w && 4 * lk < a.cout) {
+        const int x = x0 + li, co0 = 4 * (lk & 1);
+        if (x < w && co0 < a.cout) {
 #pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                const int y = y0 + 3 * wv + m;
+            for (int m = 0; m < 2; ++m) {
+                const int y = y0 + 4 * wv + 2 * m + (lk >> 1);
                 if (y >= h) continue;
                 const long pix = (long)y * w + x;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (4 * lk + r < a.cout) a.out[(long)(4 * lk + r) * hw + pix] = fmaxf(acc[m][r] + bb[r], 0.0f);
+                    if (co0 + r < a.cout) a.out[(long)(co0 + r) * hw + pix] = fmaxf(acc[m][r] + bb[r], 0.0f);
             }
         }
     }
@@ -2602,7 +2609,7 @@ extern "C" int EFFI_FN(effi_conv2d_k3_twice_bf16x3_f32)(const float* in, int cin
                                                const void* w2_bf16, const float* bias2, int cout, int h, int w, float* out,
                                                effi_stream_t stream) {
     if (!in || !w1_bf16 || !bias1 || !w2_bf16 || !bias2 || !out || cin < 1 || cout < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
-    if ((w & 3) || cin > 8 || cout > 16) return EFFI_ERR_UNSUPPORTED;
+    if ((w & 3) || cin > 8 || cout > 8) return EFFI_ERR_UNSUPPORTED;
     ConvTwiceArgs a;
     a.src = in; a.cin = cin;
     a.w_a = reinterpret_cast<const float*>(w1_bf16); a.bias_a = bias1;
@@ -2610,8 +2617,8 @@ extern "C" int EFFI_FN(effi_conv2d_k3_twice_bf16x3_f32)(const float* in, int cin
     a.cout = cout; a.h = h; a.w = w; a.out = out;
     a.zeros = effi_zero_page();
     if (!a.zeros) return EFFI_ERR_WORKSPACE;
-    const int tiles_x = effi_cdiv(w, 16), ntiles = tiles_x * effi_cdiv(h, 12);
-    const int nwg = ntiles < 1024 ? ntiles : 1024;         // 4 persistent workgroups per CU (36 KB of LDS each)
+    const int tiles_x = effi_cdiv(w, 16), ntiles = tiles_x * effi_cdiv(h, 16);
+    const int nwg = ntiles < 1024 ? ntiles : 1024;         // 4 persistent workgroups per CU (38 KB of LDS each)
     hipLaunchKernelGGL(conv2d_k3_twice_oct_kernel, dim3(nwg), dim3(256), 0, effi_s(stream), a, tiles_x, ntiles);
     return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }

@@ -286,7 +286,7 @@ class P_1to8_FeatureNet_Fast(nn.Module):
         x = img
         c0 = list(self.conv0)
         if (ops.uses_split() and len(c0) == 2 and all(self._is_k3s1(b) and b.relu for b in c0) and c0[0].conv.in_channels <= 8
-                and c0[0].conv.out_channels <= 8 and c0[1].conv.out_channels <= 16 and img.shape[-1] % 4 == 0
+                and c0[0].conv.out_channels <= 8 and c0[1].conv.out_channels <= 8 and img.shape[-1] % 4 == 0
                 and os.environ.get("EFFI_FPN_CONV0_FUSED", "1") != "0"):
             # the two full-resolution layers in one kernel: their 8-channel intermediate (61 MB at 1184x1600) stays in LDS
             (w1, b1), (w2, b2) = (self._pk_oct(f"conv0.{i}", b.conv, b.bn) for i, b in enumerate(c0))

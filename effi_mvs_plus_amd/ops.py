@@ -918,7 +918,7 @@ def conv2d_k3_k1_x3(srcs, wpack, bias, cout1, extra, w2pack, bias2, cout2, relu=
 
 def conv2d_k3_twice(x, w1, b1, w2, b2, cout, out=None):
     """relu(conv3x3(relu(conv3x3(x)))) with at most 8 channels into each layer (8 between them) in one kernel, the intermediate map
-    in LDS (``packing.pack_conv2d_bf16x3_oct`` weights): the pyramid's full-resolution block.  x [cin<=8,h,w] -> [cout<=16,h,w]."""
+    in LDS (``packing.pack_conv2d_bf16x3_oct`` weights): the pyramid's full-resolution block.  x [cin<=8,h,w] -> [cout<=8,h,w]."""
     _t(x, "conv input")
     cin, h, w = x.shape
     if out is None:

@@ -238,14 +238,17 @@ def pack_conv2d_bf16x3(weight, bias, scale=1.0):
 
 
 def pack_conv2d_bf16x3_oct(weight, bias, scale=1.0):
-    """[cout <= 16, cin <= 8, 3, 3] (+bias) for the one-octet layers of ``effi_conv2d_k3_twice_bf16x3_f32``: K index = tap (one octet of
-    channels), K-step s takes taps 4s..4s+3; lane = q*16 + j holds W[j][e][tap = 4s + q] (zero for taps 9..11, e >= cin, j >= cout).
-    -> (bf16 [3, 2(hi|lo), 64, 8], bias fp32 [16])."""
+    """[cout <= 8, cin <= 8, 3, 3] (+bias) for the one-octet layers of ``effi_conv2d_k3_twice_bf16x3_f32``, ROW-PAIR operand: MFMA rows
+    0-7 are the output channels of an image row, rows 8-15 the same channels of the row below; K index = tap of the 4 x 3 window both
+    rows see, tap = dy*3 + dx = 4 s + q: lane = q*16 + j holds W[j][e][dy][dx] for j < 8 (zero at dy = 3) and W[j-8][e][dy-1][dx] for
+    j >= 8 (zero at dy = 0); zero for e >= cin, channels >= cout.  -> (bf16 [3, 2(hi|lo), 64, 8], bias fp32 [16], entries 0..7 used)."""
     cout, cin, ks, _ = weight.shape
-    assert ks == 3 and cout <= 16 and cin <= 8
-    w = torch.zeros(16, 8, 12, device=weight.device, dtype=torch.float32)       # [j, e, tap]
-    w[:cout, :cin, :9] = weight.reshape(cout, cin, 9).float() * scale
-    w = w.view(16, 8, 3, 4).permute(2, 3, 0, 1).contiguous()                    # [s, q, j, e]
+    assert ks == 3 and cout <= 8 and cin <= 8
+    wf = weight.float() * scale
+    w = torch.zeros(16, 8, 4, 3, device=weight.device, dtype=torch.float32)     # [row, e, dy, dx]
+    w[:cout, :cin, 0:3] = wf
+    w[8:8 + cout, :cin, 1:4] = wf
+    w = w.reshape(16, 8, 3, 4).permute(2, 3, 0, 1).contiguous()                 # taps (dy, dx) flattened = 4 s + q -> [s, q, j, e]
     hi = w.to(torch.bfloat16)
     lo = (w - hi.float()).to(torch.bfloat16)
     wp = torch.stack([hi, lo], dim=1).contiguous().view(3, 2, 64, 8)

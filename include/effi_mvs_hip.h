@@ -167,8 +167,10 @@ int effi_conv2d_k3_bf16x3_pair_f32(const float* const* srcs_a, const int* src_ch
                                    float* out_b, int cout, int h, int w, int act, effi_stream_t stream);
 /* Two chained 3x3 convolutions with ReLU after each, at most 8 channels into each (the pyramid's full-resolution block conv0 =
  * Conv2d(3, 8) -> Conv2d(8, 8) with BatchNorm folded, models/module.py:353-356), in one kernel: the 8-channel intermediate map
- * stays in LDS (first layer computed on each 12 x 16 tile grown by one pixel).  in [cin][h][w], cin <= 8; the first layer has at
- * most 8 outputs (the packed operands are zero-padded to 8); out [cout][h][w], cout <= 16; w1 / w2 as packing.pack_conv2d_bf16x3_oct, biases padded to 16; w % 4 == 0. */
+ * stays in LDS (first layer computed on each 16 x 16 tile grown by one pixel).  in [cin][h][w], cin <= 8; both layers have at most 8
+ * outputs, out [cout][h][w]; w1 / w2 = ROW-PAIR operands [3][hi|lo][64][8] bf16 (packing.pack_conv2d_bf16x3_oct: MFMA rows 0-7 = the
+ * channels of an image row, rows 8-15 = the same channels of the row below, K = the 12 taps of the 4 x 3 window both rows see),
+ * biases padded to 16; w % 4 == 0. */
 int effi_conv2d_k3_twice_bf16x3_f32(const float* in, int cin, const void* w1_bf16, const float* bias1, const void* w2_bf16,
                                     const float* bias2, int cout, int h, int w, float* out, effi_stream_t stream);
 /* Tail of the update block's encoder in one kernel (models/update.py:87-96): cor = relu(convc2(cor1)), dfm = relu(convd2(dfm1)),
