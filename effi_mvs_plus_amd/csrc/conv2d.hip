@@ -2172,6 +2172,195 @@ extern "C" int effi_conv2d_k5s2_f32(const float* in, int cin, const float* wpack
 }
 #endif
 
+// ---- 5x5 stride-2 convolution in split precision (the pyramid's down-sampling layers) ---------------------------
+// out[y][x] = sum W[ky][kx] in[2y + ky - 2][2x + kx - 2]: the fp32-MFMA form above is bound by the fp32 MFMA rate (K = 25 cin in steps of 4);
+// here the products are 3 bf16 MFMAs of K = 32 as in the 3x3 kernels.
+//   * chunk = 8 input channels (one octet), K item = tap (ky, kx): 25 items = 7 K-steps (the last three are zero);
+//   * the input region of a 16 x (4 MR) output tile is (8 MR + 3) rows x 40 columns (float4-aligned from 2 x0 - 4).  It is stored with
+//     the columns DE-INTERLEAVED by parity, [row][parity][20 slots][8 ch]: the 16 pixels of a lane group then read 16 consecutive slots
+//     for every tap (slot = li + 1 + (kx >> 1) of parity kx & 1), conflict-free, although they are 2 input columns apart;
+//   * cout > 32 is split over blockIdx.y in groups of NT = 2 N-tiles (the weight fragments of a chunk are 14 KB per N-tile).
+namespace {
+template <int NT, int MR>
+__global__ __launch_bounds__(256) void conv2d_k5s2_bf16x3_kernel(const Conv2dArgs a, int tiles_x, int ntiles) {
+    constexpr int TR = 4 * MR, IR = 2 * TR + 3, NQ = 10, NSLOT = 20, NKS = 7;
+    constexpr int ROWE = 2 * NSLOT * 8;                                // bf16 elements per staged input row (both parities)
+    constexpr int NITEMS = IR * NQ;                                    // (row, pixel quad) staging items
+    constexpr int NIT = (NITEMS + 255) / 256;
+    constexpr int NBF = NKS * NT * 2 * 64, NB4 = (NBF + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned short lds_ah[IR * ROWE];
+    __shared__ __attribute__((aligned(16))) unsigned short lds_al[IR * ROWE];
+    __shared__ __attribute__((aligned(16))) unsigned short lds_b[NB4 * 256 * 8];
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int h = a.h, w = a.w, hin = a.hin, win = a.win;
+    const long hw = (long)h * w;
+    const int tile = effi_xcd_remap(blockIdx.x, gridDim.x);
+    if (tile >= ntiles) return;
+    const int ty_ = tile / tiles_x;
+    const int x0 = (tile - ty_ * tiles_x) * 16, y0 = ty_ * TR;
+    const int ng = blockIdx.y;                                         // group of NT output tiles
+    const unsigned short* wbf = reinterpret_cast<const unsigned short*>(a.wpack);
+    const int nchunks = (a.cin + 7) >> 3;
+    const int ngroups = gridDim.y;
+
+    f32x4 pa[NIT][8];
+    auto prefetch = [&](int ch) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int item = tid + it * 256;
+            const int r = item / NQ, q = item - r * NQ;
+            const int gy = 2 * y0 - 2 + r, gx = 2 * x0 - 4 + 4 * q;
+            const bool in = (item < NITEMS) & (gy >= 0) & (gy < hin) & (gx >= 0) & (gx < win);
+            const int cb = ch * 8;
+            const int emax = min(a.cin - cb, 8) - 1;
+            const float* qp = in ? a.src[0] + ((long)cb * a.cstride + (long)gy * win + gx) : a.zeros;
+            const long step = in ? a.cstride : 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                pa[it][e] = *reinterpret_cast<const f32x4*>(qp);
+                qp += (e < emax) ? step : 0;
+            }
+        }
+    };
+    auto stash = [&](int ch) {
+        f32x4 tb[NB4];
+#pragma unroll
+        for (int j = 0; j < NB4; ++j) {
+            const int u = min(tid + j * 256, NBF - 1);
+            tb[j] = *reinterpret_cast<const f32x4*>(wbf + (((long)ch * ngroups + ng) * NBF + u) * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int item = tid + it * 256;
+            if (item < NITEMS) {
+                const int r = item / NQ, q = item - r * NQ;
+#pragma unroll
+                for (int px = 0; px < 4; ++px) {
+                    bf16x8 hi, lo;
+                    split_octet(pa[it], px, hi, lo);
+                    const int o = r * ROWE + ((px & 1) * NSLOT + 2 * q + (px >> 1)) * 8;
+                    *reinterpret_cast<bf16x8*>(&lds_ah[o]) = hi;
+                    if (!kHiOnly) *reinterpret_cast<bf16x8*>(&lds_al[o]) = lo;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB4; ++j) *reinterpret_cast<f32x4*>(&lds_b[(tid + j * 256) * 8]) = tb[j];
+    };
+
+    int koff[NKS];
+#pragma unroll
+    for (int s_ = 0; s_ < NKS; ++s_) {
+        const int tap = min(4 * s_ + lk, 24);                           // items 25..27 are padding (B is zero there)
+        const int ky = tap / 5, kx = tap - ky * 5;
+        koff[s_] = ky * ROWE + ((kx & 1) * NSLOT + 1 + (kx >> 1)) * 8;
+    }
+    const int lane_base = (2 * wv * MR) * ROWE + li * 8;
+
+    f32x4 acc[MR][NT];
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    prefetch(0);
+    stash(0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunks; ++ch) {
+        if (ch + 1 < nchunks) prefetch(ch + 1);
+#pragma unroll
+        for (int s_ = 0; s_ < NKS; ++s_) {
+            bf16x8 ah[MR], al[MR];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                ah[m] = *reinterpret_cast<const bf16x8*>(&lds_ah[lane_base + koff[s_] + m * 2 * ROWE]);
+                if (!kHiOnly) al[m] = *reinterpret_cast<const bf16x8*>(&lds_al[lane_base + koff[s_] + m * 2 * ROWE]);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&lds_b[(((s_ * NT + n) * 2 + 0) * 64 + lane) * 8]);
+                bf16x8 bl = bh;
+                if (!kHiOnly) bl = *reinterpret_cast<const bf16x8*>(&lds_b[(((s_ * NT + n) * 2 + 1) * 64 + lane) * 8]);
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[m], acc[m][n], 0, 0, 0);
+                    if (!kHiOnly) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[m], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[m], acc[m][n], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (ch + 1 < nchunks) {
+            __syncthreads();
+            stash(ch + 1);
+            __syncthreads();
+        }
+    }
+    const int x = x0 + li;
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+        const int y = y0 + wv * MR + m;
+        if (y >= h || x >= w) continue;
+        const long pix = (long)y * w + x;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) conv_epilogue_store_t<EFFI_EPI_PLAIN>(a, acc[m][n], (ng * NT + n) * 16 + 4 * lk, pix, hw, 0);
+    }
+}
+
+}  // namespace
+
+template <int NT>
+static int launch_k5s2_x3(const Conv2dArgs& a, int ngroups, hipStream_t st) {
+    const int cols = effi_cdiv(a.w, 16);
+    if ((long)cols * effi_cdiv(a.h, 8) * ngroups >= 400) {
+        const int ntiles = cols * effi_cdiv(a.h, 8);
+        hipLaunchKernelGGL((conv2d_k5s2_bf16x3_kernel<NT, 2>), dim3(ntiles, ngroups), dim3(256), 0, st, a, cols, ntiles);
+    } else {
+        const int ntiles = cols * effi_cdiv(a.h, 4);
+        hipLaunchKernelGGL((conv2d_k5s2_bf16x3_kernel<NT, 1>), dim3(ntiles, ngroups), dim3(256), 0, st, a, cols, ntiles);
+    }
+    return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+}
+
+extern "C" int EFFI_FN(effi_conv2d_k5s2_bf16x3_f32)(const float* in, int cin, const void* wpack_bf16, const float* bias, int cout, int hin,
+                                           int win, int act, float* out, effi_stream_t stream) {
+    if (!in || !wpack_bf16 || !bias || !out || cin < 1 || cout < 1 || hin < 1 || win < 1) return EFFI_ERR_BADARG;
+    if (act < EFFI_ACT_NONE || act > EFFI_ACT_TANH) return EFFI_ERR_BADARG;
+    if ((win & 3) || cout > 128) return EFFI_ERR_UNSUPPORTED;
+    Conv2dArgs a;
+    for (int i = 0; i < EFFI_MAX_SRC; ++i) {
+        a.src[i] = in;
+        a.ch[i] = (i == 0) ? cin : 0;
+    }
+    a.cin = cin;
+    a.kgroups = 0;
+    a.zeros = effi_zero_page();
+    if (!a.zeros) return EFFI_ERR_WORKSPACE;
+    a.wpack = reinterpret_cast<const float*>(wpack_bf16);
+    a.bias = bias;
+    a.cout = cout;
+    a.hin = hin;
+    a.win = win;
+    a.h = (hin - 1) / 2 + 1;
+    a.w = (win - 1) / 2 + 1;
+    a.act = act;
+    a.hd = 0;
+    a.aux0 = a.aux1 = a.disp_range = nullptr;
+    a.n_range = 0;
+    a.out0 = out;
+    a.out1 = nullptr;
+    a.cstride = (long)hin * win;
+    a.ostride = (long)a.h * a.w;
+    a.zcount = a.zin = 0;
+    hipStream_t st = effi_s(stream);
+    const int nt = (cout + 15) / 16;
+    if (nt == 1) return launch_k5s2_x3<1>(a, 1, st);
+    return launch_k5s2_x3<2>(a, (nt + 1) / 2, st);           // weights packed in groups of two N-tiles (zero-padded)
+}
+
 // ---- split-bf16 3x3 convolution entry --------------------------------------------------------------------------
 // Rows per wave (MR): 4 rows amortise the B fragments best, but the grid must still cover the 256 CUs (>= ~400 workgroups),
 // and with two N-tiles the 4-row variant drops to 2 workgroups per CU where the 2-row one keeps 4: on large maps the latter

@@ -275,7 +275,7 @@ class P_1to8_FeatureNet_Fast(nn.Module):
         w, b = self._pk(name, blk.conv, blk.bn)
         act = ops.ACT_RELU if blk.relu else ops.ACT_NONE
         if blk.conv.kernel_size == (5, 5) and blk.conv.stride == (2, 2) and blk.conv.padding == (2, 2):
-            return ops.conv2d_k5s2(x, w.w32, b, blk.conv.out_channels, act=act)
+            return ops.conv2d_k5s2(x, w, b, blk.conv.out_channels, act=act)
         if blk.conv.kernel_size == (3, 3) and blk.conv.stride == (1, 1) and blk.conv.padding == (1, 1):
             return ops.conv2d([x], w, b, blk.conv.out_channels, 3, act=act)
         raise NotImplementedError("feature pyramid: only 3x3/s1/p1 and 5x5/s2/p2 blocks are instantiated on the HIP path")

@@ -972,6 +972,12 @@ def conv2d_k5s2(x, wpack, bias, cout, act=ACT_RELU):
     ho, wo = (hin - 1) // 2 + 1, (win - 1) // 2 + 1
     out = torch.empty(cout, ho, wo, device=x.device, dtype=torch.float32)
     work = lambda: {"flops": 2.0 * ho * wo * cin * cout * 25, "bytes": 4.0 * (hin * win * cin + ho * wo * cout)}
+    if hasattr(wpack, "w32"):                 # packing.Conv2dWeights: pick the arithmetic here
+        if uses_split() and wpack.wx is not None and win % 4 == 0 and os.environ.get("EFFI_K5S2_SPLIT", "1") != "0":
+            check(_call(f"conv2d_k5s2x3_nt{(cout + 15) // 16}", work, _x3("effi_conv2d_k5s2_bf16x3_f32"), _p(x), cin, _p(wpack.wx), _p(bias),
+                        cout, hin, win, act, _p(out), _stream()), "effi_conv2d_k5s2_bf16x3_f32")
+            return out
+        wpack = wpack.w32
     check(_call(f"conv2d_k5s2_nt{(cout + 15) // 16}", work, _lib.lib().effi_conv2d_k5s2_f32, _p(x), cin, _p(wpack), _p(bias), cout,
                 hin, win, act, _p(out), _stream()), "effi_conv2d_k5s2_f32")
     return out

@@ -350,12 +350,38 @@ class Conv2dWeights:
         self.w32, self.wx = w32, wx
 
 
+def pack_conv2d_k5s2_bf16x3(weight, bias, scale=1.0):
+    """[cout, cin, 5, 5] (+bias) for ``effi_conv2d_k5s2_bf16x3_f32``: chunks of 8 input channels, K item = tap ky*5 + kx (25 items,
+    7 K-steps), output tiles in groups of NT (1 if cout <= 16 else 2).  -> (bf16 [ceil(cin/8), G, 7, NT, 2(hi|lo), 64, 8],
+    bias fp32 [16 * NT * G])."""
+    cout, cin, ks, _ = weight.shape
+    assert ks == 5
+    nt = 1 if cout <= 16 else 2
+    g = (cout + 16 * nt - 1) // (16 * nt)
+    nch = (cin + 7) // 8
+    w = torch.zeros(g * nt * 16, nch * 8, 28, device=weight.device, dtype=torch.float32)      # [co, ci, tap]
+    w[:cout, :cin, :25] = weight.reshape(cout, cin, 25).float() * scale
+    # [g, n, j, chunk, e, s, q] -> [chunk, g, s, n, q, j, e]
+    w = w.view(g, nt, 16, nch, 8, 7, 4).permute(3, 0, 5, 1, 6, 2, 4).contiguous()
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    wp = torch.stack([hi, lo], dim=4).contiguous().view(nch, g, 7, nt, 2, 64, 8)
+    b = torch.zeros(g * nt * 16, device=weight.device, dtype=torch.float32)
+    if bias is not None:
+        b[:cout] = bias.float() * scale
+    return wp, b
+
+
 def pack_conv2d(weight, bias, scale=1.0):
     """-> (Conv2dWeights, bias [16*NT]) for ``ops.conv2d``."""
     w32, b = pack_conv2d_mfma(weight, bias, scale)
     wx = None
     if weight.shape[2] == 3 and weight.shape[0] > 1:
         wx, _ = pack_conv2d_bf16x3(weight, bias, scale)
+    elif weight.shape[2] == 5:
+        wx, bx = pack_conv2d_k5s2_bf16x3(weight, bias, scale)      # the stride-2 pyramid layers in split precision
+        if bx.numel() > b.numel():                                 # groups of two output tiles: the longer zero-padded bias serves both
+            b = bx
     return Conv2dWeights(w32, wx), b
 
 

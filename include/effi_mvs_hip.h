@@ -165,6 +165,13 @@ int effi_conv2d_k3_bf16x3_pair_f32(const float* const* srcs_a, const int* src_ch
                                    const float* bias_a, float* out_a, const float* const* srcs_b,
                                    const int* src_channels_b, int n_src_b, const void* wpack_b, const float* bias_b,
                                    float* out_b, int cout, int h, int w, int act, effi_stream_t stream);
+/* 5x5 / stride 2 / padding 2 convolution (+bias, activation) in split precision: the pyramid's down-sampling layers
+ * (models/module.py:359,365,370), same contract as effi_conv2d_k5s2_f32 with win % 4 == 0.  wpack_bf16 =
+ * [ceil(cin/8)][G][7][NT][hi|lo][64][8] bf16 with G = groups of NT output tiles (NT = 1 for cout <= 16, else 2; G = ceil(cout/32)),
+ * K item = tap ky*5 + kx of an 8-channel chunk, lane = q*16 + j holds W[16(g NT + n) + j][8 chunk + e][tap = 4 s + q]
+ * (packing.pack_conv2d_k5s2_bf16x3); bias padded to 16 * NT * G. */
+int effi_conv2d_k5s2_bf16x3_f32(const float* in, int cin, const void* wpack_bf16, const float* bias, int cout, int hin, int win,
+                                int act, float* out, effi_stream_t stream);
 /* Two chained 3x3 convolutions with ReLU after each, at most 8 channels into each (the pyramid's full-resolution block conv0 =
  * Conv2d(3, 8) -> Conv2d(8, 8) with BatchNorm folded, models/module.py:353-356), in one kernel: the 8-channel intermediate map
  * stays in LDS (first layer computed on each 16 x 16 tile grown by one pixel).  in [cin][h][w], cin <= 8; both layers have at most 8
@@ -510,6 +517,8 @@ int effi_conv2d_k3_k1_bf16x3_f32_bf16(const float* const* srcs, const int* src_c
                                  const float* bias, int cout1, int relu1, const float* extra, int c_extra,
                                  const void* w2pack_bf16, const float* bias2, int cout2, int relu, int h, int w, float* out,
                                  effi_stream_t stream);
+int effi_conv2d_k5s2_bf16x3_f32_bf16(const float* in, int cin, const void* wpack_bf16, const float* bias, int cout, int hin, int win,
+                                int act, float* out, effi_stream_t stream);
 int effi_conv2d_k3_twice_bf16x3_f32_bf16(const float* in, int cin, const void* w1_bf16, const float* bias1, const void* w2_bf16,
                                     const float* bias2, int cout, int h, int w, float* out, effi_stream_t stream);
 int effi_encoder_tail_bf16x3_f32_bf16(const float* cor1, const float* dfm1, int hd, const void* wc2_bf16, const float* bias_c2,

@@ -944,6 +944,29 @@ def test_conv3x3_twice_in_one_kernel(h, w, cin, cout):
     check_close(f"3x3 twice vs two launches {cin}->{cmid}->{cout} {h}x{w}", got, two.cpu(), rtol=0.0, atol=2e-5 * float(want.abs().max()))
 
 
+@pytest.mark.parametrize("hin,win", [(8, 8), (37, 52), (74, 100), (96, 520)])
+@pytest.mark.parametrize("cin,cout", [(8, 16), (16, 32), (32, 64), (4, 8), (3, 24)])
+def test_conv5x5_stride2_split_precision(hin, win, cin, cout):
+    """effi_conv2d_k5s2_bf16x3_f32 (column parities de-interleaved in LDS, 8-channel chunks, groups of two output tiles) against torch
+    on the CPU and against the fp32-MFMA kernel; odd heights, maps smaller than a tile, cin not a multiple of 8."""
+    from effi_mvs_plus_amd import ops, packing
+    g = torch.Generator().manual_seed(hin * 3 + cin)
+    x = torch.randn(cin, hin, win, generator=g)
+    wt, b = torch.randn(cout, cin, 5, 5, generator=g) * 0.1, torch.randn(cout, generator=g) * 0.1
+    want = F.relu(F.conv2d(x[None], wt, b, stride=2, padding=2))[0]
+    wp, bp = packing.pack_conv2d(t(wt, DEV), t(b, DEV))
+    before = ops.get_precision()
+    try:
+        ops.set_precision("split")
+        got = ops.conv2d_k5s2(t(x, DEV), wp, bp, cout, act=ops.ACT_RELU)
+        ops.set_precision("fp32")
+        ref = ops.conv2d_k5s2(t(x, DEV), wp, bp, cout, act=ops.ACT_RELU)
+    finally:
+        ops.set_precision(before)
+    check_close(f"5x5 s2 split {cin}->{cout} {hin}x{win}", got, want, **conv_tol("split", want, 1e-4, 2e-5, 1))
+    check_close(f"5x5 s2 fp32 {cin}->{cout} {hin}x{win}", ref, want, rtol=1e-4, atol=2e-5)
+
+
 def test_cpu_tensor_fails_loudly():
     from effi_mvs_plus_amd import ops
     from effi_mvs_plus_amd._lib import EffiLibraryError
