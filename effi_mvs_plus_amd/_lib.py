@@ -52,6 +52,8 @@ SIGNATURES = {
     "effi_resize_linear_f32": [_vp, _i, _i, _i, _i, _i, _vp, _vp],
     "effi_encoder_inputs_f32": [_vp, _vp, _i, _vp, _vp, _l, _l, _i, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp, _vp,
                                 _i, _vp, _vp, _vp],
+    "effi_encoder_inputs_bf16x3_f32": [_vp, _vp, _i, _vp, _vp, _l, _l, _i, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp, _vp,
+                                       _i, _vp, _vp, _vp],
     "effi_conv2d_k3_bf16x3_pair_f32": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "effi_conv2d_k3_k1_up2x_bf16x3_f32": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "effi_conv2d_k3_k1_bf16x3_f32": [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
@@ -59,6 +61,7 @@ SIGNATURES = {
     "effi_conv2d_k5s2_f32": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "effi_conv2d_k5s2_bf16x3_f32": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "effi_conv2d_c1k7_relu_f32": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "effi_conv2d_c1k7_relu_bf16x3_f32": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "effi_convex_upsample2x_f32": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "effi_compose_rel_proj_stages_f32": [_vp, _i, _i, _vp, _vp],
     "effi_split_tanh_relu_stages_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],

@@ -122,3 +122,94 @@ __device__ __forceinline__ void effi_c1k7_relu_tile(const float* __restrict__ in
 #pragma unroll
     for (int c = 0; c < CG; ++c) out[(c0 + c) * hw + pix] = fmaxf(acc[c / 2][c & 1], 0.0f);
 }
+
+// The same tile on the matrix cores in split precision (hi*hi + lo*hi + hi*lo on v_mfma_f32_16x16x32_bf16, fp32 accumulation): the
+// VALU form above issues 392 packed FMAs per pixel and 16 channels.  K = (ky, kx8): a lane quarter lk owns kernel row ky = 4 s + lk
+// in K-step s, its 8 K-values are 8 consecutive input columns of that row (kx = 0..6 and one zero weight; row 7 is all zero), read
+// from the fp32 LDS tile with 8 conflict-free ds_read_b32 and split in registers.  One workgroup computes ALL COUT channels of a
+// 32 x 8 pixel tile (16 row segments of 16 pixels, 4 per wave): the split input fragments are shared by the COUT / 16 output tiles.
+// Weight fragments are built once per workgroup from the fp32 [49][COUT] table.
+typedef float effi_f32x4_t __attribute__((ext_vector_type(4)));
+typedef float effi_f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 effi_bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 effi_bf16x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void effi_split8(const float (&x)[8], effi_bf16x8_t& hi, effi_bf16x8_t& lo) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const effi_f32x2_t v = {x[e], x[e + 1]};
+        const effi_bf16x2_t h2 = __builtin_convertvector(v, effi_bf16x2_t);
+        const effi_bf16x2_t l2 = __builtin_convertvector(v - __builtin_convertvector(h2, effi_f32x2_t), effi_bf16x2_t);
+        hi[e] = h2[0]; hi[e + 1] = h2[1];
+        lo[e] = l2[0]; lo[e + 1] = l2[1];
+    }
+}
+
+template <int COUT>
+__device__ __forceinline__ void effi_c1k7_relu_tile_x3(const float* __restrict__ in, const float* __restrict__ wgt,
+                                                       const float* __restrict__ bias, int h, int w, float* __restrict__ out,
+                                                       int bx, int by) {
+    constexpr int TXX = EFFI_C1K7_TX, TYY = EFFI_C1K7_TY, IWX = 40, IHY = TYY + 7, NT = COUT / 16;
+    static_assert(TXX == 32 && TYY == 8, "16 row segments of 16 pixels, 4 per wave");
+    __shared__ float tile[IHY * IWX];                      // rows y0-3 .. y0+TYY+3 (the extra row is multiplied by zero weights)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int x0 = bx * TXX, y0 = by * TYY;
+    for (int e = tid; e < IHY * IWX; e += 256) {
+        const int yy = e / IWX, xx = e - yy * IWX;
+        const int gy = y0 - 3 + yy, gx = x0 - 3 + xx;
+        tile[e] = (yy < IHY - 1 && gy >= 0 && gy < h && gx >= 0 && gx < w) ? in[(long)gy * w + gx] : 0.0f;
+    }
+    // weight fragments: lane (cout j = li, quarter lk) holds W[16 n + j][ky = 4 s + lk][kx = 0..7]
+    effi_bf16x8_t wh[2][NT], wl[2][NT];
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int ky = 4 * s_ + lk;
+            float wv8[8];
+#pragma unroll
+            for (int kx = 0; kx < 8; ++kx)
+                wv8[kx] = (ky < 7 && kx < 7) ? wgt[(ky * 7 + kx) * COUT + 16 * n + li] : 0.0f;
+            effi_split8(wv8, wh[s_][n], wl[s_][n]);
+        }
+    __syncthreads();
+    effi_f32x4_t acc[4][NT];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = effi_f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+    // segment m of wave wv: tile row 2 wv + (m >> 1), columns 16 (m & 1) .. + 15
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int ry = 2 * wv + (m >> 1), cx = 16 * (m & 1) + li;
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+            const float* row = tile + (ry + 4 * s_ + lk) * IWX + cx;
+            float x8[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x8[i] = row[i];
+            effi_bf16x8_t ah, al;
+            effi_split8(x8, ah, al);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s_][n], ah, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s_][n], ah, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s_][n], al, acc[m][n], 0, 0, 0);
+            }
+        }
+    }
+    const long hw = (long)h * w;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int y = y0 + 2 * wv + (m >> 1), x = x0 + 16 * (m & 1) + li;
+        if (y >= h || x >= w) continue;
+        const long pix = (long)y * w + x;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = 16 * n + 4 * lk + r;
+                out[co * hw + pix] = fmaxf(acc[m][n][r] + bias[co], 0.0f);
+            }
+    }
+}

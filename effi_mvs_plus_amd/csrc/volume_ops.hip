@@ -422,12 +422,17 @@ __global__ __launch_bounds__(TPB) void getcost_conv1x1_kernel(const GetcostConvA
 // relu(convd1(inv_depth)) (7x7, effi_c1k7_relu_tile), the rest are blocks of relu(convc1(GetCost(inv_depth))).  The two are
 // independent and each alone underfills the chip at the coarse stages; as two kernels on two streams they overlap as well,
 // but every fork / join of streams inside a captured graph costs ~5 / ~11 us of idle GPU (measured), nine times per view.
-template <int NQ, int COUT>
+// X3: the 7x7 tiles on the matrix cores in split precision (effi_c1k7_relu_tile_x3: one workgroup per pixel tile, all channels).
+template <int NQ, int COUT, bool X3 = false>
 __global__ __launch_bounds__(TPB) void encoder_inputs_kernel(const GetcostConvArgs g, const float* __restrict__ w7,
                                                              const float* __restrict__ b7, int h, int w,
                                                              float* __restrict__ out7, int gx, int gy, int n7) {
     const int b = blockIdx.x;
     if (b < n7) {
+        if (X3) {
+            effi_c1k7_relu_tile_x3<COUT>(g.inv_depth, w7, b7, h, w, out7, b % gx, b / gx);
+            return;
+        }
         const int bz = b / (gx * gy), r = b - bz * gx * gy;
         effi_c1k7_relu_tile<COUT>(g.inv_depth, w7, b7, h, w, out7, r % gx, r / gx, bz);
     } else {
@@ -677,28 +682,73 @@ extern "C" int effi_getcost_conv1x1_f32(const float* inv_depth, const float* dis
     return EFFI_OK;
 }
 
-extern "C" int effi_encoder_inputs_f32(const float* inv_depth, const float* disp_range, int n_range, const float* interval,
-                                       const float* cur_vol, long cds, long cps, int Dcur, const float* reg_vol, long rds,
-                                       long rps, int Dreg, const float* dmin, const float* dmax, long range_ps, int nq, int h,
-                                       int w, const float* weight_c1, const float* bias_c1, const float* weight_d1,
-                                       const float* bias_d1, int cout, float* out_c1, float* out_d1, effi_stream_t stream) {
+static int encoder_inputs_launch(bool x3, const float* inv_depth, const float* disp_range, int n_range, const float* interval,
+                                 const float* cur_vol, long cds, long cps, int Dcur, const float* reg_vol, long rds,
+                                 long rps, int Dreg, const float* dmin, const float* dmax, long range_ps, int nq, int h,
+                                 int w, const float* weight_c1, const float* bias_c1, const float* weight_d1,
+                                 const float* bias_d1, int cout, float* out_c1, float* out_d1, effi_stream_t stream) {
     if (!inv_depth || !interval || !cur_vol || !reg_vol || !dmin || !dmax || !weight_c1 || !bias_c1 || !weight_d1 || !bias_d1 ||
         !out_c1 || !out_d1 || !disp_range || n_range < 2)
         return EFFI_ERR_BADARG;
     if (Dcur < 2 || Dreg < 2 || h < 1 || w < 1) return EFFI_ERR_BADARG;
     if (nq != 3 || (cout != 16 && cout != 32 && cout != 48)) return EFFI_ERR_UNSUPPORTED;
-    const int gx = effi_cdiv(w, EFFI_C1K7_TX), gy = effi_cdiv(h, EFFI_C1K7_TY), n7 = gx * gy * (cout / 16);
+    const int gx = effi_cdiv(w, EFFI_C1K7_TX), gy = effi_cdiv(h, EFFI_C1K7_TY), n7 = gx * gy * (x3 ? 1 : cout / 16);
     const dim3 grid(n7 + effi_cdiv((long)h * w, TPB));
     hipStream_t st = effi_s(stream);
     const GetcostConvArgs g{inv_depth, disp_range, n_range, 0, interval, cur_vol, cds, cps, Dcur, reg_vol, rds, rps,
                             Dreg, dmin, dmax, range_ps, h * w, weight_c1, bias_c1, cout, 1, out_c1};
-#define EFFI_EI(CO) hipLaunchKernelGGL((encoder_inputs_kernel<3, CO>), grid, dim3(TPB), 0, st, g, weight_d1, bias_d1, h, w, out_d1, gx, gy, n7)
+#define EFFI_EI(CO)                                                                                                                     \
+    do {                                                                                                                                \
+        if (x3) hipLaunchKernelGGL((encoder_inputs_kernel<3, CO, true>), grid, dim3(TPB), 0, st, g, weight_d1, bias_d1, h, w, out_d1, gx, gy, n7);  \
+        else hipLaunchKernelGGL((encoder_inputs_kernel<3, CO, false>), grid, dim3(TPB), 0, st, g, weight_d1, bias_d1, h, w, out_d1, gx, gy, n7);    \
+    } while (0)
     switch (cout) {
         case 16: EFFI_EI(16); break;
         case 32: EFFI_EI(32); break;
         default: EFFI_EI(48); break;
     }
 #undef EFFI_EI
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_encoder_inputs_f32(const float* inv_depth, const float* disp_range, int n_range, const float* interval,
+                                       const float* cur_vol, long cds, long cps, int Dcur, const float* reg_vol, long rds,
+                                       long rps, int Dreg, const float* dmin, const float* dmax, long range_ps, int nq, int h,
+                                       int w, const float* weight_c1, const float* bias_c1, const float* weight_d1,
+                                       const float* bias_d1, int cout, float* out_c1, float* out_d1, effi_stream_t stream) {
+    return encoder_inputs_launch(false, inv_depth, disp_range, n_range, interval, cur_vol, cds, cps, Dcur, reg_vol, rds, rps, Dreg, dmin,
+                                 dmax, range_ps, nq, h, w, weight_c1, bias_c1, weight_d1, bias_d1, cout, out_c1, out_d1, stream);
+}
+
+extern "C" int effi_encoder_inputs_bf16x3_f32(const float* inv_depth, const float* disp_range, int n_range, const float* interval,
+                                              const float* cur_vol, long cds, long cps, int Dcur, const float* reg_vol, long rds,
+                                              long rps, int Dreg, const float* dmin, const float* dmax, long range_ps, int nq, int h,
+                                              int w, const float* weight_c1, const float* bias_c1, const float* weight_d1,
+                                              const float* bias_d1, int cout, float* out_c1, float* out_d1, effi_stream_t stream) {
+    return encoder_inputs_launch(true, inv_depth, disp_range, n_range, interval, cur_vol, cds, cps, Dcur, reg_vol, rds, rps, Dreg, dmin,
+                                 dmax, range_ps, nq, h, w, weight_c1, bias_c1, weight_d1, bias_d1, cout, out_c1, out_d1, stream);
+}
+
+namespace {
+template <int COUT>
+__global__ __launch_bounds__(TPB) void conv2d_c1k7_relu_x3_kernel(const float* __restrict__ in, const float* __restrict__ wgt,
+                                                                  const float* __restrict__ bias, int h, int w, float* __restrict__ out) {
+    effi_c1k7_relu_tile_x3<COUT>(in, wgt, bias, h, w, out, blockIdx.x, blockIdx.y);
+}
+}  // namespace
+
+extern "C" int effi_conv2d_c1k7_relu_bf16x3_f32(const float* in, const float* weight, const float* bias, int cout, int h, int w,
+                                                float* out, effi_stream_t stream) {
+    if (!in || !weight || !bias || !out || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    const dim3 grid(effi_cdiv(w, EFFI_C1K7_TX), effi_cdiv(h, EFFI_C1K7_TY));
+    hipStream_t st = effi_s(stream);
+    switch (cout) {
+        case 16: hipLaunchKernelGGL(conv2d_c1k7_relu_x3_kernel<16>, grid, dim3(TPB), 0, st, in, weight, bias, h, w, out); break;
+        case 32: hipLaunchKernelGGL(conv2d_c1k7_relu_x3_kernel<32>, grid, dim3(TPB), 0, st, in, weight, bias, h, w, out); break;
+        case 48: hipLaunchKernelGGL(conv2d_c1k7_relu_x3_kernel<48>, grid, dim3(TPB), 0, st, in, weight, bias, h, w, out); break;
+        default: return EFFI_ERR_UNSUPPORTED;
+    }
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
 }

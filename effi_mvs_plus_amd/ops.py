@@ -803,10 +803,13 @@ def encoder_inputs(x, disp_range, interval, cur_vol, reg_vol, dmin, dmax, nq, h,
     if out_d1 is None:
         out_d1 = torch.empty(cout, h, w, device=x.device, dtype=torch.float32)
     work = lambda: {"flops": 2.0 * h * w * (2 * nq + 49) * cout, "bytes": 4.0 * h * w * (2 * cout + 1 + Dc + Dr)}
-    check(_call("encoder_inputs", work, _lib.lib().effi_encoder_inputs_f32, _p(x), _p(disp_range), disp_range.numel(),
+    # split / bf16 precision: the 7x7 half on the matrix cores (EFFI_C1K7_MFMA=0: the exact-fp32 vector form, as "fp32" precision uses)
+    x3 = uses_split() and os.environ.get("EFFI_C1K7_MFMA", "1") != "0"
+    fn = _lib.lib().effi_encoder_inputs_bf16x3_f32 if x3 else _lib.lib().effi_encoder_inputs_f32
+    check(_call("encoder_inputs", work, fn, _p(x), _p(disp_range), disp_range.numel(),
                 _p(interval), _p(cur_vol), cds, cps, Dc, _p(reg_vol), rds, rps, Dr, _p(dmin_t), _p(dmax_t), gps, nq, h, w,
                 _p(weight_c1), _p(bias_c1), _p(weight_d1), _p(bias_d1), cout, _p(out_c1), _p(out_d1), _stream()),
-          "effi_encoder_inputs_f32")
+          "effi_encoder_inputs_bf16x3_f32" if x3 else "effi_encoder_inputs_f32")
     return out_c1, out_d1
 
 
@@ -988,6 +991,10 @@ def conv2d_c1k7_relu(x, weight, bias, cout, out=None):
     h, w = x.shape[-2:]
     if out is None:
         out = torch.empty(cout, h, w, device=x.device, dtype=torch.float32)
+    if uses_split() and os.environ.get("EFFI_C1K7_MFMA", "1") != "0":
+        check(_lib.lib().effi_conv2d_c1k7_relu_bf16x3_f32(_p(x), _p(weight), _p(bias), cout, h, w, _p(out), _stream()),
+              "effi_conv2d_c1k7_relu_bf16x3_f32")
+        return out
     check(_lib.lib().effi_conv2d_c1k7_relu_f32(_p(x), _p(weight), _p(bias), cout, h, w, _p(out), _stream()),
           "effi_conv2d_c1k7_relu_f32")
     return out

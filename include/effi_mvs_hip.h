@@ -286,6 +286,14 @@ int effi_encoder_inputs_f32(const float* inv_depth, const float* disp_range, int
                             const float* dmin, const float* dmax, long range_pstride, int nq, int h, int w,
                             const float* weight_c1, const float* bias_c1, const float* weight_d1, const float* bias_d1,
                             int cout, float* out_c1, float* out_d1, effi_stream_t stream);
+/* The same with the 7x7 convolution on the matrix cores in split precision (hi*hi + lo*hi + hi*lo bf16 MFMAs, fp32 accumulation; one
+ * workgroup per 32 x 8 pixel tile computes all channels): what the default ("split") precision uses. */
+int effi_encoder_inputs_bf16x3_f32(const float* inv_depth, const float* disp_range, int n_range, const float* interval,
+                            const float* cur_vol, long cur_dstride, long cur_pstride, int Dcur,
+                            const float* reg_vol, long reg_dstride, long reg_pstride, int Dreg,
+                            const float* dmin, const float* dmax, long range_pstride, int nq, int h, int w,
+                            const float* weight_c1, const float* bias_c1, const float* weight_d1, const float* bias_d1,
+                            int cout, float* out_c1, float* out_d1, effi_stream_t stream);
 
 /* ---- K9: 2-D convolutions of the update block on the fp32 MFMA path (v_mfma_f32_16x16x4_f32).
  * models/update.py:14-15,36-38,73-81,109-112.  ks in {1,3}, padding ks/2, stride 1.
@@ -317,6 +325,9 @@ int effi_conv2d_k5s2_f32(const float* in, int cin, const float* wpack, const flo
 /* 7x7, one input channel (convd1, models/update.py:76,90): in [h][w]; weight [49][cout]
  * (host-packed), bias [cout]; out planar [cout][h][w] = relu(conv + bias).  cout in {16,32,48}. */
 int effi_conv2d_c1k7_relu_f32(const float* in, const float* weight, const float* bias, int cout,
+                              int h, int w, float* out, effi_stream_t stream);
+/* The same on the matrix cores in split precision (see effi_encoder_inputs_bf16x3_f32). */
+int effi_conv2d_c1k7_relu_bf16x3_f32(const float* in, const float* weight, const float* bias, int cout,
                               int h, int w, float* out, effi_stream_t stream);
 
 /* ---- K10: convex upsampling x2 (upsample_depth, models/Effi_MVS_plus.py:167-178) fused with
