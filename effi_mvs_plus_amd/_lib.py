@@ -74,11 +74,11 @@ SIGNATURES = {
     "effi_encoder_tail_bf16x3_f32": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp],
     # scope row n2: training kernels
     "effi_conv_wgrad_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
-    "effi_channel_sum_f32": [_vp, _i, _i, _l, _vp, _vp],
+    "effi_channel_sum_f32": [_vp, _i, _i, _l, _vp, _vp, _i, _vp],
     "effi_conv2d_k5s2_dgrad_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
-    "effi_bn_moment_f32": [_vp, _i, _i, _l, _vp, _i, _vp, _vp],
+    "effi_bn_moment_f32": [_vp, _i, _i, _l, _vp, _i, _vp, _vp, _i, _vp],
     "effi_bn_apply_f32": [_vp, _i, _i, _l, _vp, _vp, _vp, _vp, _i, _vp, _vp],
-    "effi_bn_bwd_f32": [_vp, _vp, _vp, _i, _i, _l, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "effi_bn_bwd_f32": [_vp, _vp, _vp, _i, _i, _l, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "effi_pointwise_f32": [_i, _vp, _vp, _vp, _vp, _f, _f, _l, _l, _i, _vp, _vp, _vp, _vp],
     "effi_vol_lookup1d_bwd_f32": [_vp, _l, _l, _i, _vp, _l, _l, _l, _i, _vp, _vp, _l, _i, _i, _vp, _vp],
     "effi_getcost_bwd_f32": [_vp, _vp, _i, _i, _vp, _vp, _l, _l, _i, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _vp, _vp],

@@ -88,7 +88,8 @@ __global__ __launch_bounds__(TPB) void wgrad_nd_kernel(const float* __restrict__
 }
 
 // per-channel sums of a [B][C][n] tensor (bias gradients): out[c] += sum_{b,i} g[b][c][i]
-__global__ __launch_bounds__(TPB) void channel_sum_kernel(const float* __restrict__ g, int Bn, int C, long n, float* __restrict__ out) {
+__global__ __launch_bounds__(TPB) void channel_sum_kernel(const float* __restrict__ g, int Bn, int C, long n, float* __restrict__ out,
+                                                          float* __restrict__ partial) {
     const int c = blockIdx.x;
     const long total = (long)Bn * n;
     const long per = (total + gridDim.y - 1) / gridDim.y;
@@ -102,7 +103,28 @@ __global__ __launch_bounds__(TPB) void channel_sum_kernel(const float* __restric
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(&out[c], red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        const float t = red[0] + red[1] + red[2] + red[3];
+        if (partial) partial[(long)c * gridDim.y + blockIdx.y] = t;
+        else out[c] += t;                                   // one workgroup per channel
+    }
+}
+
+// Second stage of the split reductions: out_k[c] += sum_j partial[(c * nsplit + j) * K + k], j in ascending order -- a fixed order,
+// so the result does not depend on which workgroup finished first (with atomics, WHICH activations sit on a ReLU kink differed
+// between runs of the same training step).
+template <int K>
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, int C, int nsplit, float* __restrict__ out0,
+                                       float* __restrict__ out1) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        float s = 0.0f;
+        for (int j = 0; j < nsplit; ++j) s += partial[((long)c * nsplit + j) * K + k];
+        if (k == 0) out0[c] += s;
+        else out1[c] += s;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -111,7 +133,7 @@ __global__ __launch_bounds__(TPB) void channel_sum_kernel(const float* __restric
 // out[c] += sum (x - shift[c])^P over batch and positions (P = 1 with shift = nullptr: the sum; P = 2 with shift = mean)
 template <int P>
 __global__ __launch_bounds__(TPB) void bn_moment_kernel(const float* __restrict__ x, int Bn, int C, long n, const float* __restrict__ shift,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, float* __restrict__ partial) {
     const int c = blockIdx.x;
     const long total = (long)Bn * n;
     const long per = (total + gridDim.y - 1) / gridDim.y;
@@ -127,7 +149,11 @@ __global__ __launch_bounds__(TPB) void bn_moment_kernel(const float* __restrict_
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(&out[c], red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        const float t = red[0] + red[1] + red[2] + red[3];
+        if (partial) partial[(long)c * gridDim.y + blockIdx.y] = t;
+        else out[c] += t;
+    }
 }
 
 // y = (x - mean) * invstd * gamma + beta, then ReLU if asked
@@ -147,7 +173,7 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__
 __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                             const float* __restrict__ x, int Bn, int C, long n,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
-                                                            float* __restrict__ s1, float* __restrict__ s2) {
+                                                            float* __restrict__ s1, float* __restrict__ s2, float* __restrict__ partial) {
     const int c = blockIdx.x;
     const long total = (long)Bn * n;
     const long per = (total + gridDim.y - 1) / gridDim.y;
@@ -168,8 +194,14 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const float* __restr
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsafeAtomicAdd(&s1[c], red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-        unsafeAtomicAdd(&s2[c], red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        const float t1 = red[0][0] + red[0][1] + red[0][2] + red[0][3], t2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        if (partial) {
+            partial[((long)c * gridDim.y + blockIdx.y) * 2 + 0] = t1;
+            partial[((long)c * gridDim.y + blockIdx.y) * 2 + 1] = t2;
+        } else {
+            s1[c] += t1;
+            s2[c] += t2;
+        }
     }
 }
 
@@ -377,10 +409,6 @@ __global__ void convex_upsample2x_bwd_kernel(const float* __restrict__ inv, cons
     }
 }
 
-// One workgroup per channel: the reduction order is fixed, so the training FORWARD (BatchNorm statistics) is bitwise repeatable from
-// run to run -- with several workgroups adding atomically, WHICH activations sit on a ReLU kink differed between runs.
-int split_for(long) { return 1; }
-
 }  // namespace
 
 // ================================================================================================
@@ -405,19 +433,31 @@ extern "C" int effi_conv_wgrad_f32(const float* a, const float* b, int ca, int c
     return EFFI_OK;
 }
 
-extern "C" int effi_channel_sum_f32(const float* g, int B, int C, long n, float* out, effi_stream_t stream) {
+// Split reductions: nsplit workgroups per channel write partial sums to ``scratch`` ([C][nsplit][K] floats, caller-owned) and a second
+// tiny launch adds them in a fixed order; scratch == NULL or nsplit <= 1: one workgroup per channel.  Either way the order of the
+// additions is fixed: a training step's BatchNorm statistics are bitwise repeatable.
+static int effi_nsplit(const float* scratch, int nsplit) { return (scratch && nsplit > 1) ? (nsplit > 1024 ? 1024 : nsplit) : 1; }
+
+extern "C" int effi_channel_sum_f32(const float* g, int B, int C, long n, float* out, float* scratch, int nsplit, effi_stream_t stream) {
     if (!g || !out || B < 1 || C < 1 || n < 1) return EFFI_ERR_BADARG;
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, split_for((long)B * n)), dim3(TPB), 0, effi_s(stream), g, B, C, n, out);
+    const int ns = effi_nsplit(scratch, nsplit);
+    hipStream_t s = effi_s(stream);
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(C, ns), dim3(TPB), 0, s, g, B, C, n, out, ns > 1 ? scratch : nullptr);
+    if (ns > 1) hipLaunchKernelGGL(reduce_partials_kernel<1>, dim3((C + 63) / 64), dim3(64), 0, s, scratch, C, ns, out, out);
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
 }
 
-extern "C" int effi_bn_moment_f32(const float* x, int B, int C, long n, const float* shift, int power, float* out,
-                                  effi_stream_t stream) {
+extern "C" int effi_bn_moment_f32(const float* x, int B, int C, long n, const float* shift, int power, float* out, float* scratch,
+                                  int nsplit, effi_stream_t stream) {
     if (!x || !out || B < 1 || C < 1 || n < 1 || (power != 1 && power != 2)) return EFFI_ERR_BADARG;
-    const dim3 grid(C, split_for((long)B * n));
-    if (power == 1) hipLaunchKernelGGL(bn_moment_kernel<1>, grid, dim3(TPB), 0, effi_s(stream), x, B, C, n, shift, out);
-    else hipLaunchKernelGGL(bn_moment_kernel<2>, grid, dim3(TPB), 0, effi_s(stream), x, B, C, n, shift, out);
+    const int ns = effi_nsplit(scratch, nsplit);
+    hipStream_t s = effi_s(stream);
+    const dim3 grid(C, ns);
+    float* part = ns > 1 ? scratch : nullptr;
+    if (power == 1) hipLaunchKernelGGL(bn_moment_kernel<1>, grid, dim3(TPB), 0, s, x, B, C, n, shift, out, part);
+    else hipLaunchKernelGGL(bn_moment_kernel<2>, grid, dim3(TPB), 0, s, x, B, C, n, shift, out, part);
+    if (ns > 1) hipLaunchKernelGGL(reduce_partials_kernel<1>, dim3((C + 63) / 64), dim3(64), 0, s, scratch, C, ns, out, out);
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
 }
@@ -434,11 +474,13 @@ extern "C" int effi_bn_apply_f32(const float* x, int B, int C, long n, const flo
 
 extern "C" int effi_bn_bwd_f32(const float* gy, const float* y, const float* x, int B, int C, long n, const float* mean,
                                const float* invstd, const float* gamma, int relu, float* s1, float* s2, float* gx,
-                               effi_stream_t stream) {
+                               float* scratch, int nsplit, effi_stream_t stream) {
     if (!gy || !y || !x || !mean || !invstd || !gamma || !s1 || !s2 || !gx || B < 1 || C < 1 || n < 1) return EFFI_ERR_BADARG;
     hipStream_t s = effi_s(stream);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, split_for((long)B * n)), dim3(TPB), 0, s, gy, y, x, B, C, n, mean, invstd, relu, s1,
-                       s2);
+    const int ns = effi_nsplit(scratch, nsplit);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, ns), dim3(TPB), 0, s, gy, y, x, B, C, n, mean, invstd, relu, s1, s2,
+                       ns > 1 ? scratch : nullptr);
+    if (ns > 1) hipLaunchKernelGGL(reduce_partials_kernel<2>, dim3((C + 63) / 64), dim3(64), 0, s, scratch, C, ns, s1, s2);
     const long total = (long)B * C * n;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)min((total + TPB - 1) / TPB, 16384L)), dim3(TPB), 0, s, gy, y, x, B, C, n, mean,
                        invstd, gamma, s1, s2, relu, gx);
