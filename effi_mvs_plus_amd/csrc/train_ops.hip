@@ -87,7 +87,7 @@ __global__ __launch_bounds__(TPB) void wgrad_nd_kernel(const float* __restrict__
     }
 }
 
-// per-channel sums of a [B][C][n] tensor (bias gradients): out[c] += sum_{b,i} g[b][c][i]
+// per-channel sums of a [B][C][n] tensor (bias gradients): out[c] = sum_{b,i} g[b][c][i]
 __global__ __launch_bounds__(TPB) void channel_sum_kernel(const float* __restrict__ g, int Bn, int C, long n, float* __restrict__ out,
                                                           float* __restrict__ partial) {
     const int c = blockIdx.x;
@@ -106,11 +106,11 @@ __global__ __launch_bounds__(TPB) void channel_sum_kernel(const float* __restric
     if (threadIdx.x == 0) {
         const float t = red[0] + red[1] + red[2] + red[3];
         if (partial) partial[(long)c * gridDim.y + blockIdx.y] = t;
-        else out[c] += t;                                   // one workgroup per channel
+        else out[c] = t;                                    // one workgroup per channel
     }
 }
 
-// Second stage of the split reductions: out_k[c] += sum_j partial[(c * nsplit + j) * K + k], j in ascending order -- a fixed order,
+// Second stage of the split reductions: out_k[c] = sum_j partial[(c * nsplit + j) * K + k], j in ascending order -- a fixed order,
 // so the result does not depend on which workgroup finished first (with atomics, WHICH activations sit on a ReLU kink differed
 // between runs of the same training step).
 template <int K>
@@ -122,15 +122,15 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int C,
     for (int k = 0; k < K; ++k) {
         float s = 0.0f;
         for (int j = 0; j < nsplit; ++j) s += partial[((long)c * nsplit + j) * K + k];
-        if (k == 0) out0[c] += s;
-        else out1[c] += s;
+        if (k == 0) out0[c] = s;
+        else out1[c] = s;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // BatchNorm, training mode (nn.BatchNorm2d / 3d on batch statistics; models/module.py:148-157,191-200,217-220)
 // ------------------------------------------------------------------------------------------------
-// out[c] += sum (x - shift[c])^P over batch and positions (P = 1 with shift = nullptr: the sum; P = 2 with shift = mean)
+// out[c] = sum (x - shift[c])^P over batch and positions (P = 1 with shift = nullptr: the sum; P = 2 with shift = mean)
 template <int P>
 __global__ __launch_bounds__(TPB) void bn_moment_kernel(const float* __restrict__ x, int Bn, int C, long n, const float* __restrict__ shift,
                                                         float* __restrict__ out, float* __restrict__ partial) {
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(TPB) void bn_moment_kernel(const float* __restrict_
     if (threadIdx.x == 0) {
         const float t = red[0] + red[1] + red[2] + red[3];
         if (partial) partial[(long)c * gridDim.y + blockIdx.y] = t;
-        else out[c] += t;
+        else out[c] = t;
     }
 }
 
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__
     }
 }
 
-// s1[c] += sum g', s2[c] += sum g' * xhat, with g' = gy masked by the ReLU (y > 0) and xhat = (x - mean) * invstd
+// s1[c] = sum g', s2[c] = sum g' * xhat, with g' = gy masked by the ReLU (y > 0) and xhat = (x - mean) * invstd
 __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                             const float* __restrict__ x, int Bn, int C, long n,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
@@ -199,8 +199,8 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const float* __restr
             partial[((long)c * gridDim.y + blockIdx.y) * 2 + 0] = t1;
             partial[((long)c * gridDim.y + blockIdx.y) * 2 + 1] = t2;
         } else {
-            s1[c] += t1;
-            s2[c] += t2;
+            s1[c] = t1;
+            s2[c] = t2;
         }
     }
 }

@@ -1126,9 +1126,9 @@ def conv2d_k5s2_dgrad(grad_out, weight, hin, win):
 
 
 def _reduce_split(total, channels, k=1, device=None):
-    """Workgroups per channel of the split per-channel reductions and their scratch ([C][nsplit][k] floats): ~16 K elements per
-    workgroup, at most 64 per channel, none when the tensor is small.  The partial sums are added in a fixed order (second launch)."""
-    nsplit = int(min(64, max(1, total // 16384)))
+    """Workgroups per channel of the split per-channel reductions and their scratch ([C][nsplit][k] floats): ~8 K elements per
+    workgroup, at most 256 per channel, none when the tensor is small.  The partial sums are added in a fixed order (second launch)."""
+    nsplit = int(min(256, max(1, total // 8192)))
     if nsplit <= 1:
         return None, 1
     return torch.empty(channels * nsplit * k, device=device, dtype=torch.float32), nsplit
@@ -1139,7 +1139,7 @@ def channel_sum(g):
     _t(g, "channel_sum input")
     B, Cc = g.shape[0], g.shape[1]
     n = g.numel() // (B * Cc)
-    out = torch.zeros(Cc, device=g.device, dtype=torch.float32)
+    out = torch.empty(Cc, device=g.device, dtype=torch.float32)
     scratch, nsplit = _reduce_split(B * n, Cc, 1, g.device)
     check(_lib.lib().effi_channel_sum_f32(_p(g), B, Cc, n, _p(out), _p(scratch), nsplit, _stream()), "effi_channel_sum_f32")
     return out
@@ -1150,11 +1150,11 @@ def bn_moments(x):
     _t(x, "bn input")
     B, Cc = x.shape[0], x.shape[1]
     n = x.numel() // (B * Cc)
-    mean = torch.zeros(Cc, device=x.device, dtype=torch.float32)
+    mean = torch.empty(Cc, device=x.device, dtype=torch.float32)
     scratch, nsplit = _reduce_split(B * n, Cc, 1, x.device)
     check(_lib.lib().effi_bn_moment_f32(_p(x), B, Cc, n, None, 1, _p(mean), _p(scratch), nsplit, _stream()), "effi_bn_moment_f32")
     mean = mean / float(B * n)
-    var = torch.zeros(Cc, device=x.device, dtype=torch.float32)
+    var = torch.empty(Cc, device=x.device, dtype=torch.float32)
     check(_lib.lib().effi_bn_moment_f32(_p(x), B, Cc, n, _p(mean), 2, _p(var), _p(scratch), nsplit, _stream()), "effi_bn_moment_f32")
     return mean, var / float(B * n)
 
@@ -1172,8 +1172,8 @@ def bn_bwd(gy, y, x, mean, invstd, gamma, relu):
     """-> (gx, s1 = grad beta, s2 = grad gamma)."""
     _t(gy, "bn grad"), _t(y, "bn output"), _t(x, "bn input")
     B, Cc = x.shape[0], x.shape[1]
-    s1 = torch.zeros(Cc, device=x.device, dtype=torch.float32)
-    s2 = torch.zeros(Cc, device=x.device, dtype=torch.float32)
+    s1 = torch.empty(Cc, device=x.device, dtype=torch.float32)
+    s2 = torch.empty(Cc, device=x.device, dtype=torch.float32)
     gx = torch.empty_like(x)
     n = x.numel() // (B * Cc)
     scratch, nsplit = _reduce_split(B * n, Cc, 2, x.device)

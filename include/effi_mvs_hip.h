@@ -449,16 +449,16 @@ int effi_conv_wgrad_f32(const float* a, const float* b, int ca, int cb, int cb_t
  * training): grad_out planar [cout][ceil(hin/2)][ceil(win/2)], weight torch layout [cout][cin][5][5] -> grad_in planar [cin][hin][win]. */
 int effi_conv2d_k5s2_dgrad_f32(const float* grad_out, const float* weight, int cin, int cout, int hin, int win, float* grad_in,
                                effi_stream_t stream);
-/* out[c] += sum over batch and positions of g [B][C][n]  (bias gradients).  The per-channel reductions of this section take a
+/* out[c] = sum over batch and positions of g [B][C][n]  (bias gradients; out is overwritten).  The per-channel reductions of this section take a
  * caller-owned ``scratch`` ([C][nsplit][K] floats; K = 1, 2 for effi_bn_bwd_f32) and ``nsplit``: nsplit workgroups per channel write
  * partial sums and a second small launch adds them in ascending order; scratch == NULL or nsplit <= 1: one workgroup per channel.
  * No atomics either way: the results are bitwise repeatable. */
 int effi_channel_sum_f32(const float* g, int B, int C, long n, float* out, float* scratch, int nsplit, effi_stream_t stream);
 
 /* nn.BatchNorm2d / nn.BatchNorm3d on batch statistics (models/module.py:148-157,191-200,217-220), x planar [B][C][n]:
- *   effi_bn_moment_f32: out[c] += sum (x - shift[c])^power   (power 1 with shift = NULL: sum; power 2 with shift = mean);
+ *   effi_bn_moment_f32: out[c] = sum (x - shift[c])^power   (power 1 with shift = NULL: sum; power 2 with shift = mean);
  *   effi_bn_apply_f32:  y = (x - mean) * invstd * gamma + beta, then ReLU if relu != 0;
- *   effi_bn_bwd_f32:    s1[c] += sum g', s2[c] += sum g' * xhat (both zero on entry), then
+ *   effi_bn_bwd_f32:    s1[c] = sum g', s2[c] = sum g' * xhat (overwritten), then
  *                       gx = gamma * invstd * (g' - s1/N - xhat * s2/N), g' = gy masked by y > 0 when relu != 0.
  *                       (grad gamma = s2, grad beta = s1.) */
 int effi_bn_moment_f32(const float* x, int B, int C, long n, const float* shift, int power, float* out, float* scratch, int nsplit,
