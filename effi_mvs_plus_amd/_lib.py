@@ -60,6 +60,7 @@ SIGNATURES = {
     "effi_conv2d_k3_bf16x3_f32": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "effi_conv2d_k5s2_f32": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "effi_conv2d_k5s2_bf16x3_f32": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "effi_conv3d_k3s2_bf16x3_f32": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "effi_conv2d_c1k7_relu_f32": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "effi_conv2d_c1k7_relu_bf16x3_f32": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "effi_convex_upsample2x_f32": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
@@ -92,7 +93,7 @@ SIGNATURES = {
 BF16X3_ENTRIES = ("effi_conv2d_k3_bf16x3_pair_f32", "effi_conv2d_k3_bf16x3_f32", "effi_conv2d_k3_k1_bf16x3_f32",
                   "effi_conv2d_k3_k1_up2x_bf16x3_f32", "effi_conv3d_k3s1_bf16x3_f32", "effi_conv3d_k3s1_roll_bf16x3_f32",
                   "effi_conv3d_k3s1_roll_bf16x3_pair_f32", "effi_deconv3d_k3s2_bf16x3_f32", "effi_encoder_tail_bf16x3_f32", "effi_conv2d_k3_twice_bf16x3_f32",
-                  "effi_conv2d_k5s2_bf16x3_f32")
+                  "effi_conv2d_k5s2_bf16x3_f32", "effi_conv3d_k3s2_bf16x3_f32")
 for _n in BF16X3_ENTRIES:
     SIGNATURES[_n + "_bf16"] = SIGNATURES[_n]
 

@@ -2181,9 +2181,12 @@ extern "C" int effi_conv2d_k5s2_f32(const float* in, int cin, const float* wpack
 //     for every tap (slot = li + 1 + (kx >> 1) of parity kx & 1), conflict-free, although they are 2 input columns apart;
 //   * cout > 32 is split over blockIdx.y in groups of NT = 2 N-tiles (the weight fragments of a chunk are 14 KB per N-tile).
 namespace {
-template <int NT, int MR>
-__global__ __launch_bounds__(256) void conv2d_k5s2_bf16x3_kernel(const Conv2dArgs a, int tiles_x, int ntiles) {
-    constexpr int TR = 4 * MR, IR = 2 * TR + 3, NQ = 10, NSLOT = 20, NKS = 7;
+// KS = 3 with ZB: the stride-(2,2,2) 3-D convolution of the U-Net (conv2 / conv4) as z-batched stride-2 2-D convolutions: blockIdx.z =
+// output plane z, chunk = (input plane 2z + dz - 1, octet), 9 taps = 3 K-steps per chunk; a.cin = channels per plane.
+template <int KS, int NT, int MR, bool ZB>
+__global__ __launch_bounds__(256) void conv2d_s2_bf16x3_kernel(const Conv2dArgs a, int tiles_x, int ntiles) {
+    constexpr int PAD = KS / 2, NTAP = KS * KS;
+    constexpr int TR = 4 * MR, IR = 2 * TR + KS - 2, NQ = 10, NSLOT = 20, NKS = (NTAP + 3) / 4;
     constexpr int ROWE = 2 * NSLOT * 8;                                // bf16 elements per staged input row (both parities)
     constexpr int NITEMS = IR * NQ;                                    // (row, pixel quad) staging items
     constexpr int NIT = (NITEMS + 255) / 256;
@@ -2202,8 +2205,10 @@ __global__ __launch_bounds__(256) void conv2d_k5s2_bf16x3_kernel(const Conv2dArg
     const int x0 = (tile - ty_ * tiles_x) * 16, y0 = ty_ * TR;
     const int ng = blockIdx.y;                                         // group of NT output tiles
     const unsigned short* wbf = reinterpret_cast<const unsigned short*>(a.wpack);
-    const int nchunks = (a.cin + 7) >> 3;
+    const int noct = (a.cin + 7) >> 3;
+    const int nchunks = ZB ? 3 * noct : noct;
     const int ngroups = gridDim.y;
+    const int zpl = ZB ? blockIdx.z : 0;
 
     f32x4 pa[NIT][8];
     auto prefetch = [&](int ch) {
@@ -2211,11 +2216,14 @@ __global__ __launch_bounds__(256) void conv2d_k5s2_bf16x3_kernel(const Conv2dArg
         for (int it = 0; it < NIT; ++it) {
             const int item = tid + it * 256;
             const int r = item / NQ, q = item - r * NQ;
-            const int gy = 2 * y0 - 2 + r, gx = 2 * x0 - 4 + 4 * q;
-            const bool in = (item < NITEMS) & (gy >= 0) & (gy < hin) & (gx >= 0) & (gx < win);
-            const int cb = ch * 8;
+            const int gy = 2 * y0 - PAD + r, gx = 2 * x0 - 4 + 4 * q;
+            bool in = (item < NITEMS) & (gy >= 0) & (gy < hin) & (gx >= 0) & (gx < win);
+            const int dz = ZB ? ch / noct : 0;
+            const int cb = (ZB ? ch - dz * noct : ch) * 8;
+            const int zz = 2 * zpl + dz - 1;
+            if (ZB) in &= (zz >= 0) & (zz < a.zin);
             const int emax = min(a.cin - cb, 8) - 1;
-            const float* qp = in ? a.src[0] + ((long)cb * a.cstride + (long)gy * win + gx) : a.zeros;
+            const float* qp = in ? a.src[0] + ((long)cb * a.cstride + (ZB ? (long)zz * hin * win : 0L) + (long)gy * win + gx) : a.zeros;
             const long step = in ? a.cstride : 0;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -2253,9 +2261,10 @@ __global__ __launch_bounds__(256) void conv2d_k5s2_bf16x3_kernel(const Conv2dArg
     int koff[NKS];
 #pragma unroll
     for (int s_ = 0; s_ < NKS; ++s_) {
-        const int tap = min(4 * s_ + lk, 24);                           // items 25..27 are padding (B is zero there)
-        const int ky = tap / 5, kx = tap - ky * 5;
-        koff[s_] = ky * ROWE + ((kx & 1) * NSLOT + 1 + (kx >> 1)) * 8;
+        const int tap = min(4 * s_ + lk, NTAP - 1);                     // the items past the last tap are padding (B is zero there)
+        const int ky = tap / KS, kx = tap - ky * KS;
+        const int off = kx - PAD + 4;                                   // column offset from the aligned origin 2 x0 - 4 for pixel 0
+        koff[s_] = ky * ROWE + ((off & 1) * NSLOT + (off >> 1)) * 8;
     }
     const int lane_base = (2 * wv * MR) * ROWE + li * 8;
 
@@ -2306,21 +2315,22 @@ __global__ __launch_bounds__(256) void conv2d_k5s2_bf16x3_kernel(const Conv2dArg
         if (y >= h || x >= w) continue;
         const long pix = (long)y * w + x;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) conv_epilogue_store_t<EFFI_EPI_PLAIN>(a, acc[m][n], (ng * NT + n) * 16 + 4 * lk, pix, hw, 0);
+        for (int n = 0; n < NT; ++n) conv_epilogue_store_t<EFFI_EPI_PLAIN>(a, acc[m][n], (ng * NT + n) * 16 + 4 * lk, pix, hw, zpl);
     }
 }
 
 }  // namespace
 
-template <int NT>
-static int launch_k5s2_x3(const Conv2dArgs& a, int ngroups, hipStream_t st) {
+template <int KS, int NT, bool ZB>
+static int launch_s2_x3(const Conv2dArgs& a, int ngroups, hipStream_t st) {
     const int cols = effi_cdiv(a.w, 16);
-    if ((long)cols * effi_cdiv(a.h, 8) * ngroups >= 400) {
+    const unsigned planes = ZB ? (unsigned)a.zcount : 1u;
+    if ((long)cols * effi_cdiv(a.h, 8) * ngroups * planes >= 400) {
         const int ntiles = cols * effi_cdiv(a.h, 8);
-        hipLaunchKernelGGL((conv2d_k5s2_bf16x3_kernel<NT, 2>), dim3(ntiles, ngroups), dim3(256), 0, st, a, cols, ntiles);
+        hipLaunchKernelGGL((conv2d_s2_bf16x3_kernel<KS, NT, 2, ZB>), dim3(ntiles, ngroups, planes), dim3(256), 0, st, a, cols, ntiles);
     } else {
         const int ntiles = cols * effi_cdiv(a.h, 4);
-        hipLaunchKernelGGL((conv2d_k5s2_bf16x3_kernel<NT, 1>), dim3(ntiles, ngroups), dim3(256), 0, st, a, cols, ntiles);
+        hipLaunchKernelGGL((conv2d_s2_bf16x3_kernel<KS, NT, 1, ZB>), dim3(ntiles, ngroups, planes), dim3(256), 0, st, a, cols, ntiles);
     }
     return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
@@ -2357,8 +2367,44 @@ extern "C" int EFFI_FN(effi_conv2d_k5s2_bf16x3_f32)(const float* in, int cin, co
     a.zcount = a.zin = 0;
     hipStream_t st = effi_s(stream);
     const int nt = (cout + 15) / 16;
-    if (nt == 1) return launch_k5s2_x3<1>(a, 1, st);
-    return launch_k5s2_x3<2>(a, (nt + 1) / 2, st);           // weights packed in groups of two N-tiles (zero-padded)
+    if (nt == 1) return launch_s2_x3<5, 1, false>(a, 1, st);
+    return launch_s2_x3<5, 2, false>(a, (nt + 1) / 2, st);   // weights packed in groups of two N-tiles (zero-padded)
+}
+
+extern "C" int EFFI_FN(effi_conv3d_k3s2_bf16x3_f32)(const float* in, int cin, const void* wpack_bf16, const float* bias, int cout, int D,
+                                           int h, int w, int relu, float* out, effi_stream_t stream) {
+    if (!in || !wpack_bf16 || !bias || !out || cin < 1 || cout < 1 || D < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    if ((w & 3) || cout > 64) return EFFI_ERR_UNSUPPORTED;
+    Conv2dArgs a;
+    for (int i = 0; i < EFFI_MAX_SRC; ++i) {
+        a.src[i] = in;
+        a.ch[i] = (i == 0) ? cin : 0;
+    }
+    a.cin = cin;                                 // channels per input plane
+    a.kgroups = 0;
+    a.zeros = effi_zero_page();
+    if (!a.zeros) return EFFI_ERR_WORKSPACE;
+    a.wpack = reinterpret_cast<const float*>(wpack_bf16);
+    a.bias = bias;
+    a.cout = cout;
+    a.hin = h;
+    a.win = w;
+    a.h = (h - 1) / 2 + 1;
+    a.w = (w - 1) / 2 + 1;
+    a.zin = D;
+    a.zcount = (D - 1) / 2 + 1;
+    a.act = relu ? EFFI_ACT_RELU : EFFI_ACT_NONE;
+    a.hd = 0;
+    a.aux0 = a.aux1 = a.disp_range = nullptr;
+    a.n_range = 0;
+    a.out0 = out;
+    a.out1 = nullptr;
+    a.cstride = (long)D * h * w;
+    a.ostride = (long)a.zcount * a.h * a.w;
+    hipStream_t st = effi_s(stream);
+    const int nt = (cout + 15) / 16;
+    if (nt == 1) return launch_s2_x3<3, 1, true>(a, 1, st);
+    return launch_s2_x3<3, 2, true>(a, (nt + 1) / 2, st);
 }
 
 // ---- split-bf16 3x3 convolution entry --------------------------------------------------------------------------

@@ -58,6 +58,7 @@ class Conv3d(nn.Module):
         self._cache_planes = packing.PackCache()
         self._cache_planes_x3 = packing.PackCache()
         self._cache_roll = packing.PackCache()
+        self._cache_s2_x3 = packing.PackCache()
 
     def _packed(self):
         t = [self.conv.weight, self.conv.bias]
@@ -98,6 +99,15 @@ class Conv3d(nn.Module):
                 t += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
             wp, bp = self._cache_planes.get(t, lambda: packing.pack_conv3d_planes(self.conv, self.bn))
             return ops.conv3d_k3s1_mfma(srcs[0], wp, bp, self.out_channels, relu=self.relu)
+        if (len(srcs) == 1 and skip is None and _triple(self.conv.stride) == (2, 2, 2) and self.out_channels <= 64
+                and self.conv.in_channels >= 8 and srcs[0].shape[-1] % 4 == 0 and ops.uses_split()
+                and os.environ.get("EFFI_CONV3D_S2_SPLIT", "1") != "0"):
+            # down-sampling U-Net levels in split precision (column parities de-interleaved in LDS, as the pyramid's 5x5 stride-2 layers)
+            t = [self.conv.weight, self.conv.bias]
+            if self.bn is not None:
+                t += [self.bn.weight, self.bn.bias, self.bn.running_mean, self.bn.running_var]
+            wp, bp = self._cache_s2_x3.get(t, lambda: packing.pack_conv3d_s2_bf16x3(self.conv, self.bn))
+            return ops.conv3d_k3s2_x3(srcs[0], wp, bp, self.out_channels, relu=self.relu)
         if (len(srcs) == 1 and skip is None and _triple(self.conv.stride) == (2, 2, 2) and self.out_channels in (16, 32)
                 and self.conv.in_channels >= 8):
             # down-sampling U-Net levels: z-batched stride-2 2-D convolutions on the matrix cores

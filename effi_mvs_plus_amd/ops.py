@@ -515,6 +515,19 @@ def conv3d_k3s1_roll(srcs, wpack, bias, cout, relu=True):
     return out
 
 
+def conv3d_k3s2_x3(x, wpack, bias, cout, relu=True):
+    """x planar [cin,D,h,w] (w % 4 == 0); stride-(2,2,2) 3-D conv in split precision (``packing.pack_conv3d_s2_bf16x3``) ->
+    [cout,Do,ho,wo]."""
+    _t(x, "conv3d input")
+    cin, D, h, w = x.shape
+    Do, ho, wo = (D - 1) // 2 + 1, (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = torch.empty(cout, Do, ho, wo, device=x.device, dtype=torch.float32)
+    work = lambda: {"flops": 2.0 * 27 * cin * cout * Do * ho * wo, "bytes": 4.0 * (cin * D * h * w + cout * Do * ho * wo)}
+    check(_call(f"conv3d_s2x3_nt{(cout + 15) // 16}", work, _x3("effi_conv3d_k3s2_bf16x3_f32"), _p(x), cin, _p(wpack), _p(bias), cout,
+                D, h, w, int(relu), _p(out), _stream()), "effi_conv3d_k3s2_bf16x3_f32")
+    return out
+
+
 def conv3d_k3s2_mfma(x, wpack, bias, cout, relu=True):
     """x planar [cin,D,h,w]; stride-(2,2,2) 3-D conv as z-batched stride-2 2-D MFMA convs -> [cout,Do,ho,wo]."""
     _t(x, "conv3d input")

@@ -77,6 +77,33 @@ def pack_conv3d_planes_bf16x3(conv, bn):
     return pack_conv2d_bf16x3(w2, bias)
 
 
+def pack_conv3d_s2_bf16x3(conv, bn):
+    """nn.Conv3d [cout,cin,3,3,3] stride 2 (+BN) for ``effi_conv3d_k3s2_bf16x3_f32``: chunk = (kd, octet of input channels), K item =
+    tap ky*3 + kx (9 items, 3 K-steps), output tiles in groups of NT (1 if cout <= 16 else 2).
+    -> (bf16 [3 * ceil(cin/8), G, 3, NT, 2(hi|lo), 64, 8], bias fp32 [16 * NT * G])."""
+    w = conv.weight
+    bias = conv.bias
+    if bn is not None:
+        scale, shift = bn_scale_shift(bn)
+        w = w * scale.view(-1, 1, 1, 1, 1)
+        bias = shift if bias is None else bias * scale + shift
+    cout, cin = w.shape[0], w.shape[1]
+    nt = 1 if cout <= 16 else 2
+    g = (cout + 16 * nt - 1) // (16 * nt)
+    noct = (cin + 7) // 8
+    wz = torch.zeros(g * nt * 16, 3, noct * 8, 12, device=w.device, dtype=torch.float32)       # [co, kd, ci, tap]
+    wz[:cout, :, :cin, :9] = w.float().permute(0, 2, 1, 3, 4).reshape(cout, 3, cin, 9)
+    # [g, n, j, kd, oct, e, s, q] -> [kd, oct, g, s, n, q, j, e]
+    wz = wz.view(g, nt, 16, 3, noct, 8, 3, 4).permute(3, 4, 0, 6, 1, 7, 2, 5).contiguous()
+    hi = wz.to(torch.bfloat16)
+    lo = (wz - hi.float()).to(torch.bfloat16)
+    wp = torch.stack([hi, lo], dim=5).contiguous().view(3 * noct, g, 3, nt, 2, 64, 8)
+    b = torch.zeros(g * nt * 16, device=w.device, dtype=torch.float32)
+    if bias is not None:
+        b[:cout] = bias.float()
+    return wp, b
+
+
 def pack_conv3d_roll_bf16x3(conv, bn):
     """nn.Conv3d [cout,cin,3,3,3] (+BN), cin in {8,16}, for the rolling-window split-bf16 kernel:
     K index = (kd, ky, kx, octet, e); K-step s takes items 4s..4s+3 of (kd, ky, kx, octet); lane = q*16 + j holds

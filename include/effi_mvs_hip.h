@@ -172,6 +172,12 @@ int effi_conv2d_k3_bf16x3_pair_f32(const float* const* srcs_a, const int* src_ch
  * (packing.pack_conv2d_k5s2_bf16x3); bias padded to 16 * NT * G. */
 int effi_conv2d_k5s2_bf16x3_f32(const float* in, int cin, const void* wpack_bf16, const float* bias, int cout, int hin, int win,
                                 int act, float* out, effi_stream_t stream);
+/* Stride-(2,2,2) 3-D convolution k3 p1 (+folded BN, ReLU) in split precision: the U-Net's down-sampling levels
+ * (models/module.py:442,445), contract of effi_conv3d_k3s2_mfma_f32 with w % 4 == 0 and cout <= 64.  wpack_bf16 =
+ * [3 * ceil(cin/8)][G][3][NT][hi|lo][64][8] bf16: chunk = (kd, octet), K item = tap ky*3 + kx, groups of NT output tiles as in
+ * effi_conv2d_k5s2_bf16x3_f32 (packing.pack_conv3d_s2_bf16x3). */
+int effi_conv3d_k3s2_bf16x3_f32(const float* in, int cin, const void* wpack_bf16, const float* bias, int cout, int D, int h, int w,
+                                int relu, float* out, effi_stream_t stream);
 /* Two chained 3x3 convolutions with ReLU after each, at most 8 channels into each (the pyramid's full-resolution block conv0 =
  * Conv2d(3, 8) -> Conv2d(8, 8) with BatchNorm folded, models/module.py:353-356), in one kernel: the 8-channel intermediate map
  * stays in LDS (first layer computed on each 16 x 16 tile grown by one pixel).  in [cin][h][w], cin <= 8; both layers have at most 8
@@ -533,6 +539,8 @@ int effi_conv2d_k3_k1_bf16x3_f32_bf16(const float* const* srcs, const int* src_c
                                  const float* bias, int cout1, int relu1, const float* extra, int c_extra,
                                  const void* w2pack_bf16, const float* bias2, int cout2, int relu, int h, int w, float* out,
                                  effi_stream_t stream);
+int effi_conv3d_k3s2_bf16x3_f32_bf16(const float* in, int cin, const void* wpack_bf16, const float* bias, int cout, int D, int h, int w,
+                                int relu, float* out, effi_stream_t stream);
 int effi_conv2d_k5s2_bf16x3_f32_bf16(const float* in, int cin, const void* wpack_bf16, const float* bias, int cout, int hin, int win,
                                 int act, float* out, effi_stream_t stream);
 int effi_conv2d_k3_twice_bf16x3_f32_bf16(const float* in, int cin, const void* w1_bf16, const float* bias1, const void* w2_bf16,
