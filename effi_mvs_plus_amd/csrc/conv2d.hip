@@ -655,6 +655,8 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
     const bool s_in = stager & (sgy >= 0) & (sgy < h) & (sgx >= 0) & (sgx < w);
     const int s_off = sgy * w + sgx;
     const int s_lds = (soct * APIX + srow * AW + 4 * sqx) * 8;         // bf16 index of the quad in its octet plane
+    const int s_nv = w - sgx;                                          // elements of the quad inside its row (ZB: w % 4 may be != 0)
+    const bool s_part = s_nv < 4;
 
     f32x4 pa[8];                                      // raw loads: pa[e] = 4 pixels of channel e of the octet
     const int cin_eff = ZB ? 3 * a.cin : a.cin;
@@ -678,6 +680,17 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
         const float* base = in ? src + ((long)cl * a.cstride + zoff + s_off) : a.zeros;
         const long step = in ? a.cstride : 0;
         const float* q = base;
+        if (ZB && in && s_part) {
+            // rows that are not a multiple of 4 long (the U-Net's coarsest level is 50 wide at 1600x1184): the quad that straddles the
+            // row end takes its 1-3 valid elements one by one (the vector load would pick up the next row and could leave the tensor)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t0 = q[0], t1 = (s_nv > 1) ? q[1] : 0.0f, t2 = (s_nv > 2) ? q[2] : 0.0f;
+                pa[e] = f32x4{t0, t1, t2, 0.0f};
+                q += (e < emax) ? step : 0;
+            }
+            return;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             pa[e] = *reinterpret_cast<const f32x4*>(q);
@@ -2933,8 +2946,7 @@ extern "C" int EFFI_FN(effi_conv3d_k3s1_bf16x3_f32)(const float* const* srcs, co
                                            effi_stream_t stream) {
     if (!srcs || !src_channels || n_src < 1 || n_src > EFFI_MAX_SRC || !wpack_bf16 || !bias || !out) return EFFI_ERR_BADARG;
     if (cout < 1 || D < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
-    if (w & 3) return EFFI_ERR_UNSUPPORTED;
-    Conv2dArgs a;
+    Conv2dArgs a;                                          // any w: quads that straddle a row end are staged element by element
     a.cin = 0;
     for (int i = 0; i < EFFI_MAX_SRC; ++i) {
         a.src[i] = (i < n_src) ? srcs[i] : srcs[0];

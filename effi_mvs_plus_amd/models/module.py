@@ -83,7 +83,8 @@ class Conv3d(nn.Module):
             wp, bp = self._cache_roll.get(t, lambda: packing.pack_conv3d_roll_bf16x3(self.conv, self.bn))
             return ops.conv3d_k3s1_roll(srcs, wp, bp, self.out_channels, relu=self.relu)
         if (skip is None and _triple(self.conv.stride) == (1, 1, 1) and 1 < self.out_channels <= 32
-                and self.conv.in_channels >= 8 and srcs[0].shape[-1] % 4 == 0 and ops.uses_split()):
+                and self.conv.in_channels >= 8 and self.conv.in_channels % 8 == 0 and ops.uses_split()
+                and (srcs[0].shape[-1] % 4 == 0 or os.environ.get("EFFI_CONV3D_UNALIGNED_SPLIT", "1") != "0")):
             # stride-1 layers with >= 8 input channels: z-batched 2-D convolutions on the bf16 matrix cores in split
             # precision (single-channel inputs stay on the vector kernel: 3 of 16 K-slots used, measured slower)
             t = [self.conv.weight, self.conv.bias]

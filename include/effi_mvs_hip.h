@@ -206,7 +206,7 @@ int effi_conv2d_k3_k1_up2x_bf16x3_f32(const float* const* srcs, const int* src_c
                                       const float* bias, int cout1, const void* w2pack_bf16, const float* bias2,
                                       const float* inv_depth, const float* disp_range, int n_range, int h, int w,
                                       float* out_depth, float* out_depth_inv, effi_stream_t stream);
-/* Same operator (stride 1, cout <= 32, w % 4 == 0) in split precision: products as hi*hi + hi*lo + lo*hi on the bf16
+/* Same operator (stride 1, cout <= 32, any w: row ends that cut a pixel quad are staged element by element) in split precision: products as hi*hi + hi*lo + lo*hi on the bf16
  * matrix cores with fp32 accumulation (see effi_conv2d_k3_bf16x3_f32).  Input = channel concatenation of n_src planar
  * tensors [Ci][D][h][w] (models/module.py:513); wpack_bf16 = split-bf16 packing of the weight viewed as
  * [cout][3*cin][3][3] with input channel index kd*cin + ci; bias [16*ceil(cout/16)]; out planar [cout][D][h][w]. */
