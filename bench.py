@@ -344,6 +344,8 @@ def main():
             gaps.append((g0, g1))
         torch.cuda.synchronize()
         roof["empty_event_bracket_ms"] = sorted(a_.elapsed_time(b_) for a_, b_ in gaps)[len(gaps) // 2]
+        net_ms = max(avg_ms - roof["empty_event_bracket_ms"], 1e-6)
+        roof["frac_without_the_empty_bracket"] = roof["frac"] * avg_ms / net_ms      # what rocprofv3's per-kernel average implies
         roof["launches_timed"] = ksum["launches"]
         roof["algorithmic_flops_per_launch"] = flops_per_launch
         roof["algorithmic_bytes_per_launch"] = bytes_per_launch
