@@ -258,8 +258,15 @@ def main():
                 torch.cuda.synchronize()
                 ds = time.perf_counter() - t1
                 same = all(bool(torch.equal(a_, b_)) for a_, b_ in zip(sg.replay(0)["depth"], graphed.replay(0)["depth"]))
+                # every view the TIMED region produced (cloned while the other views were in flight) against the single-stream result of its scene
+                ref_final = [sg.replay(sc)["depth"][-1].clone() for sc in range(n_scenes)]
+                ref_conf = [sg.replay(sc)["photometric_confidence"].clone() for sc in range(n_scenes)]
+                torch.cuda.synchronize()
+                n_bad = sum(1 for i, (f_, c_) in enumerate(zip(finals, confs))
+                            if not (torch.equal(f_, ref_final[(i % n_slots) % n_scenes]) and torch.equal(c_, ref_conf[(i % n_slots) % n_scenes])))
                 single_stream = {"value": args.steps / ds, "unit": "views/s", "ms_per_view": ds / args.steps * 1e3, "steps": args.steps,
                                  "bitwise_equal_to_the_in_flight_graphs": same,
+                                 "timed_in_flight_views_differing_from_single_stream": n_bad,
                                  "note": "one view after the other: linear hipGraph replay on one stream (a view's latency; rank 0)"}
                 del sg, keep
             except Exception as exc:

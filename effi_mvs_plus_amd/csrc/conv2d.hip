@@ -3006,7 +3006,8 @@ static int launch_roll(const Conv2dArgs& a, hipStream_t st, const Conv2dArgs* pa
     if (fz) zt = atoi(fz);
     const long tiles = (long)cols * effi_cdiv(a.h, 4 * mr);
     const dim3 grid((unsigned)tiles, (unsigned)effi_cdiv(D, zt), pair ? 2 : 1);
-    if (NT == 1 && a.cout <= 8) {              // row-pair operand (see conv3d_roll_rp_bf16x3_body)
+    static const char* frp = getenv("EFFI_ROLL_RP");          // A/B switch (with packing.py): 0 = the one-row-per-tile operand
+    if (NT == 1 && a.cout <= 8 && !(frp && atoi(frp) == 0)) {     // row-pair operand (see conv3d_roll_rp_bf16x3_body)
         if (pair) {
             if (mr == 4) hipLaunchKernelGGL((conv3d_roll_rp_bf16x3_pair_kernel<NOCT, 4>), grid, dim3(256), 0, st, a, *pair, cols, (int)tiles, zt);
             else hipLaunchKernelGGL((conv3d_roll_rp_bf16x3_pair_kernel<NOCT, 2>), grid, dim3(256), 0, st, a, *pair, cols, (int)tiles, zt);

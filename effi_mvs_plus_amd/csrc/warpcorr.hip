@@ -657,7 +657,7 @@ __global__ __launch_bounds__(WIN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 // ------------------------------------------------------------------------------------------------
 // stages 2/3: hypotheses around the current depth, all views, view-weighted aggregate
 // ------------------------------------------------------------------------------------------------
-template <int C>
+template <int C, bool NODPP = true>
 __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* __restrict__ ref, EffiPtrList srcs, int S,
                                                            const float* __restrict__ rt_all,
                                                            const float* __restrict__ cur_depth,
@@ -698,8 +698,22 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* __restri
             const float ry = rt[3] * fx + rt[4] * fy + rt[5];
             const float rz = rt[6] * fx + rt[7] * fy + rt[8];
             Taps mine, t;
-            make_taps(rx * my_dep + rt[9], ry * my_dep + rt[10], rz * my_dep + rt[11], w, h, C, mine);
             const float wv = view_w[(long)v * vh * vw + vpix];
+            if (NODPP) {
+                // NO cross-lane exchange (the default): every lane sets up all GS hypotheses itself.  The exchange form below (each lane
+                // of a group sets up ONE hypothesis, the taps go round by quad_perm DPP moves; 1.5 % faster per view) gives wrong
+                // similarities for single 16-lane rows of single iterations -- one to five replays in a hundred -- as soon as kernels
+                // of OTHER hipGraph replays run on the GPU at the same time (three views in flight), never when a pass runs alone;
+                // see DESIGN.md section 6 and tools/diag_in_flight*.py.  EFFI_DYN_DPP=1 selects it for A/B runs.
+#pragma unroll
+                for (int j = 0; j < GS; ++j) {
+                    const float dep_j = 1.0f / fmaxf(smin + (float)min(d0 + j, D - 1) * step, 1e-5f);
+                    make_taps(rx * dep_j + rt[9], ry * dep_j + rt[10], rz * dep_j + rt[11], w, h, C, t);
+                    acc[j] = fmaf(wv, sample_dot(src, t, sub4, r4), acc[j]);
+                }
+                continue;
+            }
+            make_taps(rx * my_dep + rt[9], ry * my_dep + rt[10], rz * my_dep + rt[11], w, h, C, mine);
             taps_bcast<GS, 0>(mine, t);
             acc[0] = fmaf(wv, sample_dot(src, t, sub4, r4), acc[0]);
             taps_bcast<GS, 1>(mine, t);
@@ -714,7 +728,15 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < GS; ++j) {
             const int d = d0 + j;
-            const float total = (effi_group_sum<G::LPP>(acc[j]) / (float)C) / den;
+            float gsum;
+            if (NODPP) {
+                gsum = acc[j];
+#pragma unroll
+                for (int o = 1; o < G::LPP; o <<= 1) gsum += __shfl_xor(gsum, o);
+            } else {
+                gsum = effi_group_sum<G::LPP>(acc[j]);
+            }
+            const float total = (gsum / (float)C) / den;
             // every lane recomputes the hypothesis value of d (two ops) so that the owner lane can store it
             const float dep_d = 1.0f / fmaxf(smin + (float)min(d, D - 1) * step, 1e-5f);
             if (d < D && (d % G::LPP) == sub) {
@@ -1057,6 +1079,17 @@ extern "C" int effi_warpcorr_dyn_f32(const float* ref_nhwc, const float* const* 
     // (An 8-channels-per-lane form of this kernel -- one lane per pixel at C = 8, no exchange, no reduction, cheaper projection --
     // was built and measured at 592x800: 121 us against 109 us; at 296x400, C = 16: 63 against 58.  These kernels are bound by the
     // number of distinct cache lines a wave-instruction touches in the L1 / texture path, not by instruction issue.)
+    static const char* dpp = getenv("EFFI_DYN_DPP");
+    if (dpp && atoi(dpp)) {                   // the lane-exchange form: NOT safe next to other concurrent replays (see the kernel)
+        switch (C) {
+            case 32: hipLaunchKernelGGL((warpcorr_dyn_kernel<32, false>), dim3(grid_blocks<32>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples); break;
+            case 16: hipLaunchKernelGGL((warpcorr_dyn_kernel<16, false>), dim3(grid_blocks<16>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples); break;
+            case 8:  hipLaunchKernelGGL((warpcorr_dyn_kernel<8, false>), dim3(grid_blocks<8>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples); break;
+            default: return EFFI_ERR_UNSUPPORTED;
+        }
+        EFFI_LAUNCH_CHECK();
+        return EFFI_OK;
+    }
     switch (C) {
         case 32: hipLaunchKernelGGL(warpcorr_dyn_kernel<32>, dim3(grid_blocks<32>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples); break;
         case 16: hipLaunchKernelGGL(warpcorr_dyn_kernel<16>, dim3(grid_blocks<16>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples); break;

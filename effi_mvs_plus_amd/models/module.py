@@ -75,7 +75,7 @@ class Conv3d(nn.Module):
         cin_total = sum(x.shape[0] for x in srcs)
         if (skip is None and _triple(self.conv.stride) == (1, 1, 1) and 1 < self.out_channels <= 32 and len(srcs) <= 2
                 and cin_total in (8, 16) and srcs[0].shape[0] % 8 == 0 and srcs[0].shape[-1] % 4 == 0
-                and ops.uses_split()):
+                and ops.uses_split() and os.environ.get("EFFI_ROLL", "1") != "0"):
             # 8 / 16 input channels: rolling window of input planes in LDS, each plane fetched once
             t = [self.conv.weight, self.conv.bias]
             if self.bn is not None:
@@ -449,6 +449,8 @@ class cost_up_small(nn.Module):
                     and _triple(m.conv1.conv.stride) == (1, 1, 1) and m.conv2.out_channels == 1
                     and _triple(m.conv2.conv.stride) == (1, 2, 2) and m.conv0.relu and m.conv_cost.relu and m.conv1.relu
                     and m.conv2.relu and not m.training)
+        if os.environ.get("EFFI_CSP_PAIR", "1") == "0":        # A/B switch: every layer of the two blocks as its own launch
+            return False
         return stock(a) and stock(b) and ops.uses_split() and x.shape[0] == 1 and prior_w % 4 == 0
 
     @staticmethod

@@ -6,6 +6,8 @@ timed path.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 
@@ -116,7 +118,7 @@ def pack_conv3d_roll_bf16x3(conv, bn):
         bias = shift if bias is None else bias * scale + shift
     cout, cin = w.shape[0], w.shape[1]
     assert cin in (8, 16)
-    if cout <= 8:
+    if cout <= 8 and os.environ.get("EFFI_ROLL_RP", "1") != "0":
         return _pack_conv3d_roll_rowpair(w, bias)
     noct, nt = cin // 8, (cout + 15) // 16
     nit = 27 * noct
