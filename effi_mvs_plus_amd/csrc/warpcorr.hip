@@ -657,7 +657,7 @@ __global__ __launch_bounds__(WIN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 // ------------------------------------------------------------------------------------------------
 // stages 2/3: hypotheses around the current depth, all views, view-weighted aggregate
 // ------------------------------------------------------------------------------------------------
-template <int C, bool NODPP = true>
+template <int C, bool NODPP = true, bool SHFL = false>
 __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* __restrict__ ref, EffiPtrList srcs, int S,
                                                            const float* __restrict__ rt_all,
                                                            const float* __restrict__ cur_depth,
@@ -699,12 +699,30 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* __restri
             const float rz = rt[6] * fx + rt[7] * fy + rt[8];
             Taps mine, t;
             const float wv = view_w[(long)v * vh * vw + vpix];
+            if (NODPP && SHFL) {
+                // A/B form (EFFI_DYN_XCHG=shfl): each lane of a group sets up ONE hypothesis and the taps go round through ds_bpermute.
+                // Fails next to concurrent replays exactly like the DPP form below
+                make_taps(rx * my_dep + rt[9], ry * my_dep + rt[10], rz * my_dep + rt[11], w, h, C, mine);
+                const int lane0 = (int)(threadIdx.x & 63) & ~(GS - 1);
+#pragma unroll
+                for (int j = 0; j < GS; ++j) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        t.w[k] = __shfl(mine.w[k], lane0 + j);
+                        t.off[k] = __shfl(mine.off[k], lane0 + j);
+                    }
+                    acc[j] = fmaf(wv, sample_dot(src, t, sub4, r4), acc[j]);
+                }
+                continue;
+            }
             if (NODPP) {
                 // NO cross-lane exchange (the default): every lane sets up all GS hypotheses itself.  The exchange form below (each lane
                 // of a group sets up ONE hypothesis, the taps go round by quad_perm DPP moves; 1.5 % faster per view) gives wrong
                 // similarities for single 16-lane rows of single iterations -- one to five replays in a hundred -- as soon as kernels
                 // of OTHER hipGraph replays run on the GPU at the same time (three views in flight), never when a pass runs alone;
-                // see DESIGN.md section 6 and tools/diag_in_flight*.py.  EFFI_DYN_DPP=1 selects it for A/B runs.
+                // see DESIGN.md section 6 and tools/diag_in_flight*.py.  EFFI_DYN_XCHG=dpp selects it for A/B runs.  The same happens when
+                // the taps go round through ds_bpermute instead (EFFI_DYN_XCHG=shfl): it is the exchange of the set-up between lanes
+                // that fails, not one instruction.
 #pragma unroll
                 for (int j = 0; j < GS; ++j) {
                     const float dep_j = 1.0f / fmaxf(smin + (float)min(d0 + j, D - 1) * step, 1e-5f);
@@ -1079,17 +1097,22 @@ extern "C" int effi_warpcorr_dyn_f32(const float* ref_nhwc, const float* const* 
     // (An 8-channels-per-lane form of this kernel -- one lane per pixel at C = 8, no exchange, no reduction, cheaper projection --
     // was built and measured at 592x800: 121 us against 109 us; at 296x400, C = 16: 63 against 58.  These kernels are bound by the
     // number of distinct cache lines a wave-instruction touches in the L1 / texture path, not by instruction issue.)
-    static const char* dpp = getenv("EFFI_DYN_DPP");
-    if (dpp && atoi(dpp)) {                   // the lane-exchange form: NOT safe next to other concurrent replays (see the kernel)
+    // how the lanes of a group share the hypotheses' taps: not at all (default: every lane sets up every hypothesis); A/B forms that are
+    // NOT safe next to other concurrent replays (see the kernel): "dpp" = quad_perm DPP moves, "shfl" = ds_bpermute
+    static const char* xchg = getenv("EFFI_DYN_XCHG");
+#define EFFI_DYN(CC, A, B) hipLaunchKernelGGL((warpcorr_dyn_kernel<CC, A, B>), dim3(grid_blocks<CC>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples)
+    if (xchg && (xchg[0] == 'd' || xchg[0] == 's')) {
+        const bool dpp = xchg[0] == 'd';
         switch (C) {
-            case 32: hipLaunchKernelGGL((warpcorr_dyn_kernel<32, false>), dim3(grid_blocks<32>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples); break;
-            case 16: hipLaunchKernelGGL((warpcorr_dyn_kernel<16, false>), dim3(grid_blocks<16>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples); break;
-            case 8:  hipLaunchKernelGGL((warpcorr_dyn_kernel<8, false>), dim3(grid_blocks<8>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples); break;
+            case 32: if (dpp) EFFI_DYN(32, false, false); else EFFI_DYN(32, true, true); break;
+            case 16: if (dpp) EFFI_DYN(16, false, false); else EFFI_DYN(16, true, true); break;
+            case 8:  if (dpp) EFFI_DYN(8, false, false); else EFFI_DYN(8, true, true); break;
             default: return EFFI_ERR_UNSUPPORTED;
         }
         EFFI_LAUNCH_CHECK();
         return EFFI_OK;
     }
+#undef EFFI_DYN
     switch (C) {
         case 32: hipLaunchKernelGGL(warpcorr_dyn_kernel<32>, dim3(grid_blocks<32>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples); break;
         case 16: hipLaunchKernelGGL(warpcorr_dyn_kernel<16>, dim3(grid_blocks<16>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples); break;
