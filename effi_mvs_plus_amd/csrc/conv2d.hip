@@ -2421,6 +2421,15 @@ extern "C" int EFFI_FN(effi_conv3d_k3s2_bf16x3_f32)(const float* in, int cin, co
 }
 
 // ---- split-bf16 3x3 convolution entry --------------------------------------------------------------------------
+// Thresholds of the rows-per-wave choice below (workgroup counts); the environment overrides are for A/B runs of the rule
+// (with several views in flight the chip is filled by other views' kernels, which favours the larger tiles earlier).
+static long effi_env_long(const char* name, long dflt) {
+    const char* v = getenv(name);
+    return v ? atol(v) : dflt;
+}
+static long effi_mr4_min() { static const long v = effi_env_long("EFFI_MR4_MIN", 400); return v; }
+static long effi_mr4_nt2_max() { static const long v = effi_env_long("EFFI_MR4_NT2_MAX", 1024); return v; }
+static long effi_mr2_min() { static const long v = effi_env_long("EFFI_MR2_MIN", 400); return v; }
 // Rows per wave (MR): 4 rows amortise the B fragments best, but the grid must still cover the 256 CUs (>= ~400 workgroups),
 // and with two N-tiles the 4-row variant drops to 2 workgroups per CU where the 2-row one keeps 4: on large maps the latter
 // wins.  (Persistent workgroups with cross-tile prefetch were built and measured twice: no gain, more registers.)
@@ -2430,8 +2439,8 @@ static int launch_bf16x3(const Conv2dArgs& a, hipStream_t st) {
     const long planes = ZB ? a.zcount : 1;
     const long t4 = cols * effi_cdiv(a.h, 16) * planes, t2 = cols * effi_cdiv(a.h, 8) * planes;
     int mr;
-    if (t4 >= 400 && !(NT == 2 && t4 >= 1024)) mr = 4;
-    else if (t2 >= 400) mr = 2;
+    if (t4 >= effi_mr4_min() && !(NT == 2 && t4 >= effi_mr4_nt2_max())) mr = 4;
+    else if (t2 >= effi_mr2_min()) mr = 2;
     else mr = 1;
     static const char* force = getenv("EFFI_FORCE_MR");
     if (force) mr = atoi(force);
@@ -2473,8 +2482,8 @@ static int launch_bf16x3_pair(const Conv2dArgs& a0, const Conv2dArgs& a1, hipStr
     const long cols = effi_cdiv(a0.w, 16);
     const long t4 = cols * effi_cdiv(a0.h, 16) * 2, t2 = cols * effi_cdiv(a0.h, 8) * 2;
     int mr;
-    if (t4 >= 400 && !(NT == 2 && t4 >= 1024)) mr = 4;
-    else if (t2 >= 400) mr = 2;
+    if (t4 >= effi_mr4_min() && !(NT == 2 && t4 >= effi_mr4_nt2_max())) mr = 4;
+    else if (t2 >= effi_mr2_min()) mr = 2;
     else mr = 1;
     static const char* force = getenv("EFFI_FORCE_MR");
     if (force) mr = atoi(force);
