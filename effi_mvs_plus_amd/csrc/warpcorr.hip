@@ -657,7 +657,7 @@ __global__ __launch_bounds__(WIN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 // ------------------------------------------------------------------------------------------------
 // stages 2/3: hypotheses around the current depth, all views, view-weighted aggregate
 // ------------------------------------------------------------------------------------------------
-template <int C, bool NODPP = true, bool SHFL = false>
+template <int C, bool NODPP = true, bool SHFL = false, bool FAST = false>
 __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* __restrict__ ref, EffiPtrList srcs, int S,
                                                            const float* __restrict__ rt_all,
                                                            const float* __restrict__ cur_depth,
@@ -685,12 +685,23 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* __restri
     const float den = wsum + 1e-6f;
     constexpr int GS = (G::LPP >= 4) ? 4 : 2;
     const int gj = threadIdx.x % GS;
+    // FAST set-up (the default, see effi_warpcorr_dyn_f32): the kernel is bound by vector-ALU issue -- a hypothesis' set-up is ~130
+    // instructions with the four IEEE divisions of the projection, and without a lane exchange every lane sets up every hypothesis.
+    // This form uses the stage-1 window kernel's projection (project_xy: refined reciprocal + one residual step per division,
+    // correctly rounded except for rare 1-ulp cases of a continuous function) and its tap arithmetic (make_taps_win<false>), and
+    // addresses the taps as 32-bit byte offsets from the view's (uniform) base pointer.
+    const float wm1 = (float)(w - 1), hm1 = (float)(h - 1);
+    const float hw2 = wm1 / 2.0f, hh2 = hm1 / 2.0f;
+    const float rhw2 = 1.0f / hw2, rhh2 = 1.0f / hh2;              // IEEE divisions: correctly rounded reciprocals
     for (int d0 = 0; d0 < D; d0 += GS) {
         const int dm = min(d0 + gj, D - 1);
         const float my_dep = 1.0f / fmaxf(smin + (float)dm * step, 1e-5f);
-        float acc[GS];
+        float acc[GS], dep[GS];
 #pragma unroll
-        for (int j = 0; j < GS; ++j) acc[j] = 0.0f;
+        for (int j = 0; j < GS; ++j) {
+            acc[j] = 0.0f;
+            dep[j] = 1.0f / fmaxf(smin + (float)min(d0 + j, D - 1) * step, 1e-5f);
+        }
         for (int v = 0; v < S; ++v) {
             const float* __restrict__ src = pick_view(srcs, v);
             const float* __restrict__ rt = rt_all + v * 12;
@@ -699,6 +710,26 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* __restri
             const float rz = rt[6] * fx + rt[7] * fy + rt[8];
             Taps mine, t;
             const float wv = view_w[(long)v * vh * vw + vpix];
+            if (NODPP && !SHFL && FAST) {
+                const char* __restrict__ sb = reinterpret_cast<const char*>(src) + sub4 * 4;
+#pragma unroll
+                for (int j = 0; j < GS; ++j) {
+                    float ix, iy;
+                    project_xy(rx * dep[j] + rt[9], ry * dep[j] + rt[10], rz * dep[j] + rt[11], hw2, rhw2, hh2, rhh2, wm1, hm1, ix, iy);
+                    WinTaps tw;
+                    make_taps_win<false>(ix, iy, w, h, 0, 0, w, h, tw);
+                    const float4 a = *reinterpret_cast<const float4*>(sb + (unsigned)(tw.a[0] * (C * 4)));
+                    const float4 b = *reinterpret_cast<const float4*>(sb + (unsigned)(tw.a[1] * (C * 4)));
+                    const float4 c = *reinterpret_cast<const float4*>(sb + (unsigned)(tw.a[2] * (C * 4)));
+                    const float4 e = *reinterpret_cast<const float4*>(sb + (unsigned)(tw.a[3] * (C * 4)));
+                    float sd = tw.w[0] * dot4(a, r4);
+                    sd = fmaf(tw.w[1], dot4(b, r4), sd);
+                    sd = fmaf(tw.w[2], dot4(c, r4), sd);
+                    sd = fmaf(tw.w[3], dot4(e, r4), sd);
+                    acc[j] = fmaf(wv, sd, acc[j]);
+                }
+                continue;
+            }
             if (NODPP && SHFL) {
                 // A/B form (EFFI_DYN_XCHG=shfl): each lane of a group sets up ONE hypothesis and the taps go round through ds_bpermute.
                 // Fails next to concurrent replays exactly like the DPP form below
@@ -725,8 +756,7 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* __restri
                 // that fails, not one instruction.
 #pragma unroll
                 for (int j = 0; j < GS; ++j) {
-                    const float dep_j = 1.0f / fmaxf(smin + (float)min(d0 + j, D - 1) * step, 1e-5f);
-                    make_taps(rx * dep_j + rt[9], ry * dep_j + rt[10], rz * dep_j + rt[11], w, h, C, t);
+                    make_taps(rx * dep[j] + rt[9], ry * dep[j] + rt[10], rz * dep[j] + rt[11], w, h, C, t);
                     acc[j] = fmaf(wv, sample_dot(src, t, sub4, r4), acc[j]);
                 }
                 continue;
@@ -762,6 +792,80 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* __restri
                 samples[(long)d * hw + pix] = dep_d;
             }
         }
+    }
+}
+
+// Hypothesis-per-lane form of the same operator (EFFI_DYN_FORM=hyp): the C/4 lanes of a pixel no longer split the channels of every
+// hypothesis -- which makes every lane set up every hypothesis once the set-up cannot be exchanged between lanes -- but the
+// hypotheses: lane `sub` owns d = sub, sub + C/4, ... with ALL C channels of the pixel (the reference features sit in C registers),
+// so a pixel's D x S set-ups are computed exactly once, and nothing crosses lanes (no exchange, no reduction).  Same FAST set-up
+// arithmetic as above; the channel sum runs over C in one lane (a different association than 4 + butterfly: ~1e-7 relative).
+template <int C>
+__global__ __launch_bounds__(256) void warpcorr_dyn_hyp_kernel(const float* __restrict__ ref, EffiPtrList srcs, int S,
+                                                               const float* __restrict__ rt_all,
+                                                               const float* __restrict__ cur_depth,
+                                                               const float* __restrict__ interval,
+                                                               const float* __restrict__ view_w, int vw_shift,
+                                                               int h, int w, int D, float* __restrict__ sim,
+                                                               float* __restrict__ samples) {
+    using G = WarpGeom<C>;
+    int x, y, sub;
+    if (!tile_pixel<C>(blockIdx.x, gridDim.x, h, w, x, y, sub)) return;
+    const int hw = h * w, pix = y * w + x;
+    float4 r[C / 4];
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q) r[q] = *reinterpret_cast<const float4*>(ref + (long)pix * C + 4 * q);
+    const float fx = (float)x, fy = (float)y;
+    const float inv = 1.0f / cur_depth[pix];
+    const float half = (float)(D / 2) * interval[0];
+    const float smin = fmaxf(inv - half, 1e-4f);
+    const float smax = fminf(fmaxf(inv + half, 1e-4f), 1e4f);
+    const float step = (smax - smin) / (float)(D - 1);
+    const int vh = h >> vw_shift, vw = w >> vw_shift;
+    const int vpix = (y >> vw_shift) * vw + (x >> vw_shift);
+    float wsum = 0.0f;
+    for (int v = 0; v < S; ++v) wsum = wsum + view_w[(long)v * vh * vw + vpix];
+    const float den = wsum + 1e-6f;
+    const float wm1 = (float)(w - 1), hm1 = (float)(h - 1);
+    const float hw2 = wm1 / 2.0f, hh2 = hm1 / 2.0f;
+    const float rhw2 = 1.0f / hw2, rhh2 = 1.0f / hh2;
+    for (int d = sub; d < D; d += G::LPP) {
+        const float dep = 1.0f / fmaxf(smin + (float)d * step, 1e-5f);
+        float acc = 0.0f;
+        for (int v = 0; v < S; ++v) {
+            const char* __restrict__ sb = reinterpret_cast<const char*>(pick_view(srcs, v));
+            const float* __restrict__ rt = rt_all + v * 12;
+            const float rx = rt[0] * fx + rt[1] * fy + rt[2];
+            const float ry = rt[3] * fx + rt[4] * fy + rt[5];
+            const float rz = rt[6] * fx + rt[7] * fy + rt[8];
+            const float wv = view_w[(long)v * vh * vw + vpix];
+            float ix, iy;
+            project_xy(rx * dep + rt[9], ry * dep + rt[10], rz * dep + rt[11], hw2, rhw2, hh2, rhh2, wm1, hm1, ix, iy);
+            WinTaps tw;
+            make_taps_win<false>(ix, iy, w, h, 0, 0, w, h, tw);
+            float4 tv[4][C / 4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const char* tp = sb + (unsigned)(tw.a[k] * (C * 4));
+#pragma unroll
+                for (int q = 0; q < C / 4; ++q) tv[k][q] = *reinterpret_cast<const float4*>(tp + 16 * q);
+            }
+            float sd = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float dk = tv[k][0].x * r[0].x;
+                dk = fmaf(tv[k][0].y, r[0].y, dk); dk = fmaf(tv[k][0].z, r[0].z, dk); dk = fmaf(tv[k][0].w, r[0].w, dk);
+#pragma unroll
+                for (int q = 1; q < C / 4; ++q) {
+                    dk = fmaf(tv[k][q].x, r[q].x, dk); dk = fmaf(tv[k][q].y, r[q].y, dk);
+                    dk = fmaf(tv[k][q].z, r[q].z, dk); dk = fmaf(tv[k][q].w, r[q].w, dk);
+                }
+                sd = (k == 0) ? tw.w[0] * dk : fmaf(tw.w[k], dk, sd);
+            }
+            acc = fmaf(wv, sd, acc);
+        }
+        sim[(long)d * hw + pix] = (acc / (float)C) / den;
+        samples[(long)d * hw + pix] = dep;
     }
 }
 
@@ -1100,13 +1204,33 @@ extern "C" int effi_warpcorr_dyn_f32(const float* ref_nhwc, const float* const* 
     // how the lanes of a group share the hypotheses' taps: not at all (default: every lane sets up every hypothesis); A/B forms that are
     // NOT safe next to other concurrent replays (see the kernel): "dpp" = quad_perm DPP moves, "shfl" = ds_bpermute
     static const char* xchg = getenv("EFFI_DYN_XCHG");
-#define EFFI_DYN(CC, A, B) hipLaunchKernelGGL((warpcorr_dyn_kernel<CC, A, B>), dim3(grid_blocks<CC>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples)
+#define EFFI_DYN(CC, ...) hipLaunchKernelGGL((warpcorr_dyn_kernel<CC, __VA_ARGS__>), dim3(grid_blocks<CC>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples)
     if (xchg && (xchg[0] == 'd' || xchg[0] == 's')) {
         const bool dpp = xchg[0] == 'd';
         switch (C) {
             case 32: if (dpp) EFFI_DYN(32, false, false); else EFFI_DYN(32, true, true); break;
             case 16: if (dpp) EFFI_DYN(16, false, false); else EFFI_DYN(16, true, true); break;
             case 8:  if (dpp) EFFI_DYN(8, false, false); else EFFI_DYN(8, true, true); break;
+            default: return EFFI_ERR_UNSUPPORTED;
+        }
+        EFFI_LAUNCH_CHECK();
+        return EFFI_OK;
+    }
+    static const char* form = getenv("EFFI_DYN_FORM");
+    if (form && form[0] == 'h' && (C == 8 || C == 16) && (long)h * w * C * 4 < (1L << 32)) {
+        if (C == 8) hipLaunchKernelGGL(warpcorr_dyn_hyp_kernel<8>, dim3(grid_blocks<8>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples);
+        else hipLaunchKernelGGL(warpcorr_dyn_hyp_kernel<16>, dim3(grid_blocks<16>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples);
+        EFFI_LAUNCH_CHECK();
+        return EFFI_OK;
+    }
+    // set-up arithmetic of the default (exchange-free) form: "fast" (see the kernel) unless EFFI_DYN_SETUP=exact asks for the
+    // reference's IEEE divisions op for op, or the map is too large for 32-bit byte offsets
+    static const char* setup = getenv("EFFI_DYN_SETUP");
+    if (!(setup && setup[0] == 'e') && (long)h * w * C * 4 < (1L << 32)) {
+        switch (C) {
+            case 32: EFFI_DYN(32, true, false, true); break;
+            case 16: EFFI_DYN(16, true, false, true); break;
+            case 8:  EFFI_DYN(8, true, false, true); break;
             default: return EFFI_ERR_UNSUPPORTED;
         }
         EFFI_LAUNCH_CHECK();
