@@ -795,7 +795,7 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* __restri
     }
 }
 
-// Hypothesis-per-lane form of the same operator (EFFI_DYN_FORM=hyp): the C/4 lanes of a pixel no longer split the channels of every
+// Hypothesis-per-lane form of the same operator (the default for C = 8 / 16): the C/4 lanes of a pixel no longer split the channels of every
 // hypothesis -- which makes every lane set up every hypothesis once the set-up cannot be exchanged between lanes -- but the
 // hypotheses: lane `sub` owns d = sub, sub + C/4, ... with ALL C channels of the pixel (the reference features sit in C registers),
 // so a pixel's D x S set-ups are computed exactly once, and nothing crosses lanes (no exchange, no reduction).  Same FAST set-up
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_hyp_kernel(const float* __re
     for (int d = sub; d < D; d += G::LPP) {
         const float dep = 1.0f / fmaxf(smin + (float)d * step, 1e-5f);
         float acc = 0.0f;
-        for (int v = 0; v < S; ++v) {
+        for (int v = 0; v < S; ++v) {                 // (forced unroll factors 1 / 2 / 4 measured: none better than the compiler's choice)
             const char* __restrict__ sb = reinterpret_cast<const char*>(pick_view(srcs, v));
             const float* __restrict__ rt = rt_all + v * 12;
             const float rx = rt[0] * fx + rt[1] * fy + rt[2];
@@ -1203,7 +1203,7 @@ extern "C" int effi_warpcorr_dyn_f32(const float* ref_nhwc, const float* const* 
     // number of distinct cache lines a wave-instruction touches in the L1 / texture path, not by instruction issue.)
     // how the lanes of a group share the hypotheses' taps: not at all (default: every lane sets up every hypothesis); A/B forms that are
     // NOT safe next to other concurrent replays (see the kernel): "dpp" = quad_perm DPP moves, "shfl" = ds_bpermute
-    static const char* xchg = getenv("EFFI_DYN_XCHG");
+    const char* xchg = getenv("EFFI_DYN_XCHG");
 #define EFFI_DYN(CC, ...) hipLaunchKernelGGL((warpcorr_dyn_kernel<CC, __VA_ARGS__>), dim3(grid_blocks<CC>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples)
     if (xchg && (xchg[0] == 'd' || xchg[0] == 's')) {
         const bool dpp = xchg[0] == 'd';
@@ -1216,8 +1216,13 @@ extern "C" int effi_warpcorr_dyn_f32(const float* ref_nhwc, const float* const* 
         EFFI_LAUNCH_CHECK();
         return EFFI_OK;
     }
-    static const char* form = getenv("EFFI_DYN_FORM");
-    if (form && form[0] == 'h' && (C == 8 || C == 16) && (long)h * w * C * 4 < (1L << 32)) {
+    // (the three EFFI_DYN_* switches are read at every call, so that one process -- tests/test_gpu_kernels.py -- can compare the forms)
+    // Default for C = 8 / 16 (stages 2 / 3): the hypothesis-per-lane form (91 vs 107 us at 592x800, 60 vs 75 us at 296x400);
+    // EFFI_DYN_FORM=lanes selects the channel-split form below for A/B runs.
+    const char* form = getenv("EFFI_DYN_FORM");
+    const char* setup = getenv("EFFI_DYN_SETUP");
+    const bool exact = setup && setup[0] == 'e';
+    if (!exact && !(form && form[0] == 'l') && (C == 8 || C == 16) && (long)h * w * C * 4 < (1L << 32)) {
         if (C == 8) hipLaunchKernelGGL(warpcorr_dyn_hyp_kernel<8>, dim3(grid_blocks<8>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples);
         else hipLaunchKernelGGL(warpcorr_dyn_hyp_kernel<16>, dim3(grid_blocks<16>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples);
         EFFI_LAUNCH_CHECK();
@@ -1225,8 +1230,7 @@ extern "C" int effi_warpcorr_dyn_f32(const float* ref_nhwc, const float* const* 
     }
     // set-up arithmetic of the default (exchange-free) form: "fast" (see the kernel) unless EFFI_DYN_SETUP=exact asks for the
     // reference's IEEE divisions op for op, or the map is too large for 32-bit byte offsets
-    static const char* setup = getenv("EFFI_DYN_SETUP");
-    if (!(setup && setup[0] == 'e') && (long)h * w * C * 4 < (1L << 32)) {
+    if (!exact && (long)h * w * C * 4 < (1L << 32)) {
         switch (C) {
             case 32: EFFI_DYN(32, true, false, true); break;
             case 16: EFFI_DYN(16, true, false, true); break;

@@ -515,6 +515,38 @@ def test_getcost_initvolume(model, O):
     assert torch.equal(a, b)
 
 
+def test_getcost_initvolume_kernel_forms_agree(model, monkeypatch):
+    """The stage-2/3 warp + correlation has a default form (a lane owns whole hypotheses, cheap projection) and switchable ones
+    (EFFI_DYN_FORM=lanes: lanes split the channels; EFFI_DYN_SETUP=exact: the reference's IEEE divisions op for op): every form
+    meets the golden vectors, and the forms agree far inside that tolerance."""
+    net, sd = model
+    g = load_golden("g06_initvolume.npz")
+    N, C, h, w = int(g["N"]), int(g["C"]), int(g["h"]), int(g["w"])
+    feats = synth.smooth_features(N, C, h, w, seed=int(g["feat_seed"]))
+
+    def run():
+        return net.GetCost_initvolume(t(g["cur_depth"], DEV), features=[t(f, DEV) for f in feats], proj_matrices=t(g["proj"], DEV),
+                                      depth_interval=t(g["interval"], DEV), depth_max=None, depth_min=None,
+                                      view_weights=t(g["view_weights"], DEV), CostNum=8, Inverse=True, G=1)
+    out = {}
+    for name, env in (("default", {}), ("lanes", {"EFFI_DYN_FORM": "lanes"}), ("exact", {"EFFI_DYN_SETUP": "exact"})):
+        for k in ("EFFI_DYN_FORM", "EFFI_DYN_SETUP", "EFFI_DYN_XCHG"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sim, smp = run()
+        torch.cuda.synchronize()
+        out[name] = (sim.clone(), smp.clone())
+        check_close(f"GetCost_initvolume.samples ({name})", smp, g["samples"], rtol=2e-6, atol=0)
+        check_close(f"GetCost_initvolume.similarity ({name})", sim, g["similarity"], rtol=1e-4, atol=3e-4, frac_ok=0.995)
+    peak = float(out["exact"][0].abs().max())
+    for name in ("default", "lanes"):
+        assert torch.equal(out[name][1], out["exact"][1]), "the hypotheses do not depend on the form"
+        diff = float((out[name][0] - out["exact"][0]).abs().max())
+        print(f"similarity, form {name} vs exact: max abs diff {diff:.3e} (peak {peak:.3e})")
+        assert diff <= 2e-5 * max(peak, 1.0), (name, diff, peak)
+
+
 # ---------------------------------------------------------------------------------------------
 # GRU update block
 # ---------------------------------------------------------------------------------------------
