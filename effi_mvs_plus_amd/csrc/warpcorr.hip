@@ -48,6 +48,18 @@ __device__ __forceinline__ int quad_bcast_i(int v) {
 }
 template <int G, int J>
 __device__ __forceinline__ void taps_bcast(const Taps& mine, Taps& out) {
+#ifdef EFFI_DPP_POISON
+    // diagnostic build (tools/diag_in_flight8.py with EFFI_MVS_LIB): bound_ctrl off and a poisoned `old` operand -- a destination lane
+    // whose source lane the hardware treats as invalid / disabled keeps the poison (weight 1000) instead of reading 0
+    constexpr int s0 = J, s1 = J, s2 = (G == 4) ? J : 2 + J, s3 = (G == 4) ? J : 2 + J;
+    constexpr int ctrl = s0 | (s1 << 2) | (s2 << 4) | (s3 << 6);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        out.w[k] = __int_as_float(__builtin_amdgcn_update_dpp(0x447A0000, __float_as_int(mine.w[k]), ctrl, 0xF, 0xF, false));
+        out.off[k] = __builtin_amdgcn_update_dpp(0, mine.off[k], ctrl, 0xF, 0xF, false);
+    }
+    return;
+#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         out.w[k] = __int_as_float(quad_bcast_i<G, J>(__float_as_int(mine.w[k])));
