@@ -60,6 +60,34 @@ __device__ __forceinline__ int effi_xcd_remap(int bid, int nblocks) {
 
 __device__ __forceinline__ float effi_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// Gate non-linearities of the SPLIT-precision convolution epilogues (conv2d.hip, conv_epilogue_store_t and the mask head): the
+// convolution result they are applied to already carries ~1e-5 of relative error (three bf16 partial products), so the exponential is
+// v_exp_f32 on x * log2(e) (argument rounding ~ |x| * 6e-8 relative) and the division a refined reciprocal (rcp + one Newton step,
+// <= 1 ulp) -- ~7 vector instructions instead of ~24 for expf + IEEE division, 16 times per lane and tile in the GRU's z / r
+// convolution, whose time is 56 % vector-instruction issue.  Absolute error <= 2e-7; NaN inputs propagate.  The exact-fp32 kernels
+// (precision "fp32") keep expf / tanhf / IEEE division; -DEFFI_EXACT_EPILOGUES restores them here too (A/B builds).
+__device__ __forceinline__ float effi_rcp_refined(float b) {
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    return fmaf(fmaf(-b, r0, 1.0f), r0, r0);
+}
+__device__ __forceinline__ float effi_exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float effi_sigmoid_split(float x) {
+#ifdef EFFI_EXACT_EPILOGUES
+    return effi_sigmoid(x);
+#else
+    const float r = effi_rcp_refined(1.0f + effi_exp_fast(fminf(-x, 60.0f)));       // e^60 is finite; sigmoid(-60) = 9e-27
+    return (x != x) ? x : r;
+#endif
+}
+__device__ __forceinline__ float effi_tanh_split(float x) {
+#ifdef EFFI_EXACT_EPILOGUES
+    return tanhf(x);
+#else
+    const float r = 1.0f - 2.0f * effi_rcp_refined(1.0f + effi_exp_fast(fminf(2.0f * x, 60.0f)));   // tanh(30) = 1 in fp32
+    return (x != x) ? x : r;
+#endif
+}
+
 // scale_inv_depth (models/Effi_MVS_plus.py:138-148): normalised inverse depth -> (scaled, depth)
 __device__ __forceinline__ float effi_inv_to_depth(float inv, float lo, float hi) {
     // min_disp = 1/max_depth with max_depth = 1/lo (models/Effi_MVS_plus.py:413-414): two reciprocals

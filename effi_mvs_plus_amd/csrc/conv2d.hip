@@ -343,7 +343,7 @@ __device__ __forceinline__ void conv_epilogue_store_t(const Conv2dArgs& a, const
 #pragma unroll
         for (int r = 0; r < 4; ++r) hv[r] = a.aux0[o + (long)r * hw];              // r*h needs h; harmless extra read for z
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dst[(long)r * hw] = effi_sigmoid(v[r]) * (is_z ? 1.0f : hv[r]);
+        for (int r = 0; r < 4; ++r) dst[(long)r * hw] = effi_sigmoid_split(v[r]) * (is_z ? 1.0f : hv[r]);
     } else if (EPI == EFFI_EPI_GRU_Q) {
         if (nvalid <= 0) return;
         const long o = (long)co0 * hw + pix;
@@ -354,7 +354,7 @@ __device__ __forceinline__ void conv_epilogue_store_t(const Conv2dArgs& a, const
             zv[r] = a.aux1[o + (long)r * hw];
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a.out0[o + (long)r * hw] = (1.0f - zv[r]) * hv[r] + zv[r] * tanhf(v[r]);
+        for (int r = 0; r < 4; ++r) a.out0[o + (long)r * hw] = (1.0f - zv[r]) * hv[r] + zv[r] * effi_tanh_split(v[r]);
     }
 }
 
@@ -871,12 +871,22 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
                 float e[9], sm = 0.0f;
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
+#ifdef EFFI_EXACT_EPILOGUES
                     e[k] = expf(v[k] - mx);
+#else
+                    e[k] = effi_exp_fast(v[k] - mx);                 // argument <= 0: no overflow; see effi_sigmoid_split
+#endif
                     sm = sm + e[k];
                 }
                 float ac = 0.0f;
+#ifdef EFFI_EXACT_EPILOGUES
 #pragma unroll
                 for (int k = 0; k < 9; ++k) ac = ac + (e[k] / sm) * nbv[k];
+#else
+                const float rsm = effi_rcp_refined(sm);              // 1 <= sm <= 9
+#pragma unroll
+                for (int k = 0; k < 9; ++k) ac = ac + (e[k] * rsm) * nbv[k];
+#endif
                 const long o = (long)(2 * y + (lk >> 1)) * W2 + 2 * x + (lk & 1);
                 const float dep = effi_inv_to_depth(ac, lo, hi);
                 a.out0[o] = dep;
