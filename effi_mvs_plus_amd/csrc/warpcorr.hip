@@ -1234,7 +1234,7 @@ extern "C" int effi_warpcorr_dyn_f32(const float* ref_nhwc, const float* const* 
     const char* form = getenv("EFFI_DYN_FORM");
     const char* setup = getenv("EFFI_DYN_SETUP");
     const bool exact = setup && setup[0] == 'e';
-    if (!exact && !(form && form[0] == 'l') && (C == 8 || C == 16) && (long)h * w * C * 4 < (1L << 32)) {
+    if (!exact && !(form && form[0] == 'l') && (C == 8 || C == 16) && (long)h * w * C * 4 < (1L << 31)) {
         if (C == 8) hipLaunchKernelGGL(warpcorr_dyn_hyp_kernel<8>, dim3(grid_blocks<8>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples);
         else hipLaunchKernelGGL(warpcorr_dyn_hyp_kernel<16>, dim3(grid_blocks<16>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples);
         EFFI_LAUNCH_CHECK();
@@ -1242,7 +1242,7 @@ extern "C" int effi_warpcorr_dyn_f32(const float* ref_nhwc, const float* const* 
     }
     // set-up arithmetic of the default (exchange-free) form: "fast" (see the kernel) unless EFFI_DYN_SETUP=exact asks for the
     // reference's IEEE divisions op for op, or the map is too large for 32-bit byte offsets
-    if (!exact && (long)h * w * C * 4 < (1L << 32)) {
+    if (!exact && (long)h * w * C * 4 < (1L << 31)) {
         switch (C) {
             case 32: EFFI_DYN(32, true, false, true); break;
             case 16: EFFI_DYN(16, true, false, true); break;
