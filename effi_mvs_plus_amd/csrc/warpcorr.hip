@@ -9,7 +9,10 @@
 // image and neighbouring tiles share that XCD's L2.
 //
 // Arithmetic follows the reference op for op (models/module.py:318-341 and ATen's grid_sample with
-// bilinear / zeros / align_corners=True); built with -ffp-contract=off, FMAs are explicit.
+// bilinear / zeros / align_corners=True); built with -ffp-contract=off, FMAs are explicit.  One documented exception: the
+// default kernels of the path (stage-1 window kernel, stage-2/3 hypothesis-per-lane kernel) evaluate the four divisions of the
+// projection with a refined reciprocal + one residual step (project_xy below: correctly rounded except for rare 1-ulp cases of
+// a continuous function); the exact-division forms stay selectable (EFFI_WARP_LDS_KB=-1, EFFI_DYN_SETUP=exact).
 #include "common.hpp"
 #include <cstdlib>
 
