@@ -277,12 +277,22 @@ def test_homo_warping_new_is_differentiable(O, C, h, w, D):
     check_close("homo_warping_new grad", dleaf.grad, leaf.grad, rtol=1e-3, atol=2e-4 * float(leaf.grad.abs().max()) + 1e-6, frac_ok=0.998)
 
 
-def test_pixelwise_net(model, O):
+@pytest.mark.parametrize("form", ["mfma", "valu"])
+def test_pixelwise_net(model, O, form, monkeypatch):
+    """Both kernels of the view-weight net (default: layers 2 / 3 on the fp32 matrix cores; EFFI_PIXNET_MFMA=0: vector ALU) against
+    the reference's vectors and the oracle, also on a map that is not a multiple of the 16 x 16 tile."""
     net, sd = model
+    if form == "valu":
+        monkeypatch.setenv("EFFI_PIXNET_MFMA", "0")
+    else:
+        monkeypatch.delenv("EFFI_PIXNET_MFMA", raising=False)
     g = load_golden("g03_pixelwise.npz")
     got = net.PixelwiseNet(t(g["entropy"], DEV))
-    check_close("PixelwiseNet (golden)", got, g["weight"], rtol=1e-4, atol=1e-5)
-    check_close("PixelwiseNet (oracle)", got, O.pixelwise_net(sd, "PixelwiseNet", g["entropy"]), rtol=1e-4, atol=1e-5)
+    check_close(f"PixelwiseNet (golden, {form})", got, g["weight"], rtol=1e-4, atol=1e-5)
+    check_close(f"PixelwiseNet (oracle, {form})", got, O.pixelwise_net(sd, "PixelwiseNet", g["entropy"]), rtol=1e-4, atol=1e-5)
+    ent = torch.rand(3, 1, 37, 53, generator=torch.Generator().manual_seed(5)) * 3.0
+    check_close(f"PixelwiseNet 37x53 (oracle, {form})", net.PixelwiseNet(t(ent, DEV)), O.pixelwise_net(sd, "PixelwiseNet", ent),
+                rtol=1e-4, atol=1e-5)
 
 
 def test_view_aggregate():
