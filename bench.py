@@ -753,10 +753,17 @@ def main():
                     "final_depth": perb[-1], "worst_depth_mean_norm": max(x["mean_norm"] for x in perb),
                     "worst_depth_p99_norm": max(x["p99_norm"] for x in perb), "gate": {"final_depth_mean_norm": 1e-2},
                     "pass": bool(perb[-1]["mean_norm"] <= 1e-2)}
+    n_differing = 0
     if rank == 0:
         print(json.dumps(result))
+        ss = result.get("single_stream") or {}
+        n_differing = int(ss.get("timed_in_flight_views_differing_from_single_stream") or 0)
     if distributed:
         dist.destroy_process_group()
+    if n_differing:
+        # a view produced while other views were in flight differs from the same view computed alone: the number above is void
+        print(f"[bench] {n_differing} of the timed in-flight views differ bitwise from the single-stream result", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -36,6 +36,7 @@ SIGNATURES = {
     "effi_deconv3d_k3_f32": [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "effi_softmax_regress_conf_f32": [_vp, _vp, _l, _l, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "effi_vol_lookup1d_f32": [_vp, _l, _l, _i, _vp, _l, _l, _l, _i, _vp, _vp, _l, _i, _i, _vp, _vp],
+    "effi_bilinear_sampler1d_f32": [_vp, _i, _i, _i, _vp, _l, _vp, _vp, _vp],
     "effi_getcost_conv1x1_f32": [_vp, _vp, _i, _i, _vp, _vp, _l, _l, _i, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _i,
                                  _i, _vp, _vp],
     "effi_getcost_f32": [_vp, _vp, _i, _i, _vp, _vp, _l, _l, _i, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _vp, _vp],

@@ -45,7 +45,7 @@ class _Conv2d(torch.autograd.Function):
                 if cin != 1 or act != ops.ACT_RELU or len(xs) != 1:
                     raise NotImplementedError("7x7 convolution: single-channel input followed by ReLU (ProjectionInput.convd1)")
                 w7, b7 = packing.pack_conv2d_c1k7(weight, bias)
-                y = _stack([ops.conv2d_c1k7_relu(xs[0][b], w7, b7, cout) for b in range(B)])
+                y = _stack([ops.conv2d_c1k7_relu(xs[0][b], w7, b7, cout, exact=True) for b in range(B)])
             else:
                 wp, bp = packing.pack_conv2d_mfma(weight, bias)       # exact fp32 products in training, whatever ops.get_precision() says
                 y = _stack([ops.conv2d([x[b] for x in xs], wp, bp, cout, ks, act=act) for b in range(B)])
@@ -258,7 +258,12 @@ def batch_norm_train(x, bn, relu):
     """``bn``: nn.BatchNorm2d / 3d module (its running statistics and counter are updated like nn.BatchNorm does)."""
     if bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    momentum = 0.1 if bn.momentum is None else bn.momentum
+    if bn.momentum is None:                 # nn.BatchNorm: cumulative moving average, factor 1 / num_batches_tracked
+        if bn.num_batches_tracked is None:
+            raise NotImplementedError("batch_norm_train: momentum=None needs track_running_stats (the counter)")
+        momentum = 1.0 / float(bn.num_batches_tracked.item())
+    else:
+        momentum = bn.momentum
     return _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, relu)
 
 

@@ -3,6 +3,10 @@
 #include <hip/hip_runtime.h>
 #include "../../include/effi_mvs_hip.h"
 
+// Launch status of THIS call: every entry point starts by taking (and thereby clearing) whatever non-sticky error an earlier
+// call of the host framework or of this library left pending (effi_s(), below, which every entry uses to unwrap its stream), so
+// a failed launch is reported once, by the entry that failed, and not by every later call.  The check itself peeks: the error
+// stays readable for the host framework (hipGetLastError) after the entry has returned EFFI_ERR_LAUNCH.
 #define EFFI_LAUNCH_CHECK()                                   \
     do {                                                      \
         if (hipPeekAtLastError() != hipSuccess) return EFFI_ERR_LAUNCH; \
@@ -11,7 +15,10 @@
 // zero page of the current device (caller-registered, api.hip); nullptr when none is registered
 const float* effi_zero_page();
 
-static inline hipStream_t effi_s(effi_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline hipStream_t effi_s(effi_stream_t s) {
+    (void)hipGetLastError();            // drop a stale pending error (see EFFI_LAUNCH_CHECK); sticky errors come back on the next check
+    return reinterpret_cast<hipStream_t>(s);
+}
 static inline int effi_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 struct EffiPtrList {            // by-value kernel argument: device pointers of the source views

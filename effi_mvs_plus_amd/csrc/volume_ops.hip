@@ -325,6 +325,27 @@ __device__ __forceinline__ float lookup1d(const float* __restrict__ vol, long ds
     return lookup1d_fetch(vol, dstride, Dp, x0, w0, w1);
 }
 
+// bilinear_sampler (models/Effi_MVS_plus.py:102-117): rows of an [N][C][1][W] image sampled at PIXEL x coordinates, zeros outside,
+// align_corners=True; the row index is 0 whatever ygrid says because H == 1 (grid_sample un-normalises y to 0 * (H - 1) / 2).
+// One thread per (n, query): the sampling position is shared by the C channels.
+__global__ void bilinear_sampler1d_kernel(const float* __restrict__ img, int C, int W, const float* __restrict__ coords, long nq,
+                                          long total, float* __restrict__ out, float* __restrict__ mask) {
+    const long i = (long)blockIdx.x * TPB + threadIdx.x;
+    if (i >= total) return;
+    const long n = i / nq, q = i - n * nq;
+    const float xp = coords[2 * i], yp = coords[2 * i + 1];
+    const float wm1 = (float)(W - 1);
+    const float g = 2.0f * xp / wm1 - 1.0f;                            // :107
+    float ix = ((g + 1.0f) / 2.0f) * wm1;                              // grid_sample, align_corners=True
+    ix = fminf(fmaxf(ix, -2.0f), wm1 + 2.0f);                          // neutral: both taps stay out of range
+    const float x0f = floorf(ix);
+    const int x0 = (int)x0f;
+    const float w1 = ix - x0f, w0 = (x0f + 1.0f) - ix;
+    const float* row = img + n * (long)C * W;
+    for (int c = 0; c < C; ++c) out[(n * C + c) * nq + q] = lookup1d_fetch(row + (long)c * W, 1, W, x0, w0, w1);
+    if (mask) mask[i] = ((g > -1.0f) & (yp > -1.0f) & (g < 1.0f) & (yp < 1.0f)) ? 1.0f : 0.0f;   // :113
+}
+
 // blockIdx.y = 1 (pair launch, effi_vol_lookup1d_pair_f32): the same queries into a second volume of the same shape
 __global__ void vol_lookup1d_kernel(const float* __restrict__ vol, long vds, long vps, int Dp,
                                     const float* __restrict__ query, long qds, long qys, long qxs, int nq,
@@ -642,6 +663,16 @@ extern "C" int effi_vol_lookup1d_f32(const float* vol, long vds, long vps, int D
     if (!vol || !query || !dmin || !dmax || !out || Dp < 2 || nq < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
     hipLaunchKernelGGL(vol_lookup1d_kernel, dim3(effi_cdiv((long)h * w, TPB)), dim3(TPB), 0, effi_s(stream), vol, vds,
                        vps, Dp, query, qds, qys, qxs, nq, dmin, dmax, rps, h, w, out, nullptr, nullptr);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_bilinear_sampler1d_f32(const float* img, int N, int C, int W, const float* coords, long nq, float* out,
+                                           float* mask, effi_stream_t stream) {
+    if (!img || !coords || !out || N < 1 || C < 1 || W < 1 || nq < 1) return EFFI_ERR_BADARG;
+    const long total = (long)N * nq;
+    hipLaunchKernelGGL(bilinear_sampler1d_kernel, dim3(effi_cdiv(total, TPB)), dim3(TPB), 0, effi_s(stream), img, C, W, coords, nq,
+                       total, out, mask);
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
 }

@@ -9,7 +9,7 @@ runs on the other; each slot has its own captured graph).  ``graph(features, cne
 caller's tensors into the slot (device to device) and replays; a producer that writes straight into ``graph.inputs[slot]``
 (or ``graph.load(slot, ...)`` ahead of time) calls ``graph.replay(slot)`` and skips the copy.  The returned tensors are the
 slot's static outputs -- valid until that slot's next replay (clone what must outlive it).  Replay is bitwise identical to
-the eager pass (tools/graph_test.py, tests/test_gpu_model.py).
+the eager pass (tools/graph_replay_check.py, tests/test_gpu_model.py).
 """
 from __future__ import annotations
 

@@ -41,6 +41,18 @@ def depth_to_disp(depth, min_depth, max_depth):
 
 
 @ops.on_tensor_device
+def bilinear_sampler(img, coords, mode='bilinear', mask=False):
+    """Wrapper for grid_sample on pixel coordinates, as the reference defines it (Effi_MVS_plus.py:102-117): img [N,C,1,W],
+    coords [N,Ho,Wo,2] = (x in pixels, y) -> [N,C,Ho,Wo] (with ``mask``: also the in-range mask [N,Ho,Wo,1] as float).  Like
+    the reference it only serves the 1-D ("stereo") case: H must be 1 (AssertionError otherwise); the other half of its assert,
+    ``torch.unique(ygrid).numel() == 1``, is a device sort + host sync with no effect on the values when H == 1 (every y
+    un-normalises to row 0) and is not reproduced.  ``mode`` other than 'bilinear' is ignored by the reference too (:112 does
+    not forward it)."""
+    assert img.shape[-2] == 1   # This is a stereo problem
+    return ops.bilinear_sampler1d(img.contiguous(), coords.contiguous(), want_mask=bool(mask))
+
+
+@ops.on_tensor_device
 def pro_bilinear_sampler(pro, depth_sample, depth_min, depth_max):
     """1-D linear lookup of per-pixel D-vectors at ``depth_sample`` (reference: Effi_MVS_plus.py:118-134).
 

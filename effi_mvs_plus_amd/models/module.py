@@ -360,13 +360,12 @@ class P_1to8_FeatureNet_Fast(nn.Module):
 
     def forward(self, x):
         if self.training:
-            # training: the differentiable HIP operators (forward AND backward), unless the input lives on the CPU
-            # (the stock composite stays available as ``forward_torch``: A/B baseline; note that MIOpen's weight gradient of the
-            # context pyramid's 32->32 3x3 layer on a 16x20 map is off by 7.7 % of its peak against the CPU, tools/diag_fpn.py)
-            if x.is_cuda:
-                from .. import train_path
-                return train_path.feature_pyramid(self, x)
-            return self.forward_torch(x)
+            # training: the differentiable HIP operators (forward AND backward); CPU tensors raise in there like everywhere else on
+            # the path.  (The stock composite stays available as the explicit method ``forward_torch``: A/B baseline only; note that
+            # MIOpen's weight gradient of the context pyramid's 32->32 3x3 layer on a 16x20 map is off by 7.7 % of its peak against
+            # the CPU, tools/diag_fpn.py)
+            from .. import train_path
+            return train_path.feature_pyramid(self, x)
         outs = [self.run(x[i].contiguous()) for i in range(x.shape[0])]
         return {k: _stack([o[k] for o in outs]) for k in outs[0]}
 

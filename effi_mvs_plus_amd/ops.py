@@ -689,6 +689,21 @@ def vol_lookup1d(vol, query, dmin, dmax, h, w):
     return out
 
 
+def bilinear_sampler1d(img, coords, want_mask=False):
+    """``bilinear_sampler`` of the reference (models/Effi_MVS_plus.py:102-117) for H == 1 images: img [N,C,1,W], coords
+    [N,Ho,Wo,2] pixel (x, y) -> [N,C,Ho,Wo] (and the in-range mask [N,Ho,Wo,1] as float)."""
+    _t(img, "img"), _t(coords, "coords")
+    N, Cc, H, W = img.shape
+    if H != 1 or coords.dim() != 4 or coords.shape[0] != N or coords.shape[-1] != 2:
+        raise ValueError("bilinear_sampler1d: img [N,C,1,W] and coords [N,Ho,Wo,2]")
+    Ho, Wo = coords.shape[1:3]
+    out = torch.empty(N, Cc, Ho, Wo, device=img.device, dtype=torch.float32)
+    mask = torch.empty(N, Ho, Wo, 1, device=img.device, dtype=torch.float32) if want_mask else None
+    check(_lib.lib().effi_bilinear_sampler1d_f32(_p(img), N, Cc, W, _p(coords), Ho * Wo, _p(out), _p(mask), _stream()),
+          "effi_bilinear_sampler1d_f32")
+    return (out, mask) if want_mask else out
+
+
 def vol_lookup1d_pair(vol_a, vol_b, query, dmin, dmax, h, w):
     """``vol_lookup1d`` into two planar volumes of the same shape with the same queries, one launch -> (out_a, out_b)."""
     vol_a, vds, vps, Dp = _vol_strides(vol_a, h, w)
@@ -999,12 +1014,14 @@ def conv2d_k5s2(x, wpack, bias, cout, act=ACT_RELU):
     return out
 
 
-def conv2d_c1k7_relu(x, weight, bias, cout, out=None):
+def conv2d_c1k7_relu(x, weight, bias, cout, out=None, exact=False):
+    """7x7 single-input-channel convolution + ReLU (ProjectionInput.convd1).  ``exact``: exact fp32 products whatever
+    ``get_precision()`` says (the training path, whose weight gradient is taken against this output)."""
     _t(x, "conv7 input")
     h, w = x.shape[-2:]
     if out is None:
         out = torch.empty(cout, h, w, device=x.device, dtype=torch.float32)
-    if uses_split() and os.environ.get("EFFI_C1K7_MFMA", "1") != "0":
+    if not exact and uses_split() and os.environ.get("EFFI_C1K7_MFMA", "1") != "0":
         check(_lib.lib().effi_conv2d_c1k7_relu_bf16x3_f32(_p(x), _p(weight), _p(bias), cout, h, w, _p(out), _stream()),
               "effi_conv2d_c1k7_relu_bf16x3_f32")
         return out

@@ -256,6 +256,12 @@ int effi_vol_lookup1d_f32(const float* vol, long vol_dstride, long vol_pstride, 
                           const float* dmin, const float* dmax, long range_pstride,
                           int h, int w, float* out, effi_stream_t stream);
 
+/* bilinear_sampler, models/Effi_MVS_plus.py:102-117 (the public wrapper pro_bilinear_sampler calls): img [N][C][1][W] rows sampled
+ * at pixel coordinates coords [N][nq][2] = (x, y) (linear in x, zeros outside, align_corners=True; H == 1, so y only enters the
+ * optional mask) -> out [N][C][nq]; mask (or NULL) [N][nq] = 1 where -1 < 2x/(W-1)-1 < 1 and -1 < y < 1 (:113). */
+int effi_bilinear_sampler1d_f32(const float* img, int N, int C, int W, const float* coords, long nq, float* out, float* mask,
+                                effi_stream_t stream);
+
 /* ---- K8 inside the GRU loop: GetCost.forward, models/Effi_MVS_plus.py:257-303 with
  * models/Effi_MVS_plus.py:138-148 (scale_inv_depth) applied first.
  * inv_depth [h][w]: normalised inverse depth (input_is_depth = 0; scale_inv_depth is applied in the

@@ -501,6 +501,31 @@ def test_vol_lookup(O):
     check_close("explicit-lerp restatement == grid_sample form", want, g["out_pixel"], rtol=1e-5, atol=1e-6)
 
 
+def test_bilinear_sampler_matches_golden_lookup(O):
+    """``bilinear_sampler`` (reference Effi_MVS_plus.py:102-117) called as ``pro_bilinear_sampler`` calls it (:121-130) reproduces the
+    golden lookup g07 (made by the reference), incl. its out-of-range queries; the mask follows :113."""
+    from effi_mvs_plus_amd.models.Effi_MVS_plus import bilinear_sampler
+    g = load_golden("g07_lookup.npz")
+    vol, q = g["vol"], g["query"]
+    b, D, h, w = vol.shape
+    d = q.shape[1]
+    pro = vol.permute(0, 2, 3, 1).reshape(b * h * w, 1, 1, D).contiguous()
+    for lo, hi, want, name in ((g["gmin"], g["gmax"], g["out_global"], "global"), (g["pmin"], g["pmax"], g["out_pixel"], "per-pixel")):
+        disp = O.depth_to_disp(q, lo, hi) * (D - 1)                                   # :123, plain tensor algebra on the CPU
+        x0 = disp.permute(0, 2, 3, 1).reshape(b * h * w, 1, d, 1)
+        coords = torch.cat([x0, torch.zeros_like(x0)], dim=-1)
+        got, mask = bilinear_sampler(t(pro, DEV), t(coords, DEV), mask=True)
+        assert tuple(got.shape) == (b * h * w, 1, 1, d) and tuple(mask.shape) == (b * h * w, 1, d, 1)
+        got = got.reshape(b, h, w, d).permute(0, 3, 1, 2)
+        check_close(f"bilinear_sampler {name} range (golden)", got, want, rtol=1e-4, atol=2e-5)
+        xg = 2 * coords[..., :1] / (D - 1) - 1
+        want_mask = ((xg > -1) & (xg < 1)).float()                                     # ygrid == 0 passes its two tests
+        assert torch.equal(mask.cpu(), want_mask)
+        assert torch.equal(bilinear_sampler(t(pro, DEV), t(coords, DEV)).cpu(), got.permute(0, 2, 3, 1).reshape(b * h * w, 1, 1, d).cpu())
+    with pytest.raises(AssertionError):
+        bilinear_sampler(torch.zeros(1, 1, 2, 4, device=DEV), torch.zeros(1, 1, 3, 2, device=DEV))   # H != 1: "a stereo problem"
+
+
 def test_getcost_initvolume(model, O):
     net, sd = model
     g = load_golden("g06_initvolume.npz")

@@ -55,6 +55,7 @@ def test_public_signatures_match_the_reference():
     assert params(main.Effi_MVS_plus.forward) == ["imgs", "proj_matrices", "depth_values"]
     assert params(main.pro_bilinear_sampler) == ["pro", "depth_sample", "depth_min", "depth_max"]
     assert params(main.upsample_depth) == ["depth", "mask", "ratio"]
+    assert params(main.bilinear_sampler) == ["img", "coords", "mode", "mask"]
 
 
 def test_library_exports_every_declared_symbol():

@@ -148,3 +148,37 @@ def test_training_mode_loss_and_gradients_match_the_reference(dropout_p):
     assert n_checked > 150
     for k, v in want_stats.items():                     # running statistics were updated the same way
         assert torch.allclose(sd2[k].detach().float(), v.float(), rtol=1e-6, atol=1e-7), k
+
+
+def test_public_callables_of_the_three_mirrored_files_have_the_references_signatures():
+    """Every live public class / function the reference's models/{module,update,Effi_MVS_plus}.py define (dead code of SURVEY
+    section 2 excluded) exists in the mirror with the same parameter names, order and defaults; a mirror may only APPEND
+    keyword arguments with defaults."""
+    import inspect
+    import sys
+
+    from refimport import load_reference
+    import effi_mvs_plus_amd.models  # noqa: F401
+    ref = load_reference()
+    ours = {"main": sys.modules["effi_mvs_plus_amd.models.Effi_MVS_plus"], "module": sys.modules["effi_mvs_plus_amd.models.module"],
+            "update": sys.modules["effi_mvs_plus_amd.models.update"]}
+    live = {
+        "main": ["DepthNet", "bilinear_sampler", "pro_bilinear_sampler", "disp_to_depth", "depth_to_disp", "upsample_depth",
+                 "GetCost_initvolume", "GetCost", "Effi_MVS_plus"],
+        "module": ["homo_warping_new", "Conv3d", "Deconv3d", "Conv2d", "ConvBnReLU", "CostRegNet_2_sample_FPN3D_Fast", "cost_up_small",
+                   "depth_regression", "get_cur_depth_range_samples", "get_depth_range_samples", "P_1to8_FeatureNet_Fast", "mvs_loss"],
+        "update": ["DepthHead", "ConvGRU", "ProjectionInput", "BasicUpdateBlock"],
+    }
+
+    def sigs(obj):
+        fs = [obj.__init__, obj.forward] if inspect.isclass(obj) else [obj]
+        return [[(p.name, p.default if p.default is inspect.Parameter.empty or isinstance(p.default, (int, float, bool, str, type(None), list))
+                  else repr(p.default)) for p in inspect.signature(f).parameters.values()] for f in fs]
+
+    for mod, names in live.items():
+        for name in names:
+            want, got = sigs(getattr(getattr(ref, mod), name)), sigs(getattr(ours[mod], name))
+            for w_, g_ in zip(want, got):
+                assert g_[:len(w_)] == w_, f"{mod}.{name}: {g_} vs reference {w_}"
+                for extra in g_[len(w_):]:
+                    assert extra[1] is not inspect.Parameter.empty, f"{mod}.{name}: appended parameter {extra[0]} needs a default"
