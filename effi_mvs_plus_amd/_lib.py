@@ -74,6 +74,17 @@ SIGNATURES = {
     "effi_head_update_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "effi_conv2d_k3_twice_bf16x3_f32": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "effi_encoder_tail_bf16x3_f32": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp],
+    # split-resident maps of the update block
+    "effi_sr_geometry": [_i, _i, _vp, _vp],
+    "effi_sr_clear_border": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "effi_sr_from_planar_f32": [_vp, _i, _i, _i, _vp, _i, _i, _vp],
+    "effi_split_tanh_relu_stages_sr_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "effi_encoder_inputs_bf16x3_sr": [_vp, _vp, _i, _vp, _vp, _l, _l, _i, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp, _vp,
+                                      _i, _vp, _vp, _i, _i, _vp],
+    "effi_conv2d_k3_bf16x3_sr": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "effi_conv2d_k3_bf16x3_pair_sr": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "effi_conv2d_k3_k1_bf16x3_sr": [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
+    "effi_conv2d_k3_k1_up2x_bf16x3_sr": [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     # scope row n2: training kernels
     "effi_conv_wgrad_f32": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "effi_channel_sum_f32": [_vp, _i, _i, _l, _vp, _vp, _i, _vp],
@@ -94,7 +105,8 @@ SIGNATURES = {
 BF16X3_ENTRIES = ("effi_conv2d_k3_bf16x3_pair_f32", "effi_conv2d_k3_bf16x3_f32", "effi_conv2d_k3_k1_bf16x3_f32",
                   "effi_conv2d_k3_k1_up2x_bf16x3_f32", "effi_conv3d_k3s1_bf16x3_f32", "effi_conv3d_k3s1_roll_bf16x3_f32",
                   "effi_conv3d_k3s1_roll_bf16x3_pair_f32", "effi_deconv3d_k3s2_bf16x3_f32", "effi_encoder_tail_bf16x3_f32", "effi_conv2d_k3_twice_bf16x3_f32",
-                  "effi_conv2d_k5s2_bf16x3_f32", "effi_conv3d_k3s2_bf16x3_f32")
+                  "effi_conv2d_k5s2_bf16x3_f32", "effi_conv3d_k3s2_bf16x3_f32",
+                  "effi_conv2d_k3_bf16x3_sr", "effi_conv2d_k3_bf16x3_pair_sr", "effi_conv2d_k3_k1_bf16x3_sr", "effi_conv2d_k3_k1_up2x_bf16x3_sr")
 for _n in BF16X3_ENTRIES:
     SIGNATURES[_n + "_bf16"] = SIGNATURES[_n]
 

@@ -180,10 +180,62 @@ __device__ __forceinline__ void effi_split8(const float (&x)[8], effi_bf16x8_t& 
     }
 }
 
+typedef __bf16 effi_bf16x4_t __attribute__((ext_vector_type(4)));
+
+// Split-resident activation maps ("SR"): what a split-precision convolution wants to read is not the fp32 value x but its two
+// bf16 halves hi = bf16(x), lo = bf16(x - hi) -- the same 4 bytes -- in the [octet of channels][pixel][8] order of its A
+// fragments.  The layers of the GRU update block feed each other (models/update.py:33-49,69-99,114-141): every map is read by
+// 1-2 convolutions, each of which used to redo the split for every staged pixel, halo included (half of the 1,054 vector
+// instructions per wave of the z / r convolution).  Here the PRODUCER's epilogue splits once and stores
+//     map[octet o][part q in {hi, lo}][row y + 1][column x + 1][channel e]      (bf16; [hp][wp] pixels per plane)
+// and the consumer's staging is a plain 16-byte copy.  The one-pixel zero border (and zeros up to the tile overhang on the right /
+// bottom: hp >= roundup(h, 16) + 2, wp >= roundup(w, 64) + 2) is the convolution's padding: no bounds tests, no zero page.  The
+// values are bitwise those the consumer would have computed from the fp32 map (same conversion instructions), so a chain through
+// SR maps equals the chain through fp32 maps bit for bit.
+// The MFMA result layout gives lane l = li + 16 lk the 4 consecutive channels co0 = 16 n + 4 lk .. + 3 of pixel li: lanes l and l ^ 16
+// hold the two halves of ONE octet of ONE pixel.  Stored as they stand that is two 8-byte pieces per 16-byte unit from
+// non-adjacent lanes -- measured 10-25 % slower per kernel than the fp32 stores they replace.  Instead the pair trades halves
+// (v_permlane16_swap: rows 1 / 3 of the first operand <-> rows 0 / 2 of the second): the even-lk lane ends up with the whole HI
+// octet, the odd-lk lane with the whole LO octet, and every lane issues ONE 16-byte store -- per wave instruction four fully
+// written 256-byte runs (hi / lo planes of two octets).  Must be called by both lanes of a pair (the pair shares its pixel, so a
+// bounds test on the pixel is pair-uniform).
+__device__ __forceinline__ void effi_sr_store4(unsigned short* __restrict__ base, int hp, int wp, int co0, int y, int x, const effi_f32x4_t v) {
+    typedef unsigned effi_u32x2_t __attribute__((ext_vector_type(2)));
+    typedef unsigned effi_u32x4_t __attribute__((ext_vector_type(4)));
+    const effi_bf16x4_t h4 = __builtin_convertvector(v, effi_bf16x4_t);
+    const effi_u32x2_t hu = __builtin_bit_cast(effi_u32x2_t, h4);
+#ifndef EFFI_BF16_ONLY
+    const effi_bf16x4_t l4 = __builtin_convertvector(v - __builtin_convertvector(h4, effi_f32x4_t), effi_bf16x4_t);
+    const effi_u32x2_t lu = __builtin_bit_cast(effi_u32x2_t, l4);
+#else
+    const effi_u32x2_t lu = hu;                 // hi only: the even lane still needs its partner's hi half
+#endif
+    const auto s0 = __builtin_amdgcn_permlane16_swap(hu[0], lu[0], false, false);
+    const auto s1 = __builtin_amdgcn_permlane16_swap(hu[1], lu[1], false, false);
+    // even lk: {own hi, partner's hi} = channels 0-3, 4-7 of the hi octet; odd lk: {partner's lo, own lo} = the lo octet
+    const effi_u32x4_t oct = {s0[0], s1[0], s0[1], s1[1]};
+    const int part = (co0 >> 2) & 1;            // = lk & 1
+#ifdef EFFI_BF16_ONLY
+    if (part) return;
+#endif
+    const long u = ((long)((co0 >> 3) * 2 + part) * hp + (y + 1)) * wp + (x + 1);     // 16-byte unit
+    *reinterpret_cast<effi_u32x4_t*>(base + u * 8) = oct;
+}
+
+// 8 consecutive channels (one octet, co0 % 8 == 0) of pixel (y, x): one 16-byte store per part
+__device__ __forceinline__ void effi_sr_store8(unsigned short* __restrict__ base, int hp, int wp, int co0, int y, int x, const float (&v)[8]) {
+    effi_bf16x8_t hi, lo;
+    effi_split8(v, hi, lo);
+    const long u = ((long)((co0 >> 3) * 2) * hp + (y + 1)) * wp + (x + 1);
+    *reinterpret_cast<effi_bf16x8_t*>(base + u * 8) = hi;
+    *reinterpret_cast<effi_bf16x8_t*>(base + (u + (long)hp * wp) * 8) = lo;
+}
+
 template <int COUT>
 __device__ __forceinline__ void effi_c1k7_relu_tile_x3(const float* __restrict__ in, const float* __restrict__ wgt,
                                                        const float* __restrict__ bias, int h, int w, float* __restrict__ out,
-                                                       int bx, int by) {
+                                                       int bx, int by, unsigned short* __restrict__ out_sr = nullptr, int sr_hp = 0,
+                                                       int sr_wp = 0) {
     constexpr int TXX = EFFI_C1K7_TX, TYY = EFFI_C1K7_TY, IWX = 40, IHY = TYY + 7, NT = COUT / 16;
     static_assert(TXX == 32 && TYY == 8, "16 row segments of 16 pixels, 4 per wave");
     __shared__ float tile[IHY * IWX];                      // rows y0-3 .. y0+TYY+3 (the extra row is multiplied by zero weights)
@@ -240,11 +292,16 @@ __device__ __forceinline__ void effi_c1k7_relu_tile_x3(const float* __restrict__
         if (y >= h || x >= w) continue;
         const long pix = (long)y * w + x;
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+        for (int n = 0; n < NT; ++n) {
+            effi_f32x4_t v;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = 16 * n + 4 * lk + r;
-                out[co * hw + pix] = fmaxf(acc[m][n][r] + bias[co], 0.0f);
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(acc[m][n][r] + bias[16 * n + 4 * lk + r], 0.0f);
+            if (out_sr) {                      // split-resident output (uniform branch)
+                effi_sr_store4(out_sr, sr_hp, sr_wp, 16 * n + 4 * lk, y, x, v);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(16 * n + 4 * lk + r) * hw + pix] = v[r];
             }
+        }
     }
 }

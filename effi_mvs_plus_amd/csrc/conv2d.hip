@@ -12,61 +12,10 @@
 //   B operand  (lane l: k = l>>4, cout l&15): weights are host-packed in exactly that lane order, so each
 //              k-step's B tile is ONE coalesced 256-byte global load (L1/L2 resident, shared by all blocks).
 // Epilogues (bias, activation, GRU gating, depth-head update) are fused; see EFFI_EPI_* in the header.
-#include "common.hpp"
-
-// This file is compiled twice (csrc/Makefile): as it stands, and with -DEFFI_BF16_ONLY, which keeps only the *_bf16x3_* entry points,
-// appends _bf16 to their names and drops the two lo terms of every split product (hi*hi only: plain bf16 operands, fp32
-// accumulation -- BASELINE.json's "bf16 (MFMA 3D-conv path)" configuration).  A compile-time constant, not a runtime flag: a flag
-// tested inside the MFMA loops cost the default build 5 % per view (rolling 3-D conv +17 %).
-#ifdef EFFI_BF16_ONLY
-#define EFFI_FN(name) name##_bf16
-#else
-#define EFFI_FN(name) name
-#endif
+#include "conv2d_x3.hpp"
 
 namespace {
 
-#ifdef EFFI_BF16_ONLY
-constexpr bool kHiOnly = true;
-#else
-constexpr bool kHiOnly = false;
-#endif
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct Conv2dArgs {
-    const float* src[EFFI_MAX_SRC];
-    int ch[EFFI_MAX_SRC];
-    int cin;                 // real input channels (sum of ch[])
-    int kgroups;             // ceil(cin / 4)
-    const float* wpack;      // [kgroups][KS*KS][NT][64]
-    const float* bias;       // [NT*16]
-    int cout, h, w, act, hd;
-    const float* aux0;
-    const float* aux1;
-    const float* disp_range;
-    int n_range;
-    float* out0;
-    float* out1;
-    // z-batched use (3-D convolution as per-plane 2-D convolutions, effi_conv3d_k3s1_mfma_f32): blockIdx.y = z,
-    // source s is plane z + s - 1 of the SAME [cin][D][h][w] tensor (zero when outside), channel strides are D*h*w
-    long cstride;            // input channel stride in floats (hin*win for plain 2-D)
-    long ostride;            // output channel stride
-    int zcount;              // output planes when z-batched, else 0
-    int zin;                 // input planes (= zcount for stride 1; stride-2 3-D convs read a 2x deeper volume)
-    int hin, win;            // input map size (= h, w for stride 1; stride-2 convs read a 2x larger map)
-    const float* zeros;      // >= 64 B of zeros in device memory: where padding is read from (split-precision kernels)
-    const float* xptr0;      // EPI_K1UP: the hypotheses' inverse-depth range (first / last entry used), zin = its length
-};
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-    switch (act) {
-        case EFFI_ACT_RELU: return fmaxf(v, 0.0f);
-        case EFFI_ACT_SIGMOID: return effi_sigmoid(v);
-        case EFFI_ACT_TANH: return tanhf(v);
-        default: return v;
-    }
-}
 
 template <int KS, int NT, int EPI>
 __global__ __launch_bounds__(256) void conv2d_mfma_kernel(const Conv2dArgs a) {
@@ -283,80 +232,6 @@ __device__ __forceinline__ void conv_epilogue_store(const Conv2dArgs& a, float (
     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
-// Epilogue for the TRANSPOSED fragment layout (MFMA called as weights x pixels, D[cout][pixel]): a lane holds output
-// channels co0..co0+3 of ONE pixel, and the 16 lanes of a lane group hold 16 consecutive pixels of a row, so every store /
-// auxiliary load of a wave instruction is 4 runs of 64 contiguous bytes written by ADJACENT lanes (they coalesce), instead of
-// 16 scattered 16-byte pieces per run as in the pixel-major layout above -- the store phase of the planar epilogues was the
-// largest single cost of the memory-bound layers.  Channel-last output becomes one float4 per lane, 1 KB contiguous per wave.
-template <int EPI>
-__device__ __forceinline__ void conv_epilogue_store_t(const Conv2dArgs& a, const f32x4& acc, int co0, long pix, long hw,
-                                                      int zpl) {
-    constexpr bool kShuf = (EPI == EFFI_EPI_ADD_SHUF2 || EPI == EFFI_EPI_NHWC_ADD_SHUF2);
-    constexpr bool kNhwc = (EPI == EFFI_EPI_NHWC || EPI == EFFI_EPI_NHWC_ADD_SHUF2);
-    constexpr bool kPlain = (EPI == EFFI_EPI_PLAIN || EPI == EFFI_EPI_ADD_SHUF2);
-    float v[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = acc[r] + a.bias[co0 + r];       // bias is padded to 16*NT entries
-    if (kNhwc || kPlain) {                                             // activation: one uniform branch for the 4 values
-        if (a.act == EFFI_ACT_RELU) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
-        } else if (a.act != EFFI_ACT_NONE) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], a.act);
-        }
-    }
-    if (kShuf) {
-        // + a coarser map with the four sub-pixel parities as channel groups (pixel shuffle): aux0 planar [4*cout][h/2][w/2],
-        // channel ((y & 1) * 2 + (x & 1)) * cout + co at (y >> 1, x >> 1) -- the nearest-upsampled branch of the pyramid's last
-        // head, evaluated at half resolution (models/module.py:407-408, see packing.pack_fpn_head_split)
-        const int y = (int)(pix / a.w), x = (int)(pix - (long)y * a.w);
-        const long hw4 = (long)(a.h >> 1) * (a.w >> 1);
-        const float* up = a.aux0 + (long)(((y & 1) * 2 + (x & 1)) * a.cout + co0) * hw4 + (long)(y >> 1) * (a.w >> 1) + (x >> 1);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (co0 + r < a.cout) v[r] = v[r] + up[(long)r * hw4];
-    }
-    if (kNhwc) {
-        if (co0 + 3 < a.cout) {
-            *reinterpret_cast<float4*>(a.out0 + pix * a.cout + co0) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (co0 + r < a.cout) a.out0[pix * a.cout + co0 + r] = v[r];
-        }
-        return;
-    }
-    // channel guard: one test per group of 4 when cout is a multiple of 4 (every layer of the model), else per channel
-    const int nvalid = ((a.cout & 3) == 0) ? (co0 < a.cout ? 4 : 0) : a.cout - co0;
-    if (kPlain) {
-        float* dst = a.out0 + (long)co0 * a.ostride + (long)zpl * hw + pix;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (r < nvalid) dst[(long)r * a.ostride] = v[r];
-    } else if (EPI == EFFI_EPI_GRU_ZR) {         // co0 is a multiple of 4 and hd of 16: the 4 channels are all z or all r
-        if (nvalid <= 0) return;                 // cout % 16 == 0 for the GRU epilogues (checked by the host): all or nothing
-        const bool is_z = co0 < a.hd;
-        const long o = (long)(is_z ? co0 : co0 - a.hd) * hw + pix;
-        float* dst = (is_z ? a.out0 : a.out1) + o;
-        float hv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) hv[r] = a.aux0[o + (long)r * hw];              // r*h needs h; harmless extra read for z
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dst[(long)r * hw] = effi_sigmoid_split(v[r]) * (is_z ? 1.0f : hv[r]);
-    } else if (EPI == EFFI_EPI_GRU_Q) {
-        if (nvalid <= 0) return;
-        const long o = (long)co0 * hw + pix;
-        float hv[4], zv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            hv[r] = a.aux0[o + (long)r * hw];
-            zv[r] = a.aux1[o + (long)r * hw];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) a.out0[o + (long)r * hw] = (1.0f - zv[r]) * hv[r] + zv[r] * effi_tanh_split(v[r]);
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // v3 (used whenever w % 4 == 0): both operands come from LDS inside the k-loop, workgroups are persistent.
@@ -567,392 +442,6 @@ __global__ __launch_bounds__(256) void conv2d_mfma_v2_kernel(const Conv2dArgs a,
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Split-precision 3x3 convolution ("bf16x3"): every fp32 operand is written as hi + lo with hi = bf16(x),
-// lo = bf16(x - hi), and a product is evaluated as hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 with fp32
-// accumulation (the dropped lo*lo term and the bf16 rounding of lo are ~2^-17 relative, i.e. ~1e-5 vs 6e-8 for the
-// exact fp32 MFMA).  One bf16 MFMA covers K = 32 in 16 cycles where the fp32 MFMA covers K = 4 in 32-40, so the three
-// MFMAs per product are still ~6x cheaper; the three run back to back on the same accumulator.
-//   * chunk = 16 input channels.  K index inside a chunk = (tap, octet of 8 channels); a K-step of 32 = 4 such items
-//     (lane quarter q = lane>>4 owns item 4s+q), 9 taps x 2 octets = 18 items -> 5 K-steps (the last two items are zero).
-//   * A tile in LDS is bf16 [octet][pixel][8 ch] for hi and for lo, so a lane's fragment (8 consecutive channels of one
-//     pixel at one tap) is ONE ds_read_b128 and the 16 pixels of a lane group sit in 16 consecutive 16-byte slots = all 64
-//     banks (conflict-free whatever the tap shift).  Staging does the transposition in registers: a thread owns (4 pixels,
-//     8 channels) = 8 coalesced float4 loads from the planar fp32 map, splits them and writes 2 x 4 ds_write_b128; pixel
-//     slot p is stored at p ^ ((p >> 3) & 1), which keeps the reads conflict-free and makes the stores 2-way (13 vs 16
-//     LDS cycles) instead of 4-way.
-//   * B fragments are pre-split and pre-ordered by the host ([chunk][K-step][N-tile][hi|lo][lane][8] bf16) and copied to LDS.
-// Same tiling (16 x 4*MR pixels per workgroup), prefetch-into-registers structure and epilogues as the fp32 kernel.
-// ------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-// ZB = z-batched (3-D convolution, effi_conv3d_k3s1_bf16x3_f32): blockIdx.y = output plane z, the effective input channels
-// are (dz, c) = cat over dz of the sources' channels at plane z + dz - 1 (zero outside), channel strides D*h*w.
-//
-// These layers are bound by the vector-ALU instruction count around the MFMAs (measured: 751 VALU instructions per wave and
-// tile for 60 MFMAs before this form), so the staging is written for few instructions:
-//   * every source but the last has a multiple of 8 channels (checked by the host), so a thread's octet of 8 channels lies in
-//     one source: ONE source/plane selection per chunk, then 8 loads at p + e*cstride;
-//   * padding outside the map / the volume is read from a zero page (base and channel step are selected once per chunk)
-//     instead of being masked; channels beyond cin re-read the last real channel (their weights are zero);
-//   * fp32 -> (hi, lo) uses the packed conversion (v_cvt_pk_bf16_f32) on channel pairs;
-//   * A fragments sit at lane_base + koff[s] + m*row with the row term as an immediate (no address swizzle: the stores are then
-//     4-way instead of 2-way conflicted, ~0.5k LDS cycles per tile, against ~150 address instructions per wave).
-#define EFFI_EPI_K1 6        // internal: the 3x3 result (+ extra channels) goes through a fused 1x1 convolution (see below)
-#define EFFI_EPI_K1UP 8      // internal: K1 producing the 36-channel convex-upsampling mask, consumed in registers (see below)
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// 8 fp32 channels of 4 pixels (pa[e] = 4 pixels of channel e) -> hi/lo bf16x8 of pixel px
-__device__ __forceinline__ void split_octet(const f32x4 (&pa)[8], int px, bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-        const f32x2 x = {pa[e][px], pa[e + 1][px]};
-        const bf16x2 h2 = __builtin_convertvector(x, bf16x2);
-        const f32x2 hf = __builtin_convertvector(h2, f32x2);
-        const bf16x2 l2 = __builtin_convertvector(x - hf, bf16x2);
-        hi[e] = h2[0];
-        hi[e + 1] = h2[1];
-        lo[e] = l2[0];
-        lo[e + 1] = l2[1];
-    }
-}
-
-// WIDE: the workgroup's tile is 4 rows x 16*MR columns (one row per wave, MR column groups per wave) instead of 4*MR rows x 16
-// columns: same LDS image size and halo factor, but every row segment the tile reads (64*MR + 32 bytes) and writes (64*MR bytes)
-// is MR times longer, which is what HBM likes once the working set no longer fits the 256 MB MALL.
-template <int NT, int MR, int EPI, bool ZB, bool WIDE>
-__device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int tiles_x, int ntiles, int bid, int nbid, int bidy) {
-    constexpr int TR = WIDE ? 4 : 4 * MR, TW = WIDE ? 16 * MR : 16;
-    constexpr int AR = TR + 2, AW = TW + 8, AQ = AW / 4, XOFF = 3, XLEFT = 4, CCH = 16, NKS = 5;
-    constexpr int MROW = WIDE ? 0 : AW * 8, MCOL = WIDE ? 16 * 8 : 0;   // LDS element step between a wave's MR sub-tiles
-    constexpr int APIX = AR * AW, NITEMS = (APIX / 4) * 2;             // staging work items: (pixel quad, octet)
-    constexpr int NBF = NKS * NT * 2 * 64;                             // 16-byte units of B per chunk
-    constexpr int NB4 = (NBF + 255) / 256;
-    static_assert(NITEMS <= 256, "one staging item per thread");
-    static_assert(EPI != EFFI_EPI_HEAD && EPI != EFFI_EPI_ADD_UP2, "epilogue not instantiated for the split-precision kernel");
-    static_assert((EPI != EFFI_EPI_K1 && EPI != EFFI_EPI_K1UP) || !ZB, "the fused 1x1 epilogue is 2-D only");
-    __shared__ __attribute__((aligned(16))) unsigned short lds_ah[APIX * CCH];
-    __shared__ __attribute__((aligned(16))) unsigned short lds_al[APIX * CCH];
-    __shared__ __attribute__((aligned(16))) unsigned short lds_b[NB4 * 256 * 8];
-
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int li = lane & 15, lk = lane >> 4;
-    const int h = a.h, w = a.w;
-    const long hw = (long)h * w;
-    const int tile = effi_xcd_remap(bid, nbid);
-    if (tile >= ntiles) return;
-    const int ty_ = tile / tiles_x;
-    const int x0 = (tile - ty_ * tiles_x) * TW, y0 = ty_ * TR;
-    const int zpl = ZB ? bidy : 0;
-
-    // staging item of this thread
-    const bool stager = tid < NITEMS;
-    const int pq = stager ? tid % (APIX / 4) : 0, soct = stager ? tid / (APIX / 4) : 0;
-    const int srow = pq / AQ, sqx = pq - srow * AQ;
-    const int sgy = y0 - 1 + srow, sgx = x0 - XLEFT + 4 * sqx;
-    const bool s_in = stager & (sgy >= 0) & (sgy < h) & (sgx >= 0) & (sgx < w);
-    const int s_off = sgy * w + sgx;
-    const int s_lds = (soct * APIX + srow * AW + 4 * sqx) * 8;         // bf16 index of the quad in its octet plane
-    const int s_nv = w - sgx;                                          // elements of the quad inside its row (ZB: w % 4 may be != 0)
-    const bool s_part = s_nv < 4;
-
-    f32x4 pa[8];                                      // raw loads: pa[e] = 4 pixels of channel e of the octet
-    const int cin_eff = ZB ? 3 * a.cin : a.cin;
-    const int nchunks = (cin_eff + CCH - 1) / CCH;
-    const unsigned short* wbf = reinterpret_cast<const unsigned short*>(a.wpack);
-    auto prefetch = [&](int ch) {
-        int cb = ch * CCH + soct * 8;                                  // first channel of this thread's octet
-        const int emax = min(cin_eff - cb, 8) - 1;                     // last real channel of the octet (< 0: none)
-        bool in = s_in & (emax >= 0);
-        long zoff = 0;
-        if (ZB) {
-            const int dz = (cb >= a.cin) + (cb >= 2 * a.cin);          // a.cin % 8 == 0: the octet lies in one plane
-            cb -= dz * a.cin;
-            const int zz = zpl + dz - 1;
-            in &= (zz >= 0) & (zz < a.zcount);
-            zoff = (long)zz * hw;
-        }
-        const int c1 = cb - a.ch[0], c2 = c1 - a.ch[1];
-        const float* src = (c1 < 0) ? a.src[0] : (c2 < 0 ? a.src[1] : a.src[2]);
-        const int cl = (c1 < 0) ? cb : (c2 < 0 ? c1 : c2);
-        const float* base = in ? src + ((long)cl * a.cstride + zoff + s_off) : a.zeros;
-        const long step = in ? a.cstride : 0;
-        const float* q = base;
-        if (ZB && in && s_part) {
-            // rows that are not a multiple of 4 long (the U-Net's coarsest level is 50 wide at 1600x1184): the quad that straddles the
-            // row end takes its 1-3 valid elements one by one (the vector load would pick up the next row and could leave the tensor)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float t0 = q[0], t1 = (s_nv > 1) ? q[1] : 0.0f, t2 = (s_nv > 2) ? q[2] : 0.0f;
-                pa[e] = f32x4{t0, t1, t2, 0.0f};
-                q += (e < emax) ? step : 0;
-            }
-            return;
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            pa[e] = *reinterpret_cast<const f32x4*>(q);
-            q += (e < emax) ? step : 0;                                // channels past the last real one re-read it
-        }
-    };
-    // A: split + transpose out of the prefetch registers.  B (pre-split by the host, L2-resident, identical for every
-    // workgroup) is copied global -> LDS (all its loads are issued before the first use; the LDS image is padded to whole
-    // 256-thread passes so the copy needs no predicate).
-    auto stash = [&](int ch) {
-        f32x4 tb[NB4];
-#pragma unroll
-        for (int j = 0; j < NB4; ++j) {
-            const int u = min(tid + j * 256, NBF - 1);
-            tb[j] = *reinterpret_cast<const f32x4*>(wbf + ((long)ch * NBF + u) * 8);
-        }
-        if (stager) {
-#pragma unroll
-            for (int px = 0; px < 4; ++px) {
-                bf16x8 hi, lo;
-                split_octet(pa, px, hi, lo);
-                *reinterpret_cast<bf16x8*>(&lds_ah[s_lds + px * 8]) = hi;
-                if (!kHiOnly) *reinterpret_cast<bf16x8*>(&lds_al[s_lds + px * 8]) = lo;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NB4; ++j) *reinterpret_cast<f32x4*>(&lds_b[(tid + j * 256) * 8]) = tb[j];
-    };
-
-    // fragment addressing: lane (pixel li, quarter lk) owns item 4s + lk = (tap, octet) of K-step s
-    int koff[NKS];
-#pragma unroll
-    for (int s_ = 0; s_ < NKS; ++s_) {
-        const int item = 4 * s_ + lk;
-        const int tap = min(item >> 1, 8), oct = item & 1;               // items 18, 19 are padding (B is zero there)
-        koff[s_] = (((WIDE ? wv : wv * MR) + tap / 3) * AW + li + XOFF + tap % 3 + oct * APIX) * 8;
-    }
-
-    f32x4 acc[MR][NT];
-#pragma unroll
-    for (int m = 0; m < MR; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
-    prefetch(0);
-    stash(0);
-    __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
-        if (ch + 1 < nchunks) prefetch(ch + 1);
-#pragma unroll
-        for (int s_ = 0; s_ < NKS; ++s_) {
-            bf16x8 ah[MR], al[MR];
-#pragma unroll
-            for (int m = 0; m < MR; ++m) {
-                ah[m] = *reinterpret_cast<const bf16x8*>(&lds_ah[koff[s_] + m * (MROW + MCOL)]);
-                if (!kHiOnly) al[m] = *reinterpret_cast<const bf16x8*>(&lds_al[koff[s_] + m * (MROW + MCOL)]);
-            }
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&lds_b[(((s_ * NT + n) * 2 + 0) * 64 + lane) * 8]);
-                bf16x8 bl = bh;
-                if (!kHiOnly) bl = *reinterpret_cast<const bf16x8*>(&lds_b[(((s_ * NT + n) * 2 + 1) * 64 + lane) * 8]);
-#pragma unroll
-                for (int m = 0; m < MR; ++m) {
-                    // weights x pixels: D[cout][pixel] (transposed fragment, see conv_epilogue_store_t)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[m], acc[m][n], 0, 0, 0);
-                    if (!kHiOnly) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[m], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[m], acc[m][n], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        if (ch + 1 < nchunks) {
-            __syncthreads();
-            stash(ch + 1);
-            __syncthreads();
-        }
-    }
-
-    if (EPI == EFFI_EPI_K1 || EPI == EFFI_EPI_K1UP) {
-        // Fused 1x1 convolution (convd -> convc of the encoder, models/update.py:78-80,93-96): the 3x3 result of a lane
-        // -- channels 4*lk..4*lk+3 of pixel li, per N-tile -- is exactly the B fragment of v_mfma_f32_16x16x16_bf16 (K = 16
-        // channels), so out2[co2][px] = sum_k W2[co2][k] * cat(conv3x3 + b1, extra)[k][px] needs no data movement: one K = 16 step
-        // per N-tile plus one for the extra (context) channels, weights W2 as A fragments from a small L2-resident table.
-        // Fields reused: aux0 = extra [c_extra][h][w], hd = c_extra, aux1 = W2 fragments (bf16 [NT2][NT+1][hi|lo][64][4]),
-        // disp_range = bias2 (padded to 16*NT2), n_range = cout2, act = activation of the 1x1 result, kgroups = 1 if the 3x3
-        // result passes through a ReLU first (mask head, models/update.py:112-114).
-        const unsigned short* w2 = reinterpret_cast<const unsigned short*>(a.aux1);
-        const int nt2 = (a.n_range + 15) >> 4;
-        const bool relu1 = a.kgroups != 0;
-        // B fragments of all the wave's pixels first (the extra-channel loads are issued together), then per output tile
-        // the W2 fragments are fetched once and reused for the MR sub-tiles
-        bf16x4 xh[MR][NT + 1], xl[MR][NT + 1];
-        bool inside[MR];
-        long pixm[MR];
-        f32x4 ex[MR];
-#pragma unroll
-        for (int m = 0; m < MR; ++m) {
-            const int x = x0 + li + (WIDE ? 16 * m : 0);
-            const int y = y0 + (WIDE ? wv : wv * MR + m);
-            inside[m] = (y < h) & (x < w);
-            pixm[m] = inside[m] ? (long)y * w + x : 0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = 4 * lk + r;
-                ex[m][r] = (c < a.hd) ? a.aux0[(long)c * hw + pixm[m]] : 0.0f;   // a.hd == 0: aux0 is a valid dummy, never read
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < MR; ++m) {
-#pragma unroll
-            for (int n = 0; n <= NT; ++n) {
-                f32x4 vf;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    vf[r] = (n < NT) ? acc[m][n][r] + a.bias[n * 16 + 4 * lk + r] : (inside[m] ? ex[m][r] : 0.0f);
-                if (relu1 && n < NT) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) vf[r] = fmaxf(vf[r], 0.0f);
-                }
-                xh[m][n] = __builtin_convertvector(vf, bf16x4);
-                xl[m][n] = __builtin_convertvector(vf - __builtin_convertvector(xh[m][n], f32x4), bf16x4);
-            }
-        }
-        if constexpr (EPI == EFFI_EPI_K1UP) {
-            // Mask head + convex upsampling (models/update.py:109-112,136-138 + upsample_depth, models/Effi_MVS_plus.py:167-178 +
-            // scale_inv_depth): the 36 mask values of a pixel never reach HBM.  The host orders the rows of the 1x1 convolution so that
-            // row 16 t + 4 lk + r is mask entry (tap k = 4 t + r, sub-pixel lk) (packing.pack_mask_taps_per_lane; rows with k > 8 are
-            // zero): a lane holds all nine taps of ONE sub-pixel of its pixel, so the softmax over the taps and the weighted sum of the
-            // 3x3 inverse-depth neighbourhood need no cross-lane traffic, and every lane stores one output value (the 16 pixels x 2
-            // columns of a sub-pixel row are 32 consecutive floats).  aux0 = inverse depth [h][w], out0 / out1 = depth /
-            // depth_to_disp(depth) [2h][2w], xptr0 / zin = the hypotheses' range.
-            f32x4 om[MR][3];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                bf16x4 wh[NT + 1], wl[NT + 1];
-#pragma unroll
-                for (int n = 0; n <= NT; ++n) {
-                    const long f = ((long)(t * (NT + 1) + n) * 2) * 64 + lane;
-                    wh[n] = *reinterpret_cast<const bf16x4*>(w2 + f * 4);
-                    wl[n] = *reinterpret_cast<const bf16x4*>(w2 + (f + 64) * 4);
-                }
-                const int co = t * 16 + 4 * lk;
-#pragma unroll
-                for (int m = 0; m < MR; ++m) {
-                    f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                    for (int n = 0; n <= NT; ++n) {
-                        o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[n], xh[m][n], o, 0, 0, 0);
-                        if (!kHiOnly) {
-                            o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wl[n], xh[m][n], o, 0, 0, 0);
-                            o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[n], xl[m][n], o, 0, 0, 0);
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) om[m][t][r] = o[r] + a.disp_range[co + r];
-                }
-            }
-            const float lo = a.xptr0[0], hi = a.xptr0[a.zin - 1];
-            const int W2 = 2 * w;
-#pragma unroll
-            for (int m = 0; m < MR; ++m) {
-                if (!inside[m]) continue;
-                const int x = x0 + li + (WIDE ? 16 * m : 0);
-                const int y = y0 + (WIDE ? wv : wv * MR + m);
-                float v[9], nbv[9];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    v[k] = om[m][k >> 2][k & 3];
-                    const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
-                    const bool ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w);
-                    nbv[k] = ok ? a.aux0[ok ? (long)yy * w + xx : 0] : 0.0f;         // F.unfold zero padding
-                }
-                float mx = v[0];
-#pragma unroll
-                for (int k = 1; k < 9; ++k) mx = fmaxf(mx, v[k]);
-                float e[9], sm = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-#ifdef EFFI_EXACT_EPILOGUES
-                    e[k] = expf(v[k] - mx);
-#else
-                    e[k] = effi_exp_fast(v[k] - mx);                 // argument <= 0: no overflow; see effi_sigmoid_split
-#endif
-                    sm = sm + e[k];
-                }
-                float ac = 0.0f;
-#ifdef EFFI_EXACT_EPILOGUES
-#pragma unroll
-                for (int k = 0; k < 9; ++k) ac = ac + (e[k] / sm) * nbv[k];
-#else
-                const float rsm = effi_rcp_refined(sm);              // 1 <= sm <= 9
-#pragma unroll
-                for (int k = 0; k < 9; ++k) ac = ac + (e[k] * rsm) * nbv[k];
-#endif
-                const long o = (long)(2 * y + (lk >> 1)) * W2 + 2 * x + (lk & 1);
-                const float dep = effi_inv_to_depth(ac, lo, hi);
-                a.out0[o] = dep;
-                if (a.out1) a.out1[o] = effi_depth_to_inv(dep, lo, hi);
-            }
-            return;
-        }
-        for (int t = 0; t < nt2; ++t) {
-            bf16x4 wh[NT + 1], wl[NT + 1];
-#pragma unroll
-            for (int n = 0; n <= NT; ++n) {
-                const long f = ((long)(t * (NT + 1) + n) * 2) * 64 + lane;
-                wh[n] = *reinterpret_cast<const bf16x4*>(w2 + f * 4);
-                wl[n] = *reinterpret_cast<const bf16x4*>(w2 + (f + 64) * 4);
-            }
-            const int co = t * 16 + 4 * lk;
-            float b2[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) b2[r] = a.disp_range[co + r];
-#pragma unroll
-            for (int m = 0; m < MR; ++m) {
-                f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (int n = 0; n <= NT; ++n) {
-                    o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[n], xh[m][n], o, 0, 0, 0);
-                    if (!kHiOnly) {
-                        o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wl[n], xh[m][n], o, 0, 0, 0);
-                        o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh[n], xl[m][n], o, 0, 0, 0);
-                    }
-                }
-                if (inside[m]) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = o[r] + b2[r];
-                        if (a.act == EFFI_ACT_RELU) v = fmaxf(v, 0.0f);
-                        if (co + r < a.n_range) a.out0[(long)(co + r) * hw + pixm[m]] = v;
-                    }
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int m = 0; m < MR; ++m) {
-        const int x = x0 + li + (WIDE ? 16 * m : 0);                   // lane = (pixel li, channels 4*lk .. 4*lk+3)
-        const int y = y0 + (WIDE ? wv : wv * MR + m);
-        if (y >= h || x >= w) continue;
-        const long pix = (long)y * w + x;
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-            conv_epilogue_store_t<((EPI == EFFI_EPI_K1 || EPI == EFFI_EPI_K1UP) ? EFFI_EPI_PLAIN : EPI)>(a, acc[m][n], n * 16 + 4 * lk, pix, hw, zpl);
-    }
-}
-
-template <int NT, int MR, int EPI, bool ZB = false, bool WIDE = false>
-__global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs a, int tiles_x, int ntiles) {
-    conv2d_k3_bf16x3_tile<NT, MR, EPI, ZB, WIDE>(a, tiles_x, ntiles, blockIdx.x, gridDim.x, blockIdx.y);
-}
-
-// Two independent convolutions of the same shape (NT, h, w) in one launch: blockIdx.y picks the argument set.  Used for the
-// update block's convc2 / convd2 (models/update.py:87,91), which would otherwise be forked onto two streams.
-template <int NT, int MR, bool WIDE>
-__global__ __launch_bounds__(256) void conv2d_k3_bf16x3_pair_kernel(const Conv2dArgs a0, const Conv2dArgs a1, int tiles_x, int ntiles) {
-    if (blockIdx.y == 0) conv2d_k3_bf16x3_tile<NT, MR, EFFI_EPI_PLAIN, false, WIDE>(a0, tiles_x, ntiles, blockIdx.x, gridDim.x, 0);
-    else conv2d_k3_bf16x3_tile<NT, MR, EFFI_EPI_PLAIN, false, WIDE>(a1, tiles_x, ntiles, blockIdx.x, gridDim.x, 0);
-}
 
 // ------------------------------------------------------------------------------------------------
 // TWO chained 3x3 layers in one kernel, the intermediate map in LDS only ("tail" of the update block's encoder,
@@ -2430,85 +1919,6 @@ extern "C" int EFFI_FN(effi_conv3d_k3s2_bf16x3_f32)(const float* in, int cin, co
     return launch_s2_x3<3, 2, true>(a, (nt + 1) / 2, st);
 }
 
-// ---- split-bf16 3x3 convolution entry --------------------------------------------------------------------------
-// Thresholds of the rows-per-wave choice below (workgroup counts); the environment overrides are for A/B runs of the rule
-// (with several views in flight the chip is filled by other views' kernels, which favours the larger tiles earlier).
-static long effi_env_long(const char* name, long dflt) {
-    const char* v = getenv(name);
-    return v ? atol(v) : dflt;
-}
-static long effi_mr4_min() { static const long v = effi_env_long("EFFI_MR4_MIN", 400); return v; }
-static long effi_mr4_nt2_max() { static const long v = effi_env_long("EFFI_MR4_NT2_MAX", 1024); return v; }
-static long effi_mr2_min() { static const long v = effi_env_long("EFFI_MR2_MIN", 400); return v; }
-// Rows per wave (MR): 4 rows amortise the B fragments best, but the grid must still cover the 256 CUs (>= ~400 workgroups),
-// and with two N-tiles the 4-row variant drops to 2 workgroups per CU where the 2-row one keeps 4: on large maps the latter
-// wins.  (Persistent workgroups with cross-tile prefetch were built and measured twice: no gain, more registers.)
-template <int NT, int EPI, bool ZB = false>
-static int launch_bf16x3(const Conv2dArgs& a, hipStream_t st) {
-    const long cols = effi_cdiv(a.w, 16);
-    const long planes = ZB ? a.zcount : 1;
-    const long t4 = cols * effi_cdiv(a.h, 16) * planes, t2 = cols * effi_cdiv(a.h, 8) * planes;
-    int mr;
-    if (t4 >= effi_mr4_min() && !(NT == 2 && t4 >= effi_mr4_nt2_max())) mr = 4;
-    else if (t2 >= effi_mr2_min()) mr = 2;
-    else mr = 1;
-    static const char* force = getenv("EFFI_FORCE_MR");
-    if (force) mr = atoi(force);
-    // wide tiles (4 rows x 64 columns) pay off on the large maps only (measured with an HBM-cold working set, 592x800:
-    // 16->16 23.8 -> 22.6 us, 32->12 33.3 -> 30.7, 32->16 GRU update 41.9 -> 38.6; 296x400: 38 -> 49 us for 64->64)
-    static const char* wide_env = getenv("EFFI_WIDE_TILES");
-    const bool wide = wide_env ? atoi(wide_env) != 0 : (mr == 4 && a.w >= 512 && !ZB);
-    if (wide) {
-        const int tiles_x = effi_cdiv(a.w, 16 * mr), ntiles = tiles_x * effi_cdiv(a.h, 4);
-        const dim3 grid(ntiles, (unsigned)planes);
-        if (mr == 4) hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 4, EPI, ZB, true>), grid, dim3(256), 0, st, a, tiles_x, ntiles);
-        else if (mr == 2) hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 2, EPI, ZB, true>), grid, dim3(256), 0, st, a, tiles_x, ntiles);
-        else hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 1, EPI, ZB, true>), grid, dim3(256), 0, st, a, tiles_x, ntiles);
-        return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
-    }
-    const int tiles_x = (int)cols, ntiles = tiles_x * effi_cdiv(a.h, 4 * mr);
-    const dim3 grid(ntiles, (unsigned)planes);
-    if (mr == 4) hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 4, EPI, ZB>), grid, dim3(256), 0, st, a, tiles_x, ntiles);
-    else if (mr == 2) hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 2, EPI, ZB>), grid, dim3(256), 0, st, a, tiles_x, ntiles);
-    else hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 1, EPI, ZB>), grid, dim3(256), 0, st, a, tiles_x, ntiles);
-    return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
-}
-
-template <int EPI>
-static int dispatch_bf16x3(const Conv2dArgs& a, int nt, hipStream_t st) {
-    switch (nt) {
-        case 1: return launch_bf16x3<1, EPI>(a, st);
-        case 2: return launch_bf16x3<2, EPI>(a, st);
-        case 3: return launch_bf16x3<3, EPI>(a, st);
-        case 4: return launch_bf16x3<4, EPI>(a, st);
-        case 6: return launch_bf16x3<6, EPI>(a, st);
-        default: return EFFI_ERR_UNSUPPORTED;
-    }
-}
-
-// Pair launch (see conv2d_k3_bf16x3_pair_kernel): tile shape chosen as launch_bf16x3 does for two planes.
-template <int NT>
-static int launch_bf16x3_pair(const Conv2dArgs& a0, const Conv2dArgs& a1, hipStream_t st) {
-    const long cols = effi_cdiv(a0.w, 16);
-    const long t4 = cols * effi_cdiv(a0.h, 16) * 2, t2 = cols * effi_cdiv(a0.h, 8) * 2;
-    int mr;
-    if (t4 >= effi_mr4_min() && !(NT == 2 && t4 >= effi_mr4_nt2_max())) mr = 4;
-    else if (t2 >= effi_mr2_min()) mr = 2;
-    else mr = 1;
-    static const char* force = getenv("EFFI_FORCE_MR");
-    if (force) mr = atoi(force);
-    if (mr == 4 && a0.w >= 512) {
-        const int tiles_x = effi_cdiv(a0.w, 64), ntiles = tiles_x * effi_cdiv(a0.h, 4);
-        hipLaunchKernelGGL((conv2d_k3_bf16x3_pair_kernel<NT, 4, true>), dim3(ntiles, 2), dim3(256), 0, st, a0, a1, tiles_x, ntiles);
-        return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
-    }
-    const int tiles_x = (int)cols, ntiles = tiles_x * effi_cdiv(a0.h, 4 * mr);
-    const dim3 grid(ntiles, 2);
-    if (mr == 4) hipLaunchKernelGGL((conv2d_k3_bf16x3_pair_kernel<NT, 4, false>), grid, dim3(256), 0, st, a0, a1, tiles_x, ntiles);
-    else if (mr == 2) hipLaunchKernelGGL((conv2d_k3_bf16x3_pair_kernel<NT, 2, false>), grid, dim3(256), 0, st, a0, a1, tiles_x, ntiles);
-    else hipLaunchKernelGGL((conv2d_k3_bf16x3_pair_kernel<NT, 1, false>), grid, dim3(256), 0, st, a0, a1, tiles_x, ntiles);
-    return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
-}
 
 static int fill_bf16x3_plain(Conv2dArgs& a, const float* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
                              const float* bias, int cout, int h, int w, int act, float* out0) {

@@ -402,6 +402,8 @@ struct GetcostConvArgs {
     const float* reg_vol; long rds, rps; int Dreg;
     const float* dmin; const float* dmax; long range_ps;
     int hw; const float* weight; const float* bias; int cout; int relu; float* out;
+    // split-resident outputs (effi_encoder_inputs_bf16x3_sr; nullptr: the fp32 maps above): see effi_sr_store4, common.hpp
+    unsigned short* out_sr; unsigned short* out7_sr; int w, sr_hp, sr_wp;
 };
 
 template <int NQ>
@@ -446,7 +448,14 @@ __device__ __forceinline__ void getcost_conv1x1_block(const GetcostConvArgs& g, 
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = fmaf(cost[k], weight[k * cout + c0 + j], acc[j]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) out[(long)(c0 + j) * hw + p] = relu ? fmaxf(acc[j], 0.0f) : acc[j];
+        for (int j = 0; j < 8; ++j) acc[j] = relu ? fmaxf(acc[j], 0.0f) : acc[j];
+        if (g.out_sr) {                        // split-resident output (uniform branch): the octet c0 / 8 of this pixel, 16 bytes per part
+            const int y = p / g.w;
+            effi_sr_store8(g.out_sr, g.sr_hp, g.sr_wp, c0, y, p - y * g.w, acc);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) out[(long)(c0 + j) * hw + p] = acc[j];
+        }
     }
 }
 
@@ -465,7 +474,7 @@ __global__ __launch_bounds__(TPB) void encoder_inputs_kernel(const GetcostConvAr
     const int b = blockIdx.x;
     if (b < n7) {
         if (X3) {
-            effi_c1k7_relu_tile_x3<COUT>(g.inv_depth, w7, b7, h, w, out7, b % gx, b / gx);
+            effi_c1k7_relu_tile_x3<COUT>(g.inv_depth, w7, b7, h, w, out7, b % gx, b / gx, g.out7_sr, g.sr_hp, g.sr_wp);
             return;
         }
         const int bz = b / (gx * gy), r = b - bz * gx * gy;
@@ -731,9 +740,13 @@ static int encoder_inputs_launch(bool x3, const float* inv_depth, const float* d
                                  const float* cur_vol, long cds, long cps, int Dcur, const float* reg_vol, long rds,
                                  long rps, int Dreg, const float* dmin, const float* dmax, long range_ps, int nq, int h,
                                  int w, const float* weight_c1, const float* bias_c1, const float* weight_d1,
-                                 const float* bias_d1, int cout, float* out_c1, float* out_d1, effi_stream_t stream) {
+                                 const float* bias_d1, int cout, float* out_c1, float* out_d1, effi_stream_t stream,
+                                 void* sr_c1 = nullptr, void* sr_d1 = nullptr, int hp = 0, int wp = 0) {
+    const bool sr = sr_c1 != nullptr;
     if (!inv_depth || !interval || !cur_vol || !reg_vol || !dmin || !dmax || !weight_c1 || !bias_c1 || !weight_d1 || !bias_d1 ||
-        !out_c1 || !out_d1 || !disp_range || n_range < 2)
+        (!sr && (!out_c1 || !out_d1)) || !disp_range || n_range < 2)
+        return EFFI_ERR_BADARG;
+    if (sr && (!sr_d1 || !x3 || hp < h + 2 || wp < w + 2 || ((reinterpret_cast<uintptr_t>(sr_c1) | reinterpret_cast<uintptr_t>(sr_d1)) & 15)))
         return EFFI_ERR_BADARG;
     if (Dcur < 2 || Dreg < 2 || h < 1 || w < 1) return EFFI_ERR_BADARG;
     if (nq != 3 || (cout != 16 && cout != 32 && cout != 48)) return EFFI_ERR_UNSUPPORTED;
@@ -741,7 +754,8 @@ static int encoder_inputs_launch(bool x3, const float* inv_depth, const float* d
     const dim3 grid(n7 + effi_cdiv((long)h * w, TPB));
     hipStream_t st = effi_s(stream);
     const GetcostConvArgs g{inv_depth, disp_range, n_range, 0, interval, cur_vol, cds, cps, Dcur, reg_vol, rds, rps,
-                            Dreg, dmin, dmax, range_ps, h * w, weight_c1, bias_c1, cout, 1, out_c1};
+                            Dreg, dmin, dmax, range_ps, h * w, weight_c1, bias_c1, cout, 1, out_c1,
+                            reinterpret_cast<unsigned short*>(sr_c1), reinterpret_cast<unsigned short*>(sr_d1), w, hp, wp};
 #define EFFI_EI(CO)                                                                                                                     \
     do {                                                                                                                                \
         if (x3) hipLaunchKernelGGL((encoder_inputs_kernel<3, CO, true>), grid, dim3(TPB), 0, st, g, weight_d1, bias_d1, h, w, out_d1, gx, gy, n7);  \
@@ -773,6 +787,175 @@ extern "C" int effi_encoder_inputs_bf16x3_f32(const float* inv_depth, const floa
                                               const float* bias_d1, int cout, float* out_c1, float* out_d1, effi_stream_t stream) {
     return encoder_inputs_launch(true, inv_depth, disp_range, n_range, interval, cur_vol, cds, cps, Dcur, reg_vol, rds, rps, Dreg, dmin,
                                  dmax, range_ps, nq, h, w, weight_c1, bias_c1, weight_d1, bias_d1, cout, out_c1, out_d1, stream);
+}
+
+// The same launch writing SPLIT-RESIDENT maps (csrc/common.hpp: effi_sr_store4) for the split-precision 3x3 convolutions that follow
+// (convc2 / convd2, models/update.py:87,91): sr_c1 / sr_d1 are bf16 [cout/8][hi|lo][hp][wp][8] with a zero border.
+extern "C" int effi_encoder_inputs_bf16x3_sr(const float* inv_depth, const float* disp_range, int n_range, const float* interval,
+                                             const float* cur_vol, long cds, long cps, int Dcur, const float* reg_vol, long rds,
+                                             long rps, int Dreg, const float* dmin, const float* dmax, long range_ps, int nq, int h,
+                                             int w, const float* weight_c1, const float* bias_c1, const float* weight_d1,
+                                             const float* bias_d1, int cout, void* sr_c1, void* sr_d1, int hp, int wp,
+                                             effi_stream_t stream) {
+    if (!sr_c1 || !sr_d1) return EFFI_ERR_BADARG;
+    return encoder_inputs_launch(true, inv_depth, disp_range, n_range, interval, cur_vol, cds, cps, Dcur, reg_vol, rds, rps, Dreg, dmin,
+                                 dmax, range_ps, nq, h, w, weight_c1, bias_c1, weight_d1, bias_d1, cout, nullptr, nullptr, stream,
+                                 sr_c1, sr_d1, hp, wp);
+}
+
+// ---- split-resident maps: geometry, border, conversion from an fp32 map (block boundary of the update block) -------------------
+namespace {
+struct SrMaps {                       // up to 4 groups of planes with one geometry each (the stages of the cascade)
+    unsigned short* base[4];
+    int planes[4], h[4], w[4], hp[4], wp[4];
+    int first[5];                     // first block of each group
+};
+// zero what a producer never writes: row 0, rows h+1.., column 0, columns w+1.. of every plane (16-byte units)
+__global__ __launch_bounds__(TPB) void sr_clear_border_kernel(SrMaps a) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) k += ((int)blockIdx.x >= a.first[j]) ? 1 : 0;
+    unsigned short* base = a.base[0];
+    int planes = a.planes[0], h = a.h[0], w = a.w[0], hp = a.hp[0], wp = a.wp[0], b0 = a.first[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+        if (k == j) { base = a.base[j]; planes = a.planes[j]; h = a.h[j]; w = a.w[j]; hp = a.hp[j]; wp = a.wp[j]; b0 = a.first[j]; }
+    // border units of one plane: (hp - h) full rows + h rows of (wp - w) units
+    const int rowpart = (hp - h) * wp, per_plane = rowpart + h * (wp - w);
+    const long i = (long)(blockIdx.x - b0) * TPB + threadIdx.x;
+    if (i >= (long)planes * per_plane) return;
+    const int pl = (int)(i / per_plane), r = (int)(i - (long)pl * per_plane);
+    int y, x;
+    if (r < rowpart) {
+        const int ry = r / wp;
+        x = r - ry * wp;
+        y = ry == 0 ? 0 : h + ry;                                  // row 0, then rows h+1 .. hp-1
+    } else {
+        const int q = r - rowpart, ry = q / (wp - w), cx = q - ry * (wp - w);
+        y = 1 + ry;
+        x = cx == 0 ? 0 : w + cx;                                  // column 0, then columns w+1 .. wp-1
+    }
+    *reinterpret_cast<float4*>(base + (((long)pl * hp + y) * wp + x) * 8) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// fp32 planar [C][h][w] -> split-resident map: a thread owns (octet, pixel)
+__global__ __launch_bounds__(TPB) void sr_from_planar_kernel(const float* __restrict__ in, int C, int h, int w, unsigned short* __restrict__ sr,
+                                                             int hp, int wp) {
+    const long hw = (long)h * w, i = (long)blockIdx.x * TPB + threadIdx.x;
+    if (i >= (long)(C >> 3) * hw) return;
+    const int o = (int)(i / hw);
+    const long p = i - (long)o * hw;
+    const int y = (int)(p / w), x = (int)(p - (long)y * w);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = in[(long)(8 * o + e) * hw + p];
+    effi_sr_store8(sr, hp, wp, 8 * o, y, x, v);
+}
+
+// the hidden halves of up to 4 context maps as fp32 AND split-resident maps, the input halves as fp32 (split_tanh_relu_stages + SR)
+struct SplitStagesSr {
+    const float* ctx[4];
+    float* hidden[4];
+    float* inp[4];
+    unsigned short* hidden_sr[4];
+    int hd[4], cd[4], h[4], w[4], hp[4], wp[4];
+    int first[5];
+};
+__global__ __launch_bounds__(TPB) void split_tanh_relu_stages_sr_kernel(SplitStagesSr a) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) k += ((int)blockIdx.x >= a.first[j]) ? 1 : 0;
+    const float* __restrict__ ctx = a.ctx[0];
+    float* __restrict__ hidden = a.hidden[0];
+    float* __restrict__ inp = a.inp[0];
+    unsigned short* __restrict__ hsr = a.hidden_sr[0];
+    int hd = a.hd[0], cd = a.cd[0], h = a.h[0], w = a.w[0], hp = a.hp[0], wp = a.wp[0], b0 = a.first[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+        if (k == j) {
+            ctx = a.ctx[j]; hidden = a.hidden[j]; inp = a.inp[j]; hsr = a.hidden_sr[j];
+            hd = a.hd[j]; cd = a.cd[j]; h = a.h[j]; w = a.w[j]; hp = a.hp[j]; wp = a.wp[j]; b0 = a.first[j];
+        }
+    // work items: (octet of hidden channels, pixel) for the hidden half [hd % 8 == 0], then (channel quad, pixel) for the input half [cd % 4 == 0]
+    const long hw = (long)h * w, n_h = (long)(hd >> 3) * hw, n_i = (long)(cd >> 2) * hw;
+    const long i = (long)(blockIdx.x - b0) * TPB + threadIdx.x;
+    if (i < n_h) {
+        const int o = (int)(i / hw);
+        const long p = i - (long)o * hw;
+        const int y = (int)(p / w), x = (int)(p - (long)y * w);
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] = tanhf(ctx[(long)(8 * o + e) * hw + p]);
+            hidden[(long)(8 * o + e) * hw + p] = v[e];
+        }
+        effi_sr_store8(hsr, hp, wp, 8 * o, y, x, v);
+    } else if (i < n_h + n_i) {
+        const long q = i - n_h;
+        const int c4 = (int)(q / hw);
+        const long p = q - (long)c4 * hw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) inp[(long)(4 * c4 + e) * hw + p] = fmaxf(ctx[(long)(hd + 4 * c4 + e) * hw + p], 0.0f);
+    }
+}
+}  // namespace
+
+extern "C" int effi_sr_geometry(int h, int w, int* hp, int* wp) {
+    if (h < 1 || w < 1 || !hp || !wp) return EFFI_ERR_BADARG;
+    *hp = ((h + 15) & ~15) + 2;            // one zero row above, rows down to the bottom of the last 16-row tile + 1 below
+    *wp = ((w + 63) & ~63) + 2;            // one zero column left, columns up to the right edge of the last 64-column tile + 1
+    return EFFI_OK;
+}
+
+extern "C" int effi_sr_clear_border(void* const* maps, const int* planes, const int* h, const int* w, const int* hp, const int* wp,
+                                    int n_groups, effi_stream_t stream) {
+    if (!maps || !planes || !h || !w || !hp || !wp || n_groups < 1 || n_groups > 4) return EFFI_ERR_BADARG;
+    SrMaps a;
+    int blocks = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int j = k < n_groups ? k : 0;
+        if (!maps[j] || planes[j] < 1 || h[j] < 1 || w[j] < 1 || hp[j] < h[j] + 2 || wp[j] < w[j] + 2 || (reinterpret_cast<uintptr_t>(maps[j]) & 15))
+            return EFFI_ERR_BADARG;
+        a.base[k] = reinterpret_cast<unsigned short*>(maps[j]);
+        a.planes[k] = planes[j]; a.h[k] = h[j]; a.w[k] = w[j]; a.hp[k] = hp[j]; a.wp[k] = wp[j];
+        a.first[k] = blocks;
+        if (k < n_groups) blocks += effi_cdiv((long)planes[j] * ((long)(hp[j] - h[j]) * wp[j] + (long)h[j] * (wp[j] - w[j])), TPB);
+    }
+    a.first[4] = blocks;
+    hipLaunchKernelGGL(sr_clear_border_kernel, dim3(blocks), dim3(TPB), 0, effi_s(stream), a);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_sr_from_planar_f32(const float* in, int channels, int h, int w, void* sr, int hp, int wp, effi_stream_t stream) {
+    if (!in || !sr || channels < 8 || (channels & 7) || h < 1 || w < 1 || hp < h + 2 || wp < w + 2 || (reinterpret_cast<uintptr_t>(sr) & 15))
+        return EFFI_ERR_BADARG;
+    hipLaunchKernelGGL(sr_from_planar_kernel, dim3(effi_cdiv((long)(channels >> 3) * h * w, TPB)), dim3(TPB), 0, effi_s(stream), in,
+                       channels, h, w, reinterpret_cast<unsigned short*>(sr), hp, wp);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_split_tanh_relu_stages_sr_f32(const float* const* ctx, const int* hd, const int* cd, const int* h, const int* w,
+                                                  float* const* hidden, void* const* hidden_sr, const int* hp, const int* wp,
+                                                  float* const* inp, int n_stages, effi_stream_t stream) {
+    if (!ctx || !hd || !cd || !h || !w || !hidden || !hidden_sr || !hp || !wp || !inp || n_stages < 1 || n_stages > 4) return EFFI_ERR_BADARG;
+    SplitStagesSr a;
+    int blocks = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int j = k < n_stages ? k : 0;
+        if (!ctx[j] || !hidden[j] || !hidden_sr[j] || !inp[j] || hd[j] < 8 || cd[j] < 4 || h[j] < 1 || w[j] < 1) return EFFI_ERR_BADARG;
+        if ((hd[j] & 7) || (cd[j] & 3)) return EFFI_ERR_UNSUPPORTED;
+        if (hp[j] < h[j] + 2 || wp[j] < w[j] + 2 || (reinterpret_cast<uintptr_t>(hidden_sr[j]) & 15)) return EFFI_ERR_BADARG;
+        a.ctx[k] = ctx[j]; a.hidden[k] = hidden[j]; a.inp[k] = inp[j]; a.hidden_sr[k] = reinterpret_cast<unsigned short*>(hidden_sr[j]);
+        a.hd[k] = hd[j]; a.cd[k] = cd[j]; a.h[k] = h[j]; a.w[k] = w[j]; a.hp[k] = hp[j]; a.wp[k] = wp[j];
+        a.first[k] = blocks;
+        if (k < n_stages) blocks += effi_cdiv((long)h[j] * w[j] * ((hd[j] >> 3) + (cd[j] >> 2)), TPB);
+    }
+    a.first[4] = blocks;
+    hipLaunchKernelGGL(split_tanh_relu_stages_sr_kernel, dim3(blocks), dim3(TPB), 0, effi_s(stream), a);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
 }
 
 namespace {

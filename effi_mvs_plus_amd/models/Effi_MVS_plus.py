@@ -219,8 +219,16 @@ class GetCost(nn.Module):
             return ops.encoder_inputs(inv_depth, disp_range[b], interval, cur[b * n:(b + 1) * n], reg[b * n:(b + 1) * n],
                                       lo, hi, CostNum, h, w, wc1, bc1, wd1, bd1, cout, out_c1, out_d1)
 
+        def lookup_encoder_inputs_sr(inv_depth, wc1, bc1, wd1, bd1, cout, out_c1, out_d1):
+            """lookup_encoder_inputs writing split-resident maps (ops.SRMap)."""
+            h, w = inv_depth.shape[-2:]
+            n = h * w
+            return ops.encoder_inputs_sr(inv_depth, disp_range[b], interval, cur[b * n:(b + 1) * n], reg[b * n:(b + 1) * n],
+                                         lo, hi, CostNum, h, w, wc1, bc1, wd1, bd1, cout, out_c1, out_d1)
+
         lookup.conv1x1 = lookup_conv1x1 if CostNum in (2, 3, 4) else None
         lookup.encoder_inputs = lookup_encoder_inputs if CostNum == 3 else None
+        lookup.encoder_inputs_sr = lookup_encoder_inputs_sr if CostNum == 3 else None
         return lookup
 
     @ops.on_tensor_device
@@ -331,8 +339,23 @@ class Effi_MVS_plus(nn.Module):
             maps = [f[keys[s]] for f in feats]
             return ops.to_nhwc(maps), rts[s], maps[0].shape
 
+        # split-resident maps of the three update blocks (ops.SRMap): one allocation per stage, all borders zeroed by ONE launch, the
+        # initial hidden states written in both forms by the launch that splits the context maps
+        sr_maps = None
+        use_sr = (ops.uses_sr() and self.num_stage <= 4 and self.CostNum == 3
+                  and all(hd in (16, 32, 48) for hd in self.hdim_stage[:self.num_stage])
+                  and all(ctx[k].shape[-1] % 4 == 0 for k in keys))
+
         def all_states():
+            nonlocal sr_maps
             cs = [ctx[k].contiguous() for k in keys]
+            if use_sr:
+                nm = BasicUpdateBlock.N_SR_MAPS
+                sr_maps = [ops.sr_alloc(nm, self.hdim_stage[s], cs[s].shape[1], cs[s].shape[2], cs[s].device, clear=False)
+                           for s in range(self.num_stage)]
+                ops.sr_clear_border(sr_maps)
+                return dict(enumerate(ops.split_tanh_relu_stages_sr(cs, self.hdim_stage[:self.num_stage], self.cdim_stage[:self.num_stage],
+                                                                    [m[-1] for m in sr_maps])))
             if self.num_stage <= 4:
                 return dict(enumerate(ops.split_tanh_relu_stages(cs, self.hdim_stage[:self.num_stage], self.cdim_stage[:self.num_stage])))
             return {s: ops.split_tanh_relu(cs[s], self.hdim_stage[s], self.cdim_stage[s]) for s in range(self.num_stage)}
@@ -403,10 +426,18 @@ class Effi_MVS_plus(nn.Module):
                 return ops.encoder_inputs(inv_depth, disp_range, itv, cur_c, reg_c, lo_c, hi_c, self.CostNum, h, w,
                                           wc1, bc1, wd1, bd1, cout, out_c1, out_d1)
 
+            def lookup_encoder_inputs_sr(inv_depth, wc1, bc1, wd1, bd1, cout, out_c1, out_d1, cur_c=cur_c, reg_c=reg_c,
+                                         lo_c=lo_c, hi_c=hi_c, itv=itv, h=h, w=w):
+                return ops.encoder_inputs_sr(inv_depth, disp_range, itv, cur_c, reg_c, lo_c, hi_c, self.CostNum, h, w,
+                                             wc1, bc1, wd1, bd1, cout, out_c1, out_d1)
+
             lookup.conv1x1 = lookup_conv1x1 if self.CostNum in (2, 3, 4) else None
             lookup.encoder_inputs = lookup_encoder_inputs if self.CostNum == 3 else None
+            lookup.encoder_inputs_sr = lookup_encoder_inputs_sr if self.CostNum == 3 else None
             _, masks, invs, depths = self.update_block[s].run_fused(hidden, lookup, inv_cur, inp, self.seq_len[s],
-                                                                     disp_range, fuse_upsample=not want_intermediates)
+                                                                     disp_range, fuse_upsample=not want_intermediates,
+                                                                     sr_maps=None if sr_maps is None else sr_maps[s],
+                                                                     net_sr_ready=sr_maps is not None, net_owned=True)
             preds.extend(d[0] for d in depths)
             if isinstance(masks[-1], tuple):      # mask head + upsampling ran as one kernel
                 up_depth, inv_next = masks[-1]

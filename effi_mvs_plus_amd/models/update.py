@@ -265,12 +265,95 @@ class BasicUpdateBlock(nn.Module):
                                lambda: packing.pack_mask_taps_per_lane(self.mask[2].weight, self.mask[2].bias, c1, scale=0.25))
         return ops.conv2d_k3_k1_up2x([net], w.wx, b, c1, w2, b2, inv_depth, disp_range)
 
+    # -- fused path on split-resident maps (ops.SRMap): every 3x3 convolution of an iteration reads ready-made (hi, lo) bf16 octets
+    # and writes its result the same way; bitwise the results of ``run_fused``'s fp32-map chain --------------------------------
+    N_SR_MAPS = 5          # A: cor1 -> x, B: dfm1 -> r*h, C: cor2, D: dfm2, H: hidden state
+
+    def sr_fusable(self, net, lookup):
+        hd = net.shape[0]
+        e = self.encoder
+        cmix, cd = e.convd.out_channels, e.convc.in_channels - e.convd.out_channels
+        c1m = self.mask[0].out_channels
+        return (ops.uses_sr(net.shape[-1] * net.shape[-2]) and hd in (16, 32, 48) and net.shape[-1] % 4 == 0 and getattr(lookup, "encoder_inputs_sr", None) is not None
+                and e.convd1.in_channels == 1 and cmix <= 48 and 0 <= cd <= 16 and e.convc.out_channels == hd
+                and self.depth_head.conv1.out_channels == hd and self.depth_head.conv1.in_channels == hd
+                and self.depth_head.conv2.out_channels == 1 and (not self.UpMask or (c1m in (32, 64, 96) and self.mask[2].out_channels == 36)))
+
+    def run_fused_sr(self, net, lookup, inv_depth, context, seq_len, disp_range, fuse_upsample=False, maps=None, net_sr_ready=False,
+                     net_owned=False):
+        """``run_fused`` with the iteration's maps split-resident.  ``maps``: the N_SR_MAPS SRMaps [A, B, C, D, H] of this block
+        (borders already zero; allocated here otherwise); ``net_sr_ready``: H already holds ``net`` (written by
+        ``ops.split_tanh_relu_stages_sr``), otherwise it is converted here; ``net_owned``: ``net`` is a temporary of the caller
+        that may be overwritten (the fp32 copy of the state is then updated in place from the first iteration on).
+
+        Working set of an iteration at 592x800 (hd 16): five SR maps of 31.7 MB, the fp32 state and ONE more fp32 block that is z
+        between the z / r convolution and the update and the depth head's nine tap planes after it -- 220 MB, inside the 256-MB
+        MALL; with separate z / head / ping-pong state buffers (280 MB) stage 3 ran 7 % SLOWER than on fp32 maps."""
+        hd = net.shape[0]
+        h, w = net.shape[-2:]
+        dev = net.device
+        if maps is None:
+            maps = ops.sr_alloc(self.N_SR_MAPS, hd, h, w, dev)
+        A, B, Cm, Dm, Hm = maps
+        if not net_sr_ready:
+            ops.sr_from_planar(net, out=Hm)
+        zh_buf = torch.empty(max(hd, 9), h, w, device=dev, dtype=torch.float32)       # z, then (z is dead) the head's 9 tap planes
+        z_buf, head_buf = zh_buf[:hd], zh_buf[:9]
+        h_own = net if net_owned else None       # fp32 state we may write: each lane reads h[p] and writes h'[p] of its own pixel
+        e = self.encoder
+        wc1, bc1 = e.convc1_raw()
+        w7, b7 = e.conv7_packed()
+        wd2, bd2 = _pack(e._caches["d2"], e.convd2)
+        wc2, bc2 = _pack(e._caches["c2"], e.convc2)
+        wd, bd = _pack(e._caches["d"], e.convd)
+        cmix, cd = e.convd.out_channels, context.shape[0]
+        wca, bca = e._caches["c_after"].get([e.convc.weight, e.convc.bias],
+                                            lambda: packing.pack_conv1x1_after(e.convc.weight, e.convc.bias, cmix, cd))
+        wzr, bzr = self.depth_gru._packed_zr()
+        wq, bq = _pack(self.depth_gru._cq, self.depth_gru.convq)
+        dh = self.depth_head
+        wh1, bh1 = _pack(dh._c1, dh.conv1)
+        wh2, bh2 = dh._c2t.get([dh.conv2.weight], lambda: packing.pack_head_taps(dh.conv2.weight, hd))
+        inv_list, mask_list, depth_list = [], [], []
+        for i in range(seq_len):
+            lookup.encoder_inputs_sr(inv_depth, wc1, bc1, w7, b7, hd, A, B)                        # cor1 -> A, dfm1 -> B
+            ops.conv2d_k3_pair_sr([A], wc2.wx, bc2, Cm, [B], wd2.wx, bd2, Dm, hd, act=ops.ACT_RELU)  # cor -> C, dfm -> D
+            ops.conv2d_k3_k1_sr([Cm, Dm], wd.wx, bd, cmix, context, wca, bca, hd, relu=True, out_sr=A)   # x -> A (cor1 is dead)
+            z, _ = ops.conv2d_k3_sr([Hm, A], wzr.wx, bzr, 2 * hd, epilogue=ops.EPI_GRU_ZR, aux0=net, out0=z_buf, out_sr=B)   # r*h -> B
+            # the new state overwrites H in place (no launch reads H between the z / r convolution and here), and so does its fp32
+            # copy once it lives in a buffer of ours
+            if h_own is None:
+                h_own = torch.empty(hd, h, w, device=dev, dtype=torch.float32)
+            net, _ = ops.conv2d_k3_sr([B, A], wq.wx, bq, hd, epilogue=ops.EPI_GRU_Q, aux0=net, aux1=z, out0=h_own, out_sr=Hm)
+            want_mask = self.UpMask and i == seq_len - 1
+            fused_up = want_mask and fuse_upsample
+            if want_mask and not fused_up:
+                with ops.Branch() as br:
+                    mask = self.run_mask(net)
+            part = ops.conv2d_k3_k1_sr([Hm], wh1.wx, bh1, hd, None, wh2, bh2, 9, relu=False, relu1=True, out=head_buf)
+            inv_depth, depth = ops.head_update(part, dh.conv2.bias, inv_depth, disp_range)
+            if fused_up:                       # needs the NEW inverse depth: after the head
+                wm, bm = _pack(self._m0, self.mask[0])
+                c1 = self.mask[0].out_channels
+                w2, b2 = self._m2u.get([self.mask[2].weight, self.mask[2].bias],
+                                       lambda: packing.pack_mask_taps_per_lane(self.mask[2].weight, self.mask[2].bias, c1, scale=0.25))
+                mask = ops.conv2d_k3_k1_up2x_sr([Hm], wm.wx, bm, c1, w2, b2, inv_depth, disp_range)
+            elif want_mask:
+                br.join(mask)
+            inv_list.append(inv_depth)
+            depth_list.append(depth)
+            mask_list.append(mask if want_mask else inv_depth)
+        return net, mask_list, inv_list, depth_list
+
     # -- fused path: the cost lookup is our GetCost and scale_inv_depth is the global-range rescale ------
-    def run_fused(self, net, lookup, inv_depth, context, seq_len, disp_range, fuse_upsample=False):
+    def run_fused(self, net, lookup, inv_depth, context, seq_len, disp_range, fuse_upsample=False, sr_maps=None, net_sr_ready=False,
+                  net_owned=False):
         """Unbatched tensors; ``lookup(inv_depth, out)`` fills the [2*nq,h,w] cost for a normalised
         inverse-depth map.  Returns (net, mask_list, inv_list, depth_list).  ``fuse_upsample``: the last iteration's mask
         head and the convex upsampling it feeds run as one kernel; mask_list[-1] is then the pair (upsampled depth,
         depth_to_inv of it) instead of the mask."""
+        if self.sr_fusable(net, lookup):
+            return self.run_fused_sr(net, lookup, inv_depth, context, seq_len, disp_range, fuse_upsample, sr_maps, net_sr_ready, net_owned)
         hd = net.shape[0]
         h, w = net.shape[-2:]
         dev = net.device

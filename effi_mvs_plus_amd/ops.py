@@ -926,6 +926,233 @@ def conv2d_k3_bf16x3(srcs, wpack, bias, cout, epilogue=EPI_PLAIN, act=ACT_NONE, 
     return (out0, out1) if out1 is not None else out0
 
 
+# =============================================================================================
+# split-resident ("SR") maps of the update block: include/effi_mvs_hip.h, section "Split-resident activation maps"
+# =============================================================================================
+_SR = os.environ.get("EFFI_MVS_SR", "1") != "0"
+
+
+def set_sr(enabled):
+    """Route the update block's split-precision convolutions through split-resident maps (default) or through fp32 maps (the
+    round-2 form; bitwise the same results)."""
+    global _SR
+    _SR = bool(enabled)
+
+
+def uses_sr(pixels=None):
+    """SR maps on?  ``pixels``: size of the map in question -- EFFI_MVS_SR_MAX_PX (A/B runs) keeps larger maps on the fp32 form."""
+    if not (_SR and uses_split()):
+        return False
+    return pixels is None or pixels <= _SR_MAX_PX
+
+
+_SR_MAX_PX = int(os.environ.get("EFFI_MVS_SR_MAX_PX", str(1 << 40)))
+
+
+def sr_geometry(h, w):
+    """(hp, wp) of an SR plane for an h x w map: effi_sr_geometry."""
+    return ((h + 15) // 16) * 16 + 2, ((w + 63) // 64) * 64 + 2
+
+
+class SRMap:
+    """One split-resident map: ``t`` is a bf16 tensor [channels/8, 2 (hi, lo), hp, wp, 8]; pixel (y, x) sits at [.., y+1, x+1, :]."""
+    __slots__ = ("t", "channels", "h", "w", "hp", "wp")
+
+    def __init__(self, t, channels, h, w):
+        self.t, self.channels, self.h, self.w = t, channels, h, w
+        self.hp, self.wp = t.shape[2], t.shape[3]
+
+    def parts(self):
+        """(hi, lo) as fp32 [channels, h, w] tensors (tests / debugging; plain torch)."""
+        v = self.t[:, :, 1:self.h + 1, 1:self.w + 1, :].float()          # [o, 2, h, w, 8]
+        v = v.permute(1, 0, 4, 2, 3).reshape(2, self.channels, self.h, self.w)
+        return v[0], v[1]
+
+
+def sr_alloc(n_maps, channels, h, w, device, clear=True):
+    """``n_maps`` SR maps of one geometry in one allocation -> list of SRMap.  The border is zeroed here (one small launch) unless
+    ``clear`` is False (the caller clears several blocks at once with ``sr_clear_border``)."""
+    if channels % 8:
+        raise ValueError("SR maps hold whole octets of channels")
+    hp, wp = sr_geometry(h, w)
+    block = torch.empty(n_maps, channels // 8, 2, hp, wp, 8, device=device, dtype=torch.bfloat16)
+    maps = [SRMap(block[i], channels, h, w) for i in range(n_maps)]
+    if clear:
+        sr_clear_border([maps])
+    return maps
+
+
+def _sr(m, name):
+    if not isinstance(m, SRMap):
+        raise TypeError(f"{name}: expected an SRMap")
+    t_ = m.t
+    if not t_.is_cuda:
+        raise EffiLibraryError(f"{name}: CPU tensor passed to the HIP path (no CPU fallback exists)")
+    if t_.device.index != torch._C._cuda_getDevice():
+        raise EffiLibraryError(f"{name}: map lives on cuda:{t_.device.index} but the current device is cuda:{torch._C._cuda_getDevice()}")
+    if t_.dtype != torch.bfloat16 or not t_.is_contiguous():
+        raise ValueError(f"{name}: SR maps are contiguous bf16 tensors")
+    return m
+
+
+def sr_clear_border(groups):
+    """Zero the borders of up to 4 groups of SR maps (each group: consecutive maps of ONE allocation and geometry) in one launch."""
+    if not 1 <= len(groups) <= 4:
+        raise ValueError("sr_clear_border: 1..4 groups")
+    firsts = [_sr(g[0], "SR map") for g in groups]
+    planes = [2 * (g[0].channels // 8) * len(g) for g in groups]
+    for g in groups:       # consecutive maps of one allocation
+        step = g[0].t.numel() * 2
+        if any(m.t.data_ptr() != g[0].t.data_ptr() + i * step for i, m in enumerate(g)):
+            raise ValueError("sr_clear_border: a group must be consecutive maps of one sr_alloc block")
+    check(_lib.lib().effi_sr_clear_border(_ptr_array([m.t for m in firsts]), _int_array(planes), _int_array([m.h for m in firsts]),
+                                           _int_array([m.w for m in firsts]), _int_array([m.hp for m in firsts]),
+                                           _int_array([m.wp for m in firsts]), len(groups), _stream()), "effi_sr_clear_border")
+
+
+def sr_from_planar(x, out=None):
+    """fp32 [C,h,w] -> SRMap (a block boundary of the update block: e.g. a caller-supplied hidden state)."""
+    _t(x, "map")
+    Cc, h, w = x.shape
+    if out is None:
+        out = sr_alloc(1, Cc, h, w, x.device)[0]
+    check(_lib.lib().effi_sr_from_planar_f32(_p(x), Cc, h, w, _p(_sr(out, "SR map").t), out.hp, out.wp, _stream()), "effi_sr_from_planar_f32")
+    return out
+
+
+def split_tanh_relu_stages_sr(ctxs, hds, cds, hidden_srs):
+    """``split_tanh_relu_stages`` that also writes each hidden state into the given SRMap -> [(hidden, inp), ...] (fp32)."""
+    outs = []
+    for c_, hd, cd, m in zip(ctxs, hds, cds, hidden_srs):
+        _t(c_, "context"), _sr(m, "hidden SR map")
+        _, h, w = c_.shape
+        if (m.channels, m.h, m.w) != (hd, h, w):
+            raise ValueError("split_tanh_relu_stages_sr: SR map does not match the hidden state")
+        outs.append((torch.empty(hd, h, w, device=c_.device, dtype=torch.float32),
+                     torch.empty(cd, h, w, device=c_.device, dtype=torch.float32)))
+    if len(ctxs) > 4:
+        raise ValueError("split_tanh_relu_stages_sr: up to 4 stages")
+    check(_lib.lib().effi_split_tanh_relu_stages_sr_f32(
+        _ptr_array(ctxs), _int_array(list(hds)), _int_array(list(cds)), _int_array([c_.shape[1] for c_ in ctxs]),
+        _int_array([c_.shape[2] for c_ in ctxs]), _ptr_array([o[0] for o in outs]), _ptr_array([m.t for m in hidden_srs]),
+        _int_array([m.hp for m in hidden_srs]), _int_array([m.wp for m in hidden_srs]), _ptr_array([o[1] for o in outs]), len(ctxs),
+        _stream()), "effi_split_tanh_relu_stages_sr_f32")
+    return outs
+
+
+def encoder_inputs_sr(x, disp_range, interval, cur_vol, reg_vol, dmin, dmax, nq, h, w, weight_c1, bias_c1, weight_d1, bias_d1, cout,
+                      out_c1, out_d1):
+    """``encoder_inputs`` (split precision) writing relu(convc1(cost)) and relu(convd1(x)) as SR maps."""
+    _t(x, "inv_depth"), _t(interval, "interval"), _t(disp_range, "disp_range")
+    for t_ in (weight_c1, bias_c1, weight_d1, bias_d1):
+        _t(t_, "encoder weights")
+    _sr(out_c1, "out_c1"), _sr(out_d1, "out_d1")
+    cur_vol, cds, cps, Dc = _vol_strides(cur_vol, h, w)
+    reg_vol, rds, rps, Dr = _vol_strides(reg_vol, h, w)
+    dmin_t, gps = _range_ptr(dmin, h, w)
+    dmax_t, gps2 = _range_ptr(dmax, h, w)
+    if gps != gps2:
+        raise ValueError("depth_min / depth_max must both be global or both per-pixel")
+    if (out_c1.channels, out_c1.h, out_c1.w) != (cout, h, w) or (out_d1.channels, out_d1.h, out_d1.w) != (cout, h, w):
+        raise ValueError("encoder_inputs_sr: output maps must be [cout,h,w]")
+    work = lambda: {"flops": 2.0 * h * w * (2 * nq + 49) * cout, "bytes": 4.0 * h * w * (2 * cout + 1 + Dc + Dr)}
+    check(_call("encoder_inputs", work, _lib.lib().effi_encoder_inputs_bf16x3_sr, _p(x), _p(disp_range), disp_range.numel(),
+                _p(interval), _p(cur_vol), cds, cps, Dc, _p(reg_vol), rds, rps, Dr, _p(dmin_t), _p(dmax_t), gps, nq, h, w,
+                _p(weight_c1), _p(bias_c1), _p(weight_d1), _p(bias_d1), cout, _p(out_c1.t), _p(out_d1.t), out_c1.hp, out_c1.wp,
+                _stream()), "effi_encoder_inputs_bf16x3_sr")
+    return out_c1, out_d1
+
+
+def _sr_srcs(srcs):
+    for m in srcs:
+        _sr(m, "conv2d input")
+        if m.channels % 16:
+            raise ValueError("SR convolution sources hold multiples of 16 channels")
+    g = srcs[0]
+    if any((m.h, m.w, m.hp, m.wp) != (g.h, g.w, g.hp, g.wp) for m in srcs):
+        raise ValueError("SR convolution sources must share one geometry")
+    return g
+
+
+def conv2d_k3_sr(srcs, wpack, bias, cout, epilogue=EPI_PLAIN, act=ACT_NONE, aux0=None, aux1=None, out0=None, out_sr=None):
+    """``conv2d_k3_bf16x3`` on SR maps.  PLAIN: -> out_sr (and out0 fp32 if given); GRU_ZR: -> (z fp32, r*h SR), aux0 = h fp32;
+    GRU_Q: -> (h' fp32, h' SR), aux0 = h, aux1 = z."""
+    g = _sr_srcs(srcs)
+    h, w = g.h, g.w
+    dev = g.t.device
+    c_out_sr = cout // 2 if epilogue == EPI_GRU_ZR else cout
+    if out_sr is None:
+        out_sr = sr_alloc(1, c_out_sr, h, w, dev)[0]
+    _sr(out_sr, "out_sr")
+    if (out_sr.channels, out_sr.h, out_sr.w) != (c_out_sr, h, w):
+        raise ValueError("conv2d_k3_sr: output map does not match")
+    if out0 is None and epilogue in (EPI_GRU_ZR, EPI_GRU_Q):
+        out0 = torch.empty(c_out_sr, h, w, device=dev, dtype=torch.float32)
+    for a_ in (aux0, aux1, out0):
+        if a_ is not None:
+            _t(a_, "fp32 map")
+    cin = sum(m.channels for m in srcs)
+    work = lambda: {"flops": 2.0 * h * w * cin * cout * 9, "bytes": 4.0 * h * w * (cin + cout)}
+    check(_call(f"conv2d_k3x3_nt{(cout + 15) // 16}_epi{epilogue}", work, _x3("effi_conv2d_k3_bf16x3_sr"), _ptr_array([m.t for m in srcs]),
+                _int_array([m.channels for m in srcs]), len(srcs), _p(wpack), _p(bias), cout, h, w, g.hp, g.wp, epilogue, act,
+                _p(aux0), _p(aux1), _p(out0), _p(out_sr.t), _stream()), "effi_conv2d_k3_bf16x3_sr")
+    return (out0, out_sr) if out0 is not None else out_sr
+
+
+def conv2d_k3_pair_sr(srcs_a, wpack_a, bias_a, out_a, srcs_b, wpack_b, bias_b, out_b, cout, act=ACT_NONE):
+    """``conv2d_k3_bf16x3_pair`` on SR maps (SR in, SR out)."""
+    g = _sr_srcs(list(srcs_a) + list(srcs_b) + [out_a, out_b])
+    h, w = g.h, g.w
+    cin = sum(m.channels for m in srcs_a) + sum(m.channels for m in srcs_b)
+    work = lambda: {"flops": 2.0 * h * w * cin * cout * 9, "bytes": 4.0 * h * w * (cin + 2 * cout)}
+    check(_call(f"conv2d_k3x3_pair_nt{(cout + 15) // 16}", work, _x3("effi_conv2d_k3_bf16x3_pair_sr"), _ptr_array([m.t for m in srcs_a]),
+                _int_array([m.channels for m in srcs_a]), len(srcs_a), _p(wpack_a), _p(bias_a), _p(out_a.t),
+                _ptr_array([m.t for m in srcs_b]), _int_array([m.channels for m in srcs_b]), len(srcs_b), _p(wpack_b), _p(bias_b),
+                _p(out_b.t), cout, h, w, g.hp, g.wp, act, _stream()), "effi_conv2d_k3_bf16x3_pair_sr")
+    return out_a, out_b
+
+
+def conv2d_k3_k1_sr(srcs, wpack, bias, cout1, extra, w2pack, bias2, cout2, relu=True, relu1=False, out=None, out_sr=None):
+    """``conv2d_k3_k1_x3`` on SR inputs -> ``out_sr`` (SRMap) if given, else fp32 [cout2,h,w]."""
+    g = _sr_srcs(srcs)
+    h, w = g.h, g.w
+    c_extra = 0
+    if extra is not None:
+        _t(extra, "extra channels")
+        c_extra = extra.shape[0]
+    if out_sr is None and out is None:
+        out = torch.empty(cout2, h, w, device=g.t.device, dtype=torch.float32)
+    if out_sr is not None:
+        _sr(out_sr, "out_sr")
+        if (out_sr.channels, out_sr.h, out_sr.w) != (cout2, h, w):
+            raise ValueError("conv2d_k3_k1_sr: output map does not match")
+    cin = sum(m.channels for m in srcs)
+    work = lambda: {"flops": 2.0 * h * w * (cin * cout1 * 9 + (cout1 + c_extra) * cout2),
+                    "bytes": 4.0 * h * w * (cin + c_extra + cout2)}
+    check(_call(f"conv2d_k3k1_nt{(cout1 + 15) // 16}", work, _x3("effi_conv2d_k3_k1_bf16x3_sr"), _ptr_array([m.t for m in srcs]),
+                _int_array([m.channels for m in srcs]), len(srcs), _p(wpack), _p(bias), cout1, int(relu1), _p(extra), c_extra,
+                _p(w2pack), _p(bias2), cout2, int(relu), h, w, g.hp, g.wp, _p(None if out_sr is not None else out),
+                _p(out_sr.t if out_sr is not None else None), _stream()), "effi_conv2d_k3_k1_bf16x3_sr")
+    return out_sr if out_sr is not None else out
+
+
+def conv2d_k3_k1_up2x_sr(srcs, wpack, bias, cout1, w2pack, bias2, inv_depth, disp_range, want_depth_inv=True):
+    """``conv2d_k3_k1_up2x`` on SR inputs."""
+    g = _sr_srcs(srcs)
+    _t(inv_depth, "inv_depth"), _t(disp_range, "disp_range")
+    h, w = g.h, g.w
+    dev = g.t.device
+    out_depth = torch.empty(2 * h, 2 * w, device=dev, dtype=torch.float32)
+    out_dinv = torch.empty(2 * h, 2 * w, device=dev, dtype=torch.float32) if want_depth_inv else None
+    cin = sum(m.channels for m in srcs)
+    work = lambda: {"flops": 2.0 * h * w * (cin * cout1 * 9 + cout1 * 36), "bytes": 4.0 * h * w * (cin + 1 + 8)}
+    check(_call(f"conv2d_k3k1up_nt{(cout1 + 15) // 16}", work, _x3("effi_conv2d_k3_k1_up2x_bf16x3_sr"), _ptr_array([m.t for m in srcs]),
+                _int_array([m.channels for m in srcs]), len(srcs), _p(wpack), _p(bias), cout1, _p(w2pack), _p(bias2), _p(inv_depth),
+                _p(disp_range), disp_range.numel(), h, w, g.hp, g.wp, _p(out_depth), _p(out_dinv), _stream()),
+          "effi_conv2d_k3_k1_up2x_bf16x3_sr")
+    return out_depth, out_dinv
+
+
 def conv2d_k3_k1_x3(srcs, wpack, bias, cout1, extra, w2pack, bias2, cout2, relu=True, out=None, relu1=False):
     """3x3 split-precision conv (ReLU if ``relu1``) + the 1x1 conv over cat(result, ``extra``) in one kernel
     (``packing.pack_conv2d_bf16x3`` / ``packing.pack_conv1x1_after``) -> [cout2,h,w]."""

@@ -572,6 +572,75 @@ int effi_conv3d_k3s1_roll_bf16x3_pair_f32_bf16(const float* const* srcs_a, const
 int effi_deconv3d_k3s2_bf16x3_f32_bf16(const float* in, int cin, const void* wpack_bf16, const float* bias, int cout,
                                   int D, int h, int w, int relu, const float* skip, float* out, effi_stream_t stream);
 
+/* ================================================================================================================
+ * Split-resident ("SR") activation maps of the GRU update block, models/update.py:33-49,69-99,109-141.
+ * In split precision every 3x3 convolution reads an fp32 value x as hi = bf16(x), lo = bf16(x - hi).  The layers of the update
+ * block feed each other, so their producers store the two halves directly, in the order the consumer's MFMA fragments want:
+ *     map[octet o of 8 channels][part: 0 = hi, 1 = lo][row y + 1][column x + 1][channel e]        (bf16)
+ * with [hp][wp] pixels per plane, a one-pixel zero border and zeros up to the tile overhang (effi_sr_geometry); the border IS the
+ * convolution's zero padding.  A chain through SR maps is bitwise equal to the same chain through fp32 maps (same conversion
+ * instructions, applied once by the producer instead of by every consumer).  Maps are caller-owned; the border is zeroed with
+ * effi_sr_clear_border once per allocation (producers never write outside rows 1..h, columns 1..w).
+ * ================================================================================================================ */
+/* plane size the kernels expect for an h x w map: hp = roundup(h, 16) + 2, wp = roundup(w, 64) + 2 */
+int effi_sr_geometry(int h, int w, int* hp, int* wp);
+/* zero the border of n_groups (<= 4) blocks of planes[g] consecutive planes of geometry (h, w, hp, wp)[g]: one launch */
+int effi_sr_clear_border(void* const* maps, const int* planes, const int* h, const int* w, const int* hp, const int* wp, int n_groups,
+                         effi_stream_t stream);
+/* fp32 planar [channels][h][w] (channels % 8 == 0) -> SR map (interior only) */
+int effi_sr_from_planar_f32(const float* in, int channels, int h, int w, void* sr, int hp, int wp, effi_stream_t stream);
+/* effi_split_tanh_relu_stages_f32 (models/Effi_MVS_plus.py:442-452) that ALSO writes each hidden state as an SR map (hd % 8 == 0,
+ * cd % 4 == 0): what the first ConvGRU convolution of a stage reads. */
+int effi_split_tanh_relu_stages_sr_f32(const float* const* ctx, const int* hd, const int* cd, const int* h, const int* w,
+                                       float* const* hidden, void* const* hidden_sr, const int* hp, const int* wp, float* const* inp,
+                                       int n_stages, effi_stream_t stream);
+/* effi_encoder_inputs_bf16x3_f32 (models/update.py:86,90) writing both maps split-resident (sr_c1 = relu(convc1(cost)),
+ * sr_d1 = relu(convd1(inv_depth)); [cout/8][2][hp][wp][8]). */
+int effi_encoder_inputs_bf16x3_sr(const float* inv_depth, const float* disp_range, int n_range, const float* interval,
+                                  const float* cur_vol, long cds, long cps, int Dcur, const float* reg_vol, long rds, long rps,
+                                  int Dreg, const float* dmin, const float* dmax, long range_ps, int nq, int h, int w,
+                                  const float* weight_c1, const float* bias_c1, const float* weight_d1, const float* bias_d1,
+                                  int cout, void* sr_c1, void* sr_d1, int hp, int wp, effi_stream_t stream);
+/* effi_conv2d_k3_bf16x3_f32 on SR maps (models/update.py:36-38,43-48,75,77): srcs = SR maps of src_channels[i] channels each
+ * (multiples of 16), cout % 16 == 0.  EFFI_EPI_PLAIN: out_sr = act(conv) (out0, if given, the same values as fp32 [cout][h][w]);
+ * EFFI_EPI_GRU_ZR: out0 = z (fp32 [cout/2][h][w]), out_sr = r * h, aux0 = h (fp32); EFFI_EPI_GRU_Q: out0 AND out_sr =
+ * (1 - z) h + z tanh(conv), aux0 = h, aux1 = z (fp32). */
+int effi_conv2d_k3_bf16x3_sr(const void* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16, const float* bias,
+                             int cout, int h, int w, int hp, int wp, int epilogue, int act, const float* aux0, const float* aux1,
+                             float* out0, void* out_sr, effi_stream_t stream);
+/* effi_conv2d_k3_bf16x3_pair_f32 on SR maps: convc2 / convd2 of the encoder (models/update.py:87,91), SR in, SR out. */
+int effi_conv2d_k3_bf16x3_pair_sr(const void* const* srcs_a, const int* src_channels_a, int n_src_a, const void* wpack_a,
+                                  const float* bias_a, void* out_sr_a, const void* const* srcs_b, const int* src_channels_b,
+                                  int n_src_b, const void* wpack_b, const float* bias_b, void* out_sr_b, int cout, int h, int w,
+                                  int hp, int wp, int act, effi_stream_t stream);
+/* effi_conv2d_k3_k1_bf16x3_f32 on SR inputs (convd -> convc, models/update.py:78-80,92-96; depth head conv1 + tap projections,
+ * :14-15,21): exactly one of out (fp32 [cout2][h][w]) and out_sr (SR, cout2 % 16 == 0) is given. */
+int effi_conv2d_k3_k1_bf16x3_sr(const void* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16, const float* bias,
+                                int cout1, int relu1, const float* extra, int c_extra, const void* w2pack_bf16, const float* bias2,
+                                int cout2, int relu, int h, int w, int hp, int wp, float* out, void* out_sr, effi_stream_t stream);
+/* effi_conv2d_k3_k1_up2x_bf16x3_f32 on SR inputs (mask head + convex upsampling, models/update.py:109-112,136-138,
+ * models/Effi_MVS_plus.py:167-178). */
+int effi_conv2d_k3_k1_up2x_bf16x3_sr(const void* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
+                                     const float* bias, int cout1, const void* w2pack_bf16, const float* bias2, const float* inv_depth,
+                                     const float* disp_range, int n_range, int h, int w, int hp, int wp, float* out_depth,
+                                     float* out_depth_inv, effi_stream_t stream);
+/* the four convolution entries above with plain bf16 operands (hi only; precision "bf16"): the lo planes are neither read nor written */
+int effi_conv2d_k3_bf16x3_sr_bf16(const void* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16, const float* bias,
+                                  int cout, int h, int w, int hp, int wp, int epilogue, int act, const float* aux0, const float* aux1,
+                                  float* out0, void* out_sr, effi_stream_t stream);
+int effi_conv2d_k3_bf16x3_pair_sr_bf16(const void* const* srcs_a, const int* src_channels_a, int n_src_a, const void* wpack_a,
+                                       const float* bias_a, void* out_sr_a, const void* const* srcs_b, const int* src_channels_b,
+                                       int n_src_b, const void* wpack_b, const float* bias_b, void* out_sr_b, int cout, int h, int w,
+                                       int hp, int wp, int act, effi_stream_t stream);
+int effi_conv2d_k3_k1_bf16x3_sr_bf16(const void* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
+                                     const float* bias, int cout1, int relu1, const float* extra, int c_extra, const void* w2pack_bf16,
+                                     const float* bias2, int cout2, int relu, int h, int w, int hp, int wp, float* out, void* out_sr,
+                                     effi_stream_t stream);
+int effi_conv2d_k3_k1_up2x_bf16x3_sr_bf16(const void* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
+                                          const float* bias, int cout1, const void* w2pack_bf16, const float* bias2,
+                                          const float* inv_depth, const float* disp_range, int n_range, int h, int w, int hp, int wp,
+                                          float* out_depth, float* out_depth_inv, effi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
