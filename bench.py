@@ -661,12 +661,8 @@ def main():
             hip_ms = timed(hip_fb, n=10)
             ref_ms = timed(torch_fb, n=3)
             gd = (hip_fb() - torch_fb()).abs().max().item() / max(torch_fb().abs().max().item(), 1e-30)
-            import os as _os
-            _os.environ["EFFI_WARP_LDS_KB"] = "-1"             # the round-1 kernels (direct gather, global atomics), same call
-            try:
+            with ops.options(warp_lds_kb=-1):                   # the round-1 kernels (direct gather, global atomics), same call
                 direct_ms = timed(hip_fb, n=5)
-            finally:
-                _os.environ.pop("EFFI_WARP_LDS_KB", None)
             result["warp_correlate_fwd_bwd"] = {"ms": hip_ms, "ms_torch_rocm_autograd": ref_ms, "speedup": ref_ms / hip_ms,
                                                 "ms_direct_kernels_global_atomics": direct_ms,
                                                 "grad_ref_max_diff_rel_to_peak": gd,

@@ -19,6 +19,7 @@ _vp, _i, _l, _f = C.c_void_p, C.c_int, C.c_long, C.c_float
 SIGNATURES = {
     "effi_version": [],
     "effi_set_workspace": [_i, _vp, _l],
+    "effi_set_option": [C.c_char_p, _l],
     "effi_fusion_dynamic_filter_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _f, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp],
     "effi_compose_rel_proj_f32": [_vp, _i, _vp, _vp],
@@ -111,7 +112,7 @@ for _n in BF16X3_ENTRIES:
     SIGNATURES[_n + "_bf16"] = SIGNATURES[_n]
 
 # entry points whose return type is not the int status code (bound explicitly in lib())
-NON_STATUS_SYMBOLS = ("effi_error_string", "effi_workspace_bytes", "effi_get_workspace")
+NON_STATUS_SYMBOLS = ("effi_error_string", "effi_workspace_bytes", "effi_get_workspace", "effi_get_option", "effi_option_unset")
 
 _lock = threading.Lock()
 _lib = None
@@ -145,6 +146,10 @@ def lib():
         handle.effi_workspace_bytes.restype = _l
         handle.effi_get_workspace.argtypes = [_i]
         handle.effi_get_workspace.restype = _vp
+        handle.effi_get_option.argtypes = [C.c_char_p]
+        handle.effi_get_option.restype = _l
+        handle.effi_option_unset.argtypes = []
+        handle.effi_option_unset.restype = _l
         _lib = handle
     return _lib
 

@@ -15,6 +15,24 @@
 // zero page of the current device (caller-registered, api.hip); nullptr when none is registered
 const float* effi_zero_page();
 
+// Tuning / A-B switches of the library (api.hip): a table of integers, initialised ONCE from the environment (variable EFFI_<NAME>)
+// and changed afterwards only through effi_set_option -- no entry point calls getenv.
+enum EffiOption {
+    EFFI_OPT_WARP_LDS_KB,        // stage-1 warp kernel: LDS window in KB (unset = 72), 0 = window kernel on global loads, -1 = direct-gather kernel
+    EFFI_OPT_DYN_FORM,           // stage-2/3 warp kernel: 1 = channel-split lanes instead of hypothesis-per-lane
+    EFFI_OPT_DYN_SETUP_EXACT,    // stage-2/3 warp kernel: 1 = IEEE divisions in the projection
+    EFFI_OPT_DYN_XCHG,           // diagnostic builds (-DEFFI_DIAG_LANE_EXCHANGE) only: 1 = DPP, 2 = ds_bpermute exchange of set-ups
+    EFFI_OPT_PIXNET_MFMA,        // view-weight net: 0 = vector-ALU kernel
+    EFFI_OPT_FORCE_MR,           // split-precision 3x3 convolutions: rows per wave (1, 2, 4) instead of the rule
+    EFFI_OPT_MR4_MIN, EFFI_OPT_MR4_NT2_MAX, EFFI_OPT_MR2_MIN,     // thresholds of that rule (workgroup counts)
+    EFFI_OPT_WIDE_TILES,         // 0 / 1: 4 x 64 tiles never / always
+    EFFI_OPT_ROLL_MR, EFFI_OPT_ROLL_ZT, EFFI_OPT_ROLL_RP,         // rolling 3-D convolution: rows per wave, planes per workgroup, row-pair operand
+    EFFI_OPT_DECONV_MR,          // transposed 3-D convolution: rows per wave
+    EFFI_OPT_COUNT
+};
+constexpr long EFFI_OPT_UNSET = -0x7fffffffL;
+long effi_option(int id);        // current value, EFFI_OPT_UNSET when neither the environment nor effi_set_option gave one
+
 static inline hipStream_t effi_s(effi_stream_t s) {
     (void)hipGetLastError();            // drop a stale pending error (see EFFI_LAUNCH_CHECK); sticky errors come back on the next check
     return reinterpret_cast<hipStream_t>(s);

@@ -2429,14 +2429,13 @@ static int launch_roll(const Conv2dArgs& a, hipStream_t st, const Conv2dArgs* pa
             if (cost < best - 1e-9) { best = cost; mr = m; zt = z; }
         }
     }
-    static const char* fm = getenv("EFFI_ROLL_MR");
-    static const char* fz = getenv("EFFI_ROLL_ZT");
-    if (fm) mr = atoi(fm);
-    if (fz) zt = atoi(fz);
+    const long fm = effi_option(EFFI_OPT_ROLL_MR), fz = effi_option(EFFI_OPT_ROLL_ZT);       // A/B overrides of the rounds model
+    if (fm != EFFI_OPT_UNSET) mr = (int)fm;
+    if (fz != EFFI_OPT_UNSET) zt = (int)fz;
     const long tiles = (long)cols * effi_cdiv(a.h, 4 * mr);
     const dim3 grid((unsigned)tiles, (unsigned)effi_cdiv(D, zt), pair ? 2 : 1);
-    static const char* frp = getenv("EFFI_ROLL_RP");          // A/B switch (with packing.py): 0 = the one-row-per-tile operand
-    if (NT == 1 && a.cout <= 8 && !(frp && atoi(frp) == 0)) {     // row-pair operand (see conv3d_roll_rp_bf16x3_body)
+    // (option roll_rp = 0, with packing.py: the one-row-per-tile operand, A/B runs)
+    if (NT == 1 && a.cout <= 8 && effi_option(EFFI_OPT_ROLL_RP) != 0) {     // row-pair operand (see conv3d_roll_rp_bf16x3_body)
         if (pair) {
             if (mr == 4) hipLaunchKernelGGL((conv3d_roll_rp_bf16x3_pair_kernel<NOCT, 4>), grid, dim3(256), 0, st, a, *pair, cols, (int)tiles, zt);
             else hipLaunchKernelGGL((conv3d_roll_rp_bf16x3_pair_kernel<NOCT, 2>), grid, dim3(256), 0, st, a, *pair, cols, (int)tiles, zt);
@@ -2540,8 +2539,8 @@ extern "C" int EFFI_FN(effi_deconv3d_k3s2_bf16x3_f32)(const float* in, int cin, 
     const int occ1 = half ? 5 : 3, occ2 = half ? 3 : 2;
     const long wg1 = (long)tiles_x * effi_cdiv(h, 4) * D, wg2 = (long)tiles_x * effi_cdiv(h, 8) * D;
     bool mr2 = effi_cdiv(wg2, 256L * occ2) * 4 < effi_cdiv(wg1, 256L * occ1) * 3;
-    static const char* fdm = getenv("EFFI_DECONV_MR");
-    if (fdm) mr2 = atoi(fdm) == 2;
+    const long fdm = effi_option(EFFI_OPT_DECONV_MR);
+    if (fdm != EFFI_OPT_UNSET) mr2 = fdm == 2;
     const dim3 grid(tiles_x * effi_cdiv(h, mr2 ? 8 : 4), D);
 #define EFFI_DC(MRV, ALV, HFV) \
     hipLaunchKernelGGL((deconv3d_s2_bf16x3_kernel<MRV, ALV, HFV>), grid, dim3(256), 0, st, a, tiles_x, (int)grid.x)

@@ -595,13 +595,13 @@ __global__ __launch_bounds__(256) void conv2d_k3_bf16x3_pair_kernel(const Conv2d
 // ---- split-bf16 3x3 convolution entry --------------------------------------------------------------------------
 // Thresholds of the rows-per-wave choice below (workgroup counts); the environment overrides are for A/B runs of the rule
 // (with several views in flight the chip is filled by other views' kernels, which favours the larger tiles earlier).
-static long effi_env_long(const char* name, long dflt) {
-    const char* v = getenv(name);
-    return v ? atol(v) : dflt;
+static long effi_opt_or(int id, long dflt) {
+    const long v = effi_option(id);
+    return v == EFFI_OPT_UNSET ? dflt : v;
 }
-static long effi_mr4_min() { static const long v = effi_env_long("EFFI_MR4_MIN", 400); return v; }
-static long effi_mr4_nt2_max() { static const long v = effi_env_long("EFFI_MR4_NT2_MAX", 1024); return v; }
-static long effi_mr2_min() { static const long v = effi_env_long("EFFI_MR2_MIN", 400); return v; }
+static long effi_mr4_min() { return effi_opt_or(EFFI_OPT_MR4_MIN, 400); }
+static long effi_mr4_nt2_max() { return effi_opt_or(EFFI_OPT_MR4_NT2_MAX, 1024); }
+static long effi_mr2_min() { return effi_opt_or(EFFI_OPT_MR2_MIN, 400); }
 // Rows per wave (MR): 4 rows amortise the B fragments best, but the grid must still cover the 256 CUs (>= ~400 workgroups),
 // and with two N-tiles the 4-row variant drops to 2 workgroups per CU where the 2-row one keeps 4: on large maps the latter
 // wins.  (Persistent workgroups with cross-tile prefetch were built and measured twice: no gain, more registers.)
@@ -614,11 +614,11 @@ static int launch_bf16x3(const Conv2dArgs& a, hipStream_t st) {
     if (t4 >= effi_mr4_min() && !(NT == 2 && t4 >= effi_mr4_nt2_max())) mr = 4;
     else if (t2 >= effi_mr2_min()) mr = 2;
     else mr = 1;
-    static const long force = effi_env_long("EFFI_FORCE_MR", 0);
+    const long force = effi_opt_or(EFFI_OPT_FORCE_MR, 0);
     if (force) mr = (int)force;
     // wide tiles (4 rows x 64 columns) pay off on the large maps only (measured with an HBM-cold working set, 592x800:
     // 16->16 23.8 -> 22.6 us, 32->12 33.3 -> 30.7, 32->16 GRU update 41.9 -> 38.6; 296x400: 38 -> 49 us for 64->64)
-    static const long wide_env = effi_env_long("EFFI_WIDE_TILES", -1);
+    const long wide_env = effi_opt_or(EFFI_OPT_WIDE_TILES, -1);
     const bool wide = wide_env >= 0 ? wide_env != 0 : (mr == 4 && a.w >= 512 && !ZB);
     if (wide) {
         const int tiles_x = effi_cdiv(a.w, 16 * mr), ntiles = tiles_x * effi_cdiv(a.h, 4);
@@ -657,7 +657,7 @@ static int launch_bf16x3_pair(const Conv2dArgs& a0, const Conv2dArgs& a1, hipStr
     if (t4 >= effi_mr4_min() && !(NT == 2 && t4 >= effi_mr4_nt2_max())) mr = 4;
     else if (t2 >= effi_mr2_min()) mr = 2;
     else mr = 1;
-    static const long force = effi_env_long("EFFI_FORCE_MR", 0);
+    const long force = effi_opt_or(EFFI_OPT_FORCE_MR, 0);
     if (force) mr = (int)force;
     if (mr == 4 && a0.w >= 512) {
         const int tiles_x = effi_cdiv(a0.w, 64), ntiles = tiles_x * effi_cdiv(a0.h, 4);

@@ -221,8 +221,7 @@ __global__ __launch_bounds__(256) void pixelwise_net_mfma_kernel(const float* __
 extern "C" int effi_pixelwise_net_f32(const float* entropy, const float* params, int n, int h, int w, float* weight,
                                       effi_stream_t stream) {
     if (!entropy || !params || !weight || n < 1 || n > 65535 || h < 1 || w < 1) return EFFI_ERR_BADARG;
-    const char* form = getenv("EFFI_PIXNET_MFMA");             // A/B switch (read per call): 0 = the vector-ALU kernel
-    if (form && form[0] == '0')
+    if (effi_option(EFFI_OPT_PIXNET_MFMA) == 0)                // A/B switch (effi_set_option): the vector-ALU kernel
         hipLaunchKernelGGL(pixelwise_net_kernel, dim3(effi_cdiv(w, T), effi_cdiv(h, T), n), dim3(256), 0, effi_s(stream),
                            entropy, params, h, w, weight);
     else

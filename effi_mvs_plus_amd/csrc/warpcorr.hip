@@ -38,10 +38,18 @@ struct Taps {
     int off[4];   // element offsets of the 4 taps' pixel (already multiplied by C)
 };
 
-// Lanes of one pixel share the per-hypothesis set-up (projection, two divisions, bilinear weights): lane j of
-// every aligned group of G = min(lanes-per-pixel, 4) lanes computes hypothesis d0 + j, and the 8 results are
-// broadcast inside the quad with quad_perm DPP moves (full-rate VALU, no LDS).  For C = 32 the two quads of a
-// pixel do this redundantly (2x instead of 8x), for C = 8 a quad holds two pixels and G = 2.
+// NO KERNEL OF THE SHIPPED LIBRARY PASSES A TAP SET-UP FROM ONE LANE TO ANOTHER.  Rounds 1-2 let lane j of a group of lanes set up
+// hypothesis d0 + j (projection, divisions, bilinear weights) and broadcast the eight results inside the quad (quad_perm DPP moves;
+// ds_bpermute was tried too).  Next to kernels of OTHER queues (three hipGraph replays in flight) the stage-2/3 kernel written that
+// way produced wrong similarities: single 16-lane rows of single loop iterations, always the ODD rows of a wave (lanes 16-31 /
+// 48-63), always too small by one view's contribution; never when a pass ran alone.  Scratch / spills are excluded (every kernel
+// of this file has a zero private segment), the DPP source lanes were valid (poison probe), the static code keeps the required
+// wait states between the VALU writes and the DPP reads, and no readlane / readfirstlane sits on the tap path (DESIGN.md section 6
+// has the evidence and what the ISA comparison of the failing and the passing form shows).  The cause below the ISA was not
+// established, so the defect CLASS is closed instead: every lane now computes the set-ups it consumes (hypothesis-per-lane forms
+// for the default kernels, plain recomputation for the generic / training kernels); only RESULTS (sums, maxima) cross lanes.
+// The exchange forms are compiled only with -DEFFI_DIAG_LANE_EXCHANGE (diagnostic builds; never the shipped library).
+#ifdef EFFI_DIAG_LANE_EXCHANGE
 template <int G, int J>
 __device__ __forceinline__ int quad_bcast_i(int v) {
     // source lane inside the quad for destination lanes 0..3
@@ -69,6 +77,7 @@ __device__ __forceinline__ void taps_bcast(const Taps& mine, Taps& out) {
         out.off[k] = quad_bcast_i<G, J>(mine.off[k]);
     }
 }
+#endif   // EFFI_DIAG_LANE_EXCHANGE
 
 // (X, Y, Z) in the source camera -> 4 bilinear taps (weights zeroed when out of bounds).
 __device__ __forceinline__ void make_taps(float X, float Y, float Z, int W, int H, int C, Taps& t) {
@@ -155,32 +164,15 @@ __global__ __launch_bounds__(256) void warpcorr_views_kernel(const float* __rest
     float* simv = sim_views + (long)view * D * hw + pix;
     const float* dp = depth + (long)pix * dps;
     float m = -INFINITY;
-    constexpr int GS = (G::LPP >= 4) ? 4 : 2;                    // lanes sharing the set-up
-    const int gj = threadIdx.x % GS;
-    for (int d0 = 0; d0 < D; d0 += GS) {
-        // this lane's hypothesis (clamped: the tail group recomputes the last one and discards it)
-        const int dm = min(d0 + gj, D - 1);
-        const float dep = dp[dm * dds];
-        Taps mine;
-        make_taps(rx * dep + tx, ry * dep + ty, rz * dep + tz, w, h, C, mine);     // module.py:325-327
-        auto one = [&](const Taps& t, int d) {
-            const float s = effi_group_sum<G::LPP>(sample_dot(src, t, sub4, r4)) / (float)C;   // mean over C, :40
-            if (d < D) {
-                if ((d % G::LPP) == sub) simv[(long)d * hw] = s;
-                m = fmaxf(m, s);
-            }
-        };
+    // every lane sets up every hypothesis itself (no set-up crosses lanes: see the note at the top of this file); this is the generic
+    // kernel (C != 32, per-pixel hypotheses, EFFI option warp_lds_kb = -1), not the cascade's default
+    for (int d = 0; d < D; ++d) {
+        const float dep = dp[d * dds];
         Taps t;
-        taps_bcast<GS, 0>(mine, t);
-        one(t, d0);
-        taps_bcast<GS, 1>(mine, t);
-        one(t, d0 + 1);
-        if (GS == 4) {
-            taps_bcast<GS, 2>(mine, t);
-            one(t, d0 + 2);
-            taps_bcast<GS, 3>(mine, t);
-            one(t, d0 + 3);
-        }
+        make_taps(rx * dep + tx, ry * dep + ty, rz * dep + tz, w, h, C, t);        // module.py:325-327
+        const float s = effi_group_sum<G::LPP>(sample_dot(src, t, sub4, r4)) / (float)C;   // mean over C, :40
+        if ((d % G::LPP) == sub) simv[(long)d * hw] = s;
+        m = fmaxf(m, s);
     }
     // softmax over D and entropy (models/Effi_MVS_plus.py:43-44); lane `sub` owns d = sub, sub+LPP, ...
     float z = 0.0f;
@@ -288,99 +280,103 @@ __device__ __forceinline__ void make_taps_win(float ix, float iy, int W, int H, 
     }
 }
 
-template <int J>
-__device__ __forceinline__ void wintaps_bcast(const WinTaps& mine, WinTaps& out) {      // from lane J of every quad
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        out.w[k] = __int_as_float(quad_bcast_i<4, J>(__float_as_int(mine.w[k])));
-        out.a[k] = quad_bcast_i<4, J>(mine.a[k]);
-    }
-}
-
-// this lane's 8 channels of the 4 taps: two float4 per tap
-struct TapData {
+// The 32 reference channels of a pixel as this lane sees them: ROTATED by the lane's position in its pixel's quad -- position i
+// holds channels 8 ((sub + i) & 3) .. + 7 -- so that at step i the four lanes of a pixel read four DIFFERENT 32-byte pieces of
+// their taps: the LDS image and its bank behaviour are those of the channel-split form (a ds_read_b128 lane group = 4 pixels x 4
+// lanes is conflict-free when the four tap pixels differ mod 4), although every lane now walks all 32 channels of ITS OWN hypothesis.
+struct RefRot {
     float4 lo[4], hi[4];
 };
 
-template <bool LDSWIN>
-__device__ __forceinline__ void load_taps8(const char* __restrict__ win, const float* __restrict__ src, const WinTaps& t, int sub,
-                                           TapData& td) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (LDSWIN) {
-            // slot (8P + 2sub) ^ s = ((8P) ^ s) + 2sub (s only touches bit 0); its partner is that slot ^ 1
-            const int a = t.a[k] + sub * 32;
-            td.lo[k] = *reinterpret_cast<const float4*>(win + a);
-            td.hi[k] = *reinterpret_cast<const float4*>(win + (a ^ 16));
-        } else {
-            const float4* q = reinterpret_cast<const float4*>(src + (long)t.a[k] * 32 + sub * 8);
-            td.lo[k] = q[0];
-            td.hi[k] = q[1];
-        }
-    }
-}
-
-// sum over this lane's 8 channels of  ref[c] * (sum_t w_t * src[tap_t][c])  -- blend first, as grid_sample does, then the product
-__device__ __forceinline__ float blend_dot8(const TapData& td, const float (&w)[4], const float4 rlo, const float4 rhi) {
-    f32x2 v[4];
-#define EFFI_BLEND(dst, SRC, F0, F1)                                                            \
-    dst = f32x2{td.SRC[0].F0, td.SRC[0].F1} * f32x2{w[0], w[0]};                                \
-    dst = __builtin_elementwise_fma(f32x2{td.SRC[1].F0, td.SRC[1].F1}, f32x2{w[1], w[1]}, dst); \
-    dst = __builtin_elementwise_fma(f32x2{td.SRC[2].F0, td.SRC[2].F1}, f32x2{w[2], w[2]}, dst); \
-    dst = __builtin_elementwise_fma(f32x2{td.SRC[3].F0, td.SRC[3].F1}, f32x2{w[3], w[3]}, dst)
-    EFFI_BLEND(v[0], lo, x, y);
-    EFFI_BLEND(v[1], lo, z, w);
-    EFFI_BLEND(v[2], hi, x, y);
-    EFFI_BLEND(v[3], hi, z, w);
-#undef EFFI_BLEND
-    f32x2 acc = v[0] * f32x2{rlo.x, rlo.y};
-    acc = __builtin_elementwise_fma(v[1], f32x2{rlo.z, rlo.w}, acc);
-    acc = __builtin_elementwise_fma(v[2], f32x2{rhi.x, rhi.y}, acc);
-    acc = __builtin_elementwise_fma(v[3], f32x2{rhi.z, rhi.w}, acc);
-    return acc.x + acc.y;
-}
-
 constexpr int WIN_TW = 16, WIN_TH = 8, WIN_THREADS = 512;
+
+// all threads of the workgroup (after hyp[] is visible): are the D <= 256 hypotheses monotone (non-decreasing or non-increasing)?
+__device__ __forceinline__ bool win_hyp_monotone(const float* __restrict__ hyp, int D, int tid) {
+    const bool mine = tid + 1 < D;
+    const float a = mine ? hyp[tid] : 0.0f, b = mine ? hyp[tid + 1] : 0.0f;
+    const int inc = __syncthreads_and(!mine || b >= a), dec = __syncthreads_and(!mine || b <= a);
+    return inc || dec;
+}
 
 struct WinProj {                // per-thread projection state of its pixel and view
     float rx, ry, rz, tx, ty, tz, hw2, rhw2, hh2, rhh2, wm1, hm1;
 };
 
+// One chunk of hypotheses for this lane's pixel, HYPOTHESIS-PER-LANE: lane `sub` of the pixel's quad owns hypothesis d0 + sub with
+// all 32 channels -- its set-up (projection, weights, tap addresses) is computed once, by the lane that uses it, and nothing but the
+// finished similarity leaves the lane.  (Rounds 1-2: the four lanes split the CHANNELS of every hypothesis and passed the set-ups
+// round with quad_perm DPP moves; see the note at the top of this file.)  Per hypothesis a lane issues 32 ds_read_b128 (4 taps x 8
+// float4) -- the same LDS traffic per pixel as before -- and 80 packed FMAs; gone are the 32 DPP moves and 8 DPP adds per group of
+// four hypotheses.  Blend first, as grid_sample does, then the product with the reference features.
 template <bool LDSWIN>
 __device__ __forceinline__ void win_sample_chunk(const char* __restrict__ win, const float* __restrict__ src, const WinProj& P,
                                                  const float* __restrict__ hyp, int da, int db, int D, int w, int h,
-                                                 int x_lo, int y_lo, int ww, int wh, int sub, const float4 rlo, const float4 rhi,
+                                                 int x_lo, int y_lo, int ww, int wh, int sub, const RefRot& R,
                                                  bool valid, float* __restrict__ simv, int hw, float& m) {
-    // (A software-pipelined form -- tap reads of sample j + 1 in flight under the blend of sample j, next group's set-up under
-    // the last reads -- was built and measured: 96.7 us against 93.8 us for this plain loop at 148x200, D = 48, S = 4; it
-    // needs the 128-register cap and spills.  Four waves per SIMD hide the LDS latency well enough.)
+    int rot[4];                                   // byte offset of this lane's i-th 32-byte piece inside a pixel's 128 bytes
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rot[i] = ((sub + i) & 3) * 32;
     for (int d0 = da; d0 < db; d0 += 4) {
         const float dep = hyp[d0 + sub];      // this lane's hypothesis; hyp[] is padded with the last one to a multiple of 4
         float ix, iy;
         project_xy(P.rx * dep + P.tx, P.ry * dep + P.ty, P.rz * dep + P.tz, P.hw2, P.rhw2, P.hh2, P.rhh2, P.wm1, P.hm1, ix, iy);
-        WinTaps mine, t;
-        make_taps_win<LDSWIN>(ix, iy, w, h, x_lo, y_lo, ww, wh, mine);
-        TapData A;
-        float s[4];
-#define EFFI_ONE(J)                                                                  \
-        wintaps_bcast<J>(mine, t);                                                   \
-        load_taps8<LDSWIN>(win, src, t, sub, A);                                     \
-        s[J] = effi_group_sum<4>(blend_dot8(A, t.w, rlo, rhi)) * (1.0f / 32.0f)      /* mean over C (:40); x 2^-5 is exact */
-        EFFI_ONE(0); EFFI_ONE(1); EFFI_ONE(2); EFFI_ONE(3);
-#undef EFFI_ONE
-        const float own = (sub == 0) ? s[0] : (sub == 1) ? s[1] : (sub == 2) ? s[2] : s[3];
-        if (valid && d0 + sub < D) simv[(long)(d0 + sub) * hw] = own;
-        m = fmaxf(m, s[0]);
-        if (d0 + 1 < D) m = fmaxf(m, s[1]);
-        if (d0 + 2 < D) m = fmaxf(m, s[2]);
-        if (d0 + 3 < D) m = fmaxf(m, s[3]);
+        WinTaps t;
+        make_taps_win<LDSWIN>(ix, iy, w, h, x_lo, y_lo, ww, wh, t);
+        f32x2 acc = {0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // this step's 8 channels of the four taps, two taps at a time (16 registers of tap data in flight, not 32: with the 32
+            // reference registers the kernel must stay under the 128-register cap of two 512-thread workgroups per CU; the other
+            // three waves of the SIMD hide the LDS latency); blend in tap order, as grid_sample does
+            f32x2 v[4];
+#pragma unroll
+            for (int kp = 0; kp < 4; kp += 2) {
+                float4 lo[2], hi[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    if (LDSWIN) {
+                        // logical float4 q of window pixel P sits at slot (8P + q) ^ s: even q at t.a + 16 q, its odd partner at that ^ 16
+                        const int a = t.a[kp + k] + rot[i];
+                        lo[k] = *reinterpret_cast<const float4*>(win + a);
+                        hi[k] = *reinterpret_cast<const float4*>(win + (a ^ 16));
+                    } else {
+                        const float4* q = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(src) + ((long)t.a[kp + k] * 128 + rot[i]));
+                        lo[k] = q[0];
+                        hi[k] = q[1];
+                    }
+                }
+#define EFFI_BLEND2(dst, SRC, F0, F1)                                                                                   \
+                dst = (kp == 0) ? f32x2{SRC[0].F0, SRC[0].F1} * f32x2{t.w[0], t.w[0]}                                          \
+                                : __builtin_elementwise_fma(f32x2{SRC[0].F0, SRC[0].F1}, f32x2{t.w[kp], t.w[kp]}, dst);        \
+                dst = __builtin_elementwise_fma(f32x2{SRC[1].F0, SRC[1].F1}, f32x2{t.w[kp + 1], t.w[kp + 1]}, dst)
+                EFFI_BLEND2(v[0], lo, x, y);
+                EFFI_BLEND2(v[1], lo, z, w);
+                EFFI_BLEND2(v[2], hi, x, y);
+                EFFI_BLEND2(v[3], hi, z, w);
+#undef EFFI_BLEND2
+
+            }
+            acc = (i == 0) ? v[0] * f32x2{R.lo[0].x, R.lo[0].y} : __builtin_elementwise_fma(v[0], f32x2{R.lo[i].x, R.lo[i].y}, acc);
+            acc = __builtin_elementwise_fma(v[1], f32x2{R.lo[i].z, R.lo[i].w}, acc);
+            acc = __builtin_elementwise_fma(v[2], f32x2{R.hi[i].x, R.hi[i].y}, acc);
+            acc = __builtin_elementwise_fma(v[3], f32x2{R.hi[i].z, R.hi[i].w}, acc);
+        }
+        const float sv = (acc.x + acc.y) * (1.0f / 32.0f);          // mean over C (:40); x 2^-5 is exact
+        if (d0 + sub < D) {
+            if (valid) simv[(long)(d0 + sub) * hw] = sv;
+            m = fmaxf(m, sv);
+        }
     }
 }
 
 // wave 0: candidate k = lane >> 3 proposes the chunk [da, da + cs_k); its 8 lanes project the tile's corners at both ends of it;
 // the longest candidate whose box fits the window is published in par[0..5] = {x_lo, y_lo, ww, wh, db, use_lds}
+// mono: the hypotheses are monotone (checked once per workgroup, win_hyp_monotone): only then do the chunk's two END depths bound
+// the positions of the depths between them; otherwise every chunk is sampled from global memory (same arithmetic, any order of
+// hypotheses -- the reference accepts any depth_values)
 __device__ __forceinline__ void win_choose_chunk(const float* __restrict__ rt, const float* __restrict__ hyp, const WinProj& P,
-                                                 int txi, int tyi, int da, int D, int w, int h, int lds_px, int lane, int* par) {
+                                                 int txi, int tyi, int da, int D, int w, int h, int lds_px, int lane, int* par,
+                                                 bool mono) {
     const int ng = (D + 3) >> 2;
     const int k = lane >> 3, corner = lane & 7;
     const int rem_g = (D - da + 3) >> 2;                        // groups of 4 hypotheses still to do
@@ -410,7 +406,7 @@ __device__ __forceinline__ void win_choose_chunk(const float* __restrict__ rt, c
     x_lo = min(max(x_lo, 0), w - 1); x_hi = max(min(x_hi, w - 1), x_lo);
     y_lo = min(max(y_lo, 0), h - 1); y_hi = max(min(y_hi, h - 1), y_lo);
     const int ww = x_hi - x_lo + 1, wh = y_hi - y_lo + 1;
-    const bool fits = ok && (ww * wh <= lds_px);
+    const bool fits = ok && mono && (ww * wh <= lds_px);
     const unsigned long long mask = __ballot(fits && corner == 0);
     const int pick = mask ? (int)(__ffsll((long long)mask) - 1) : 56;      // longest fitting chunk, else the shortest
     if (lane == pick) {
@@ -444,8 +440,6 @@ __global__ __launch_bounds__(WIN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     const int hw = h * w, pix = ys * w + xs;
     // the hypotheses (shared by all pixels) once into LDS, padded with the last one to a multiple of 4
     for (int d = tid; d < ((D + 3) & ~3); d += WIN_THREADS) hyp[d] = depth[(long)min(d, D - 1) * dds];
-    const float4 rlo = *reinterpret_cast<const float4*>(ref + (long)pix * C + sub * 8);
-    const float4 rhi = *reinterpret_cast<const float4*>(ref + (long)pix * C + sub * 8 + 4);
     WinProj P;
     {
         const float fx = (float)xs, fy = (float)ys;
@@ -460,7 +454,8 @@ __global__ __launch_bounds__(WIN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     float* simv = sim_views + (long)view * D * hw + pix;
     float m = -INFINITY;
     __syncthreads();                                             // hyp[] visible
-    if (wv == 0) win_choose_chunk(rt, hyp, P, txi, tyi, 0, D, w, h, lds_px, lane, wpar[0]);
+    const bool mono = win_hyp_monotone(hyp, D, tid);
+    if (wv == 0) win_choose_chunk(rt, hyp, P, txi, tyi, 0, D, w, h, lds_px, lane, wpar[0], mono);
     __syncthreads();
     int da = 0, pb = 0;
     while (da < D) {
@@ -491,15 +486,25 @@ __global__ __launch_bounds__(WIN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
             __syncthreads();
         }
         // the next chunk's window is chosen by wave 0 before it joins the sampling (published by the barrier below)
-        if (wv == 0 && db < D) win_choose_chunk(rt, hyp, P, txi, tyi, db, D, w, h, lds_px, lane, wpar[pb ^ 1]);
+        if (wv == 0 && db < D) win_choose_chunk(rt, hyp, P, txi, tyi, db, D, w, h, lds_px, lane, wpar[pb ^ 1], mono);
+        // the pixel's reference features (rotated, see RefRot) are fetched per chunk, AFTER the window copy: 32 registers that must not
+        // stay live across the copy loop under the 128-register cap (128 L1-resident bytes per lane, 1-3 times per workgroup)
+        RefRot R;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* rp = ref + (long)pix * C + ((sub + i) & 3) * 8;
+            R.lo[i] = *reinterpret_cast<const float4*>(rp);
+            R.hi[i] = *reinterpret_cast<const float4*>(rp + 4);
+        }
         if (use_lds)
-            win_sample_chunk<true>(win, src, P, hyp, da, db, D, w, h, x_lo, y_lo, ww, wh, sub, rlo, rhi, valid, simv, hw, m);
+            win_sample_chunk<true>(win, src, P, hyp, da, db, D, w, h, x_lo, y_lo, ww, wh, sub, R, valid, simv, hw, m);
         else
-            win_sample_chunk<false>(win, src, P, hyp, da, db, D, w, h, 0, 0, w, h, sub, rlo, rhi, valid, simv, hw, m);
+            win_sample_chunk<false>(win, src, P, hyp, da, db, D, w, h, 0, 0, w, h, sub, R, valid, simv, hw, m);
         __syncthreads();           // the window is rewritten by the next chunk; wpar[pb ^ 1] is published
         da = db;
         pb ^= 1;
     }
+    m = effi_group_max<4>(m);          // a lane saw its own hypotheses only: maximum over the pixel's four lanes (a RESULT crosses lanes)
     if (!valid) return;
     // softmax over D and entropy (models/Effi_MVS_plus.py:43-44); lane `sub` owns (and wrote) d = sub, sub + 4, ...
     // exp(s - m) is evaluated once and parked in the (now free) window, [i][thread]: conflict-free, no second exp pass
@@ -535,16 +540,6 @@ struct WinTapsB {
     int a[4];     // index of the tap pixel in the LDS window (or -1: fallback to global atomics)
     int g[4];     // pixel index y*W + x in the source map
 };
-
-template <int J>
-__device__ __forceinline__ void wintapsb_bcast(const WinTapsB& mine, WinTapsB& out) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        out.w[k] = __int_as_float(quad_bcast_i<4, J>(__float_as_int(mine.w[k])));
-        out.a[k] = quad_bcast_i<4, J>(mine.a[k]);
-        out.g[k] = quad_bcast_i<4, J>(mine.g[k]);
-    }
-}
 
 template <int MAXPX>
 __global__ __launch_bounds__(WIN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void warpcorr_views_bwd_win_kernel(
@@ -596,7 +591,8 @@ __global__ __launch_bounds__(WIN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 #pragma unroll
     for (int c = 0; c < 8; ++c) gr[c] = 0.0f;
     __syncthreads();
-    if (wv == 0) win_choose_chunk(rt, hyp, P, txi, tyi, 0, D, w, h, lds_px, lane, wpar[0]);
+    const bool mono = win_hyp_monotone(hyp, D, tid);
+    if (wv == 0) win_choose_chunk(rt, hyp, P, txi, tyi, 0, D, w, h, lds_px, lane, wpar[0], mono);
     __syncthreads();
     int da = 0, pb = 0;
     while (da < D) {
@@ -607,22 +603,21 @@ __global__ __launch_bounds__(WIN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
             for (int i = tid; i < 8 * npad; i += WIN_THREADS) win4[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             __syncthreads();
         }
-        if (wv == 0 && db < D) win_choose_chunk(rt, hyp, P, txi, tyi, db, D, w, h, lds_px, lane, wpar[pb ^ 1]);
+        if (wv == 0 && db < D) win_choose_chunk(rt, hyp, P, txi, tyi, db, D, w, h, lds_px, lane, wpar[pb ^ 1], mono);
         for (int d0 = da; d0 < db; d0 += 4) {
-            const float dep = hyp[d0 + sub];
-            float ix, iy;
-            project_xy(P.rx * dep + P.tx, P.ry * dep + P.ty, P.rz * dep + P.tz, P.hw2, P.rhw2, P.hh2, P.rhh2, P.wm1, P.hm1, ix, iy);
-            WinTaps tw, tg;
-            make_taps_win<true>(ix, iy, w, h, x_lo, y_lo, ww, wh, tw);
-            make_taps_win<false>(ix, iy, w, h, 0, 0, w, h, tg);
-            WinTapsB mine, t;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { mine.w[k] = tw.w[k]; mine.a[k] = use_lds ? (tw.a[k] >> 7) : -1; mine.g[k] = tg.a[k]; }   // window pixel index
-            const float my_g = (valid && d0 + sub < D) ? gsim[(long)(d0 + sub) * hw] * (1.0f / 32.0f) : 0.0f;     // x 1/C
+            // every lane sets up all four hypotheses of the group itself (no set-up crosses lanes: note at the top of this file); the
+            // set-up is ~3 % of this kernel, which is bound by the LDS atomic unit
 #define EFFI_ONE(J)                                                                                                     \
             {                                                                                                           \
-                wintapsb_bcast<J>(mine, t);                                                                             \
-                const float g = __int_as_float(quad_bcast_i<4, J>(__float_as_int(my_g)));                               \
+                const float dep = hyp[d0 + J];                                                                          \
+                float ix, iy;                                                                                           \
+                project_xy(P.rx * dep + P.tx, P.ry * dep + P.ty, P.rz * dep + P.tz, P.hw2, P.rhw2, P.hh2, P.rhh2, P.wm1, P.hm1, ix, iy); \
+                WinTaps tw, tg;                                                                                         \
+                make_taps_win<true>(ix, iy, w, h, x_lo, y_lo, ww, wh, tw);                                              \
+                make_taps_win<false>(ix, iy, w, h, 0, 0, w, h, tg);                                                     \
+                WinTapsB t;                                                                                             \
+                _Pragma("unroll") for (int k = 0; k < 4; ++k) { t.w[k] = tw.w[k]; t.a[k] = use_lds ? (tw.a[k] >> 7) : -1; t.g[k] = tg.a[k]; } \
+                const float g = (valid && d0 + J < D) ? gsim[(long)(d0 + J) * hw] * (1.0f / 32.0f) : 0.0f;     /* x 1/C */ \
                 _Pragma("unroll") for (int k = 0; k < 4; ++k) {                                                         \
                     const float gw = g * t.w[k];                                                                        \
                     if (gw == 0.0f) continue;              /* out-of-bounds taps, masked pixels: nothing to add */      \
@@ -699,7 +694,9 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* __restri
     for (int v = 0; v < S; ++v) wsum = wsum + view_w[(long)v * vh * vw + vpix];
     const float den = wsum + 1e-6f;
     constexpr int GS = (G::LPP >= 4) ? 4 : 2;
+#ifdef EFFI_DIAG_LANE_EXCHANGE
     const int gj = threadIdx.x % GS;
+#endif
     // FAST set-up (the default, see effi_warpcorr_dyn_f32): the kernel is bound by vector-ALU issue -- a hypothesis' set-up is ~130
     // instructions with the four IEEE divisions of the projection, and without a lane exchange every lane sets up every hypothesis.
     // This form uses the stage-1 window kernel's projection (project_xy: refined reciprocal + one residual step per division,
@@ -709,8 +706,10 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* __restri
     const float hw2 = wm1 / 2.0f, hh2 = hm1 / 2.0f;
     const float rhw2 = 1.0f / hw2, rhh2 = 1.0f / hh2;              // IEEE divisions: correctly rounded reciprocals
     for (int d0 = 0; d0 < D; d0 += GS) {
+#ifdef EFFI_DIAG_LANE_EXCHANGE
         const int dm = min(d0 + gj, D - 1);
         const float my_dep = 1.0f / fmaxf(smin + (float)dm * step, 1e-5f);
+#endif
         float acc[GS], dep[GS];
 #pragma unroll
         for (int j = 0; j < GS; ++j) {
@@ -723,7 +722,10 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* __restri
             const float rx = rt[0] * fx + rt[1] * fy + rt[2];
             const float ry = rt[3] * fx + rt[4] * fy + rt[5];
             const float rz = rt[6] * fx + rt[7] * fy + rt[8];
-            Taps mine, t;
+#ifdef EFFI_DIAG_LANE_EXCHANGE
+            Taps mine;
+#endif
+            Taps t;
             const float wv = view_w[(long)v * vh * vw + vpix];
             if (NODPP && !SHFL && FAST) {
                 const char* __restrict__ sb = reinterpret_cast<const char*>(src) + sub4 * 4;
@@ -745,6 +747,7 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* __restri
                 }
                 continue;
             }
+#ifdef EFFI_DIAG_LANE_EXCHANGE
             if (NODPP && SHFL) {
                 // A/B form (EFFI_DYN_XCHG=shfl): each lane of a group sets up ONE hypothesis and the taps go round through ds_bpermute.
                 // Fails next to concurrent replays exactly like the DPP form below
@@ -761,6 +764,7 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* __restri
                 }
                 continue;
             }
+#endif
             if (NODPP) {
                 // NO cross-lane exchange (the default): every lane sets up all GS hypotheses itself.  The exchange form below (each lane
                 // of a group sets up ONE hypothesis, the taps go round by quad_perm DPP moves; 1.5 % faster per view) gives wrong
@@ -776,6 +780,7 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* __restri
                 }
                 continue;
             }
+#ifdef EFFI_DIAG_LANE_EXCHANGE
             make_taps(rx * my_dep + rt[9], ry * my_dep + rt[10], rz * my_dep + rt[11], w, h, C, mine);
             taps_bcast<GS, 0>(mine, t);
             acc[0] = fmaf(wv, sample_dot(src, t, sub4, r4), acc[0]);
@@ -787,6 +792,7 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* __restri
                 taps_bcast<GS, 3>(mine, t);
                 acc[3] = fmaf(wv, sample_dot(src, t, sub4, r4), acc[3]);
             }
+#endif
         }
 #pragma unroll
         for (int j = 0; j < GS; ++j) {
@@ -1136,15 +1142,14 @@ extern "C" int effi_homo_warp_bwd_f32(const float* rt, const float* depth, long 
 // Window capacity of the stage-1 LDS kernel in pixels (128 B each): 72 KB leaves room for two 512-thread workgroups per CU.
 constexpr int WIN_MAXPX = 576;
 
-// EFFI_WARP_LDS_KB (read at every call; tests and A/B runs only): unset = the windowed kernel with its full 72 KB window;
+// Option warp_lds_kb (effi_set_option; tests and A/B runs only): unset = the windowed kernel with its full 72 KB window;
 // 0 = the windowed kernel with every chunk sampled from global memory (same arithmetic, the bitwise cross-check);
 // -1 = the direct-gather kernel (also what C != 32 and per-pixel hypotheses use).
 static int warp_lds_px() {
-    const char* e = getenv("EFFI_WARP_LDS_KB");
-    if (!e || !*e) return WIN_MAXPX;
-    const int kb = atoi(e);
+    const long kb = effi_option(EFFI_OPT_WARP_LDS_KB);
+    if (kb == EFFI_OPT_UNSET) return WIN_MAXPX;
     if (kb < 0) return -1;
-    return min(WIN_MAXPX, kb * 1024 / 128);
+    return min(WIN_MAXPX, (int)(kb * 1024 / 128));
 }
 
 extern "C" int effi_warpcorr_views_f32(const float* ref_nhwc, const float* const* src_nhwc, int S, const float* rt,
@@ -1216,12 +1221,12 @@ extern "C" int effi_warpcorr_dyn_f32(const float* ref_nhwc, const float* const* 
     // (An 8-channels-per-lane form of this kernel -- one lane per pixel at C = 8, no exchange, no reduction, cheaper projection --
     // was built and measured at 592x800: 121 us against 109 us; at 296x400, C = 16: 63 against 58.  These kernels are bound by the
     // number of distinct cache lines a wave-instruction touches in the L1 / texture path, not by instruction issue.)
-    // how the lanes of a group share the hypotheses' taps: not at all (default: every lane sets up every hypothesis); A/B forms that are
-    // NOT safe next to other concurrent replays (see the kernel): "dpp" = quad_perm DPP moves, "shfl" = ds_bpermute
-    const char* xchg = getenv("EFFI_DYN_XCHG");
 #define EFFI_DYN(CC, ...) hipLaunchKernelGGL((warpcorr_dyn_kernel<CC, __VA_ARGS__>), dim3(grid_blocks<CC>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples)
-    if (xchg && (xchg[0] == 'd' || xchg[0] == 's')) {
-        const bool dpp = xchg[0] == 'd';
+#ifdef EFFI_DIAG_LANE_EXCHANGE
+    // diagnostic builds only: the forms that pass set-ups between lanes (option dyn_xchg: 1 = quad_perm DPP moves, 2 = ds_bpermute)
+    const long xchg = effi_option(EFFI_OPT_DYN_XCHG);
+    if (xchg == 1 || xchg == 2) {
+        const bool dpp = xchg == 1;
         switch (C) {
             case 32: if (dpp) EFFI_DYN(32, false, false); else EFFI_DYN(32, true, true); break;
             case 16: if (dpp) EFFI_DYN(16, false, false); else EFFI_DYN(16, true, true); break;
@@ -1231,13 +1236,12 @@ extern "C" int effi_warpcorr_dyn_f32(const float* ref_nhwc, const float* const* 
         EFFI_LAUNCH_CHECK();
         return EFFI_OK;
     }
-    // (the three EFFI_DYN_* switches are read at every call, so that one process -- tests/test_gpu_kernels.py -- can compare the forms)
+#endif
     // Default for C = 8 / 16 (stages 2 / 3): the hypothesis-per-lane form (91 vs 107 us at 592x800, 60 vs 75 us at 296x400);
-    // EFFI_DYN_FORM=lanes selects the channel-split form below for A/B runs.
-    const char* form = getenv("EFFI_DYN_FORM");
-    const char* setup = getenv("EFFI_DYN_SETUP");
-    const bool exact = setup && setup[0] == 'e';
-    if (!exact && !(form && form[0] == 'l') && (C == 8 || C == 16) && (long)h * w * C * 4 < (1L << 31)) {
+    // option dyn_form = 1 selects the channel-split form below, dyn_setup_exact = 1 the reference's IEEE divisions (A/B runs, tests)
+    const bool lanes = effi_option(EFFI_OPT_DYN_FORM) == 1;
+    const bool exact = effi_option(EFFI_OPT_DYN_SETUP_EXACT) == 1;
+    if (!exact && !lanes && (C == 8 || C == 16) && (long)h * w * C * 4 < (1L << 31)) {
         if (C == 8) hipLaunchKernelGGL(warpcorr_dyn_hyp_kernel<8>, dim3(grid_blocks<8>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples);
         else hipLaunchKernelGGL(warpcorr_dyn_hyp_kernel<16>, dim3(grid_blocks<16>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples);
         EFFI_LAUNCH_CHECK();

@@ -8,7 +8,6 @@ there is no eager fallback on this path.
 """
 from __future__ import annotations
 
-import os
 
 import torch
 import torch.nn as nn
@@ -75,7 +74,7 @@ class Conv3d(nn.Module):
         cin_total = sum(x.shape[0] for x in srcs)
         if (skip is None and _triple(self.conv.stride) == (1, 1, 1) and 1 < self.out_channels <= 32 and len(srcs) <= 2
                 and cin_total in (8, 16) and srcs[0].shape[0] % 8 == 0 and srcs[0].shape[-1] % 4 == 0
-                and ops.uses_split() and os.environ.get("EFFI_ROLL", "1") != "0"):
+                and ops.uses_split() and ops.option("roll") != 0):
             # 8 / 16 input channels: rolling window of input planes in LDS, each plane fetched once
             t = [self.conv.weight, self.conv.bias]
             if self.bn is not None:
@@ -84,7 +83,7 @@ class Conv3d(nn.Module):
             return ops.conv3d_k3s1_roll(srcs, wp, bp, self.out_channels, relu=self.relu)
         if (skip is None and _triple(self.conv.stride) == (1, 1, 1) and 1 < self.out_channels <= 32
                 and self.conv.in_channels >= 8 and self.conv.in_channels % 8 == 0 and ops.uses_split()
-                and (srcs[0].shape[-1] % 4 == 0 or os.environ.get("EFFI_CONV3D_UNALIGNED_SPLIT", "1") != "0")):
+                and (srcs[0].shape[-1] % 4 == 0 or ops.option("conv3d_unaligned_split") != 0)):
             # stride-1 layers with >= 8 input channels: z-batched 2-D convolutions on the bf16 matrix cores in split
             # precision (single-channel inputs stay on the vector kernel: 3 of 16 K-slots used, measured slower)
             t = [self.conv.weight, self.conv.bias]
@@ -102,7 +101,7 @@ class Conv3d(nn.Module):
             return ops.conv3d_k3s1_mfma(srcs[0], wp, bp, self.out_channels, relu=self.relu)
         if (len(srcs) == 1 and skip is None and _triple(self.conv.stride) == (2, 2, 2) and self.out_channels <= 64
                 and self.conv.in_channels >= 8 and srcs[0].shape[-1] % 4 == 0 and ops.uses_split()
-                and os.environ.get("EFFI_CONV3D_S2_SPLIT", "1") != "0"):
+                and ops.option("conv3d_s2_split") != 0):
             # down-sampling U-Net levels in split precision (column parities de-interleaved in LDS, as the pyramid's 5x5 stride-2 layers)
             t = [self.conv.weight, self.conv.bias]
             if self.bn is not None:
@@ -298,7 +297,7 @@ class P_1to8_FeatureNet_Fast(nn.Module):
         c0 = list(self.conv0)
         if (ops.uses_split() and len(c0) == 2 and all(self._is_k3s1(b) and b.relu for b in c0) and c0[0].conv.in_channels <= 8
                 and c0[0].conv.out_channels <= 8 and c0[1].conv.out_channels <= 8 and img.shape[-1] % 4 == 0
-                and os.environ.get("EFFI_FPN_CONV0_FUSED", "1") != "0"):
+                and ops.option("fpn_conv0_fused") != 0):
             # the two full-resolution layers in one kernel: their 8-channel intermediate (61 MB at 1184x1600) stays in LDS
             (w1, b1), (w2, b2) = (self._pk_oct(f"conv0.{i}", b.conv, b.bn) for i, b in enumerate(c0))
             x = ops.conv2d_k3_twice(x, w1, b1, w2, b2, c0[1].conv.out_channels)
@@ -326,7 +325,7 @@ class P_1to8_FeatureNet_Fast(nn.Module):
         co3 = self.out3.out_channels
         if (ops.uses_split() and self.out3.bias is None and self.out3.kernel_size == (3, 3) and co3 <= 16 and l1.shape[0] % 8 == 0
                 and top.shape[0] % 8 == 0 and l1.shape[-1] % 4 == 0 and top.shape[-1] % 4 == 0 and l1.shape[-2] % 2 == 0
-                and os.environ.get("EFFI_FPN_SPLIT_HEAD", "1") != "0"):
+                and ops.option("fpn_split_head") != 0):
             # the last head without its 64-channel full-resolution input: the upsampled branch is evaluated at half resolution
             # (4 parity groups of output channels), the lateral branch with out3 o inner2 composed (packing.pack_fpn_head_split)
             t = [self.out3.weight, self.inner2.weight, self.inner2.bias]
@@ -448,7 +447,7 @@ class cost_up_small(nn.Module):
                     and _triple(m.conv1.conv.stride) == (1, 1, 1) and m.conv2.out_channels == 1
                     and _triple(m.conv2.conv.stride) == (1, 2, 2) and m.conv0.relu and m.conv_cost.relu and m.conv1.relu
                     and m.conv2.relu and not m.training)
-        if os.environ.get("EFFI_CSP_PAIR", "1") == "0":        # A/B switch: every layer of the two blocks as its own launch
+        if ops.option("csp_pair") == 0:        # A/B switch: every layer of the two blocks as its own launch
             return False
         return stock(a) and stock(b) and ops.uses_split() and x.shape[0] == 1 and prior_w % 4 == 0
 

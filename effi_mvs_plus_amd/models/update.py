@@ -9,7 +9,6 @@ Inference only.
 from __future__ import annotations
 
 import functools
-import os
 
 import torch
 import torch.nn as nn
@@ -57,7 +56,7 @@ class DepthHead(nn.Module):
         """conv1 + ReLU + the nine tap projections of conv2 in one kernel (``run_taps``): split / bf16 precision, hidden sizes the
         fused 3x3 -> 1x1 kernel is built for."""
         c1 = self.conv1.out_channels
-        if os.environ.get("EFFI_HEAD_TAPS", "1") == "0":      # A/B switch: the two-kernel form
+        if ops.option("head_taps") == 0:      # A/B switch: the two-kernel form
             return False
         return (ops.uses_split() and net.shape[-1] % 4 == 0 and c1 % 16 == 0 and c1 // 16 in (1, 2, 3, 4, 6)
                 and self.conv1.in_channels % 8 == 0 and self.conv2.out_channels == 1)
@@ -174,7 +173,7 @@ class ProjectionInput(nn.Module):
             w, b = _pack(self._caches["d"], self.convd)
             cmix, cd = self.convd.out_channels, context.shape[0]
             if (hd == 16 and cmix <= 16 and cd <= 16 and w.wx is not None and self.convc.in_channels == cmix + cd
-                    and os.environ.get("EFFI_ENC_TAIL", "0") == "1"):
+                    and ops.option("enc_tail") == 1):
                 # the rest of the encoder in one kernel: the two 3x3 maps of this level never reach HBM.  Opt-in (EFFI_ENC_TAIL=1):
                 # measured at 592x800 the kernel takes 69.1 us, exactly the 31.5 + 37.3 us of the two launches it replaces (the
                 # 120 MB it saves are paid back by 1.31x first-layer work at two workgroups per CU), and a view gets 0.8 % slower

@@ -92,6 +92,60 @@ def _x3(name):
     return getattr(_lib.lib(), name + "_bf16" if _PRECISION == "bf16" else name)
 
 
+# A/B switches.  Python-level ones (which fused form a module launches) live in ``_PY_OPTS``; kernel-level ones (tile rules, kernel
+# forms) in the library's own table (include/effi_mvs_hip.h: effi_set_option).  Both are initialised ONCE from the environment
+# (EFFI_<NAME>) and changed afterwards through ``set_option`` -- nothing on a per-call path reads the environment.
+_PY_OPTION_DEFAULTS = {"c1k7_mfma": 1, "k5s2_split": 1, "roll": 1, "conv3d_unaligned_split": 1, "conv3d_s2_split": 1, "fpn_conv0_fused": 1,
+                       "fpn_split_head": 1, "csp_pair": 1, "head_taps": 1, "enc_tail": 0}
+_PY_OPTS = {k: int(os.environ.get("EFFI_" + k.upper(), v)) for k, v in _PY_OPTION_DEFAULTS.items()}
+LIB_OPTIONS = ("warp_lds_kb", "dyn_form", "dyn_setup_exact", "dyn_xchg", "pixnet_mfma", "force_mr", "mr4_min", "mr4_nt2_max", "mr2_min",
+               "wide_tiles", "roll_mr", "roll_zt", "roll_rp", "deconv_mr")
+
+
+def option(name):
+    """Current value of a Python-level switch."""
+    return _PY_OPTS[name]
+
+
+def get_option(name):
+    """Value of any switch (None = unset library switch: the built-in rule applies)."""
+    if name in _PY_OPTS:
+        return _PY_OPTS[name]
+    if name not in LIB_OPTIONS:
+        raise KeyError(name)
+    L = _lib.lib()
+    v = L.effi_get_option(name.encode())
+    return None if v == L.effi_option_unset() else int(v)
+
+
+def set_option(name, value):
+    """Set a switch (``value=None``: back to the default / unset).  Returns the previous value (for restoring)."""
+    before = get_option(name)
+    if name in _PY_OPTS:
+        _PY_OPTS[name] = _PY_OPTION_DEFAULTS[name] if value is None else int(value)
+    else:
+        L = _lib.lib()
+        check(L.effi_set_option(name.encode(), L.effi_option_unset() if value is None else int(value)), "effi_set_option")
+    return before
+
+
+class options:
+    """``with ops.options(warp_lds_kb=0, head_taps=0): ...`` -- switches set for the block, restored after it."""
+
+    def __init__(self, **kw):
+        self.kw, self.before = kw, {}
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            self.before[k] = set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.before.items():
+            set_option(k, v)
+        return False
+
+
 def set_profile(p):
     global _PROF
     _PROF = p
@@ -832,7 +886,7 @@ def encoder_inputs(x, disp_range, interval, cur_vol, reg_vol, dmin, dmax, nq, h,
         out_d1 = torch.empty(cout, h, w, device=x.device, dtype=torch.float32)
     work = lambda: {"flops": 2.0 * h * w * (2 * nq + 49) * cout, "bytes": 4.0 * h * w * (2 * cout + 1 + Dc + Dr)}
     # split / bf16 precision: the 7x7 half on the matrix cores (EFFI_C1K7_MFMA=0: the exact-fp32 vector form, as "fp32" precision uses)
-    x3 = uses_split() and os.environ.get("EFFI_C1K7_MFMA", "1") != "0"
+    x3 = uses_split() and _PY_OPTS["c1k7_mfma"] != 0
     fn = _lib.lib().effi_encoder_inputs_bf16x3_f32 if x3 else _lib.lib().effi_encoder_inputs_f32
     check(_call("encoder_inputs", work, fn, _p(x), _p(disp_range), disp_range.numel(),
                 _p(interval), _p(cur_vol), cds, cps, Dc, _p(reg_vol), rds, rps, Dr, _p(dmin_t), _p(dmax_t), gps, nq, h, w,
@@ -1231,7 +1285,7 @@ def conv2d_k5s2(x, wpack, bias, cout, act=ACT_RELU):
     out = torch.empty(cout, ho, wo, device=x.device, dtype=torch.float32)
     work = lambda: {"flops": 2.0 * ho * wo * cin * cout * 25, "bytes": 4.0 * (hin * win * cin + ho * wo * cout)}
     if hasattr(wpack, "w32"):                 # packing.Conv2dWeights: pick the arithmetic here
-        if uses_split() and wpack.wx is not None and win % 4 == 0 and os.environ.get("EFFI_K5S2_SPLIT", "1") != "0":
+        if uses_split() and wpack.wx is not None and win % 4 == 0 and _PY_OPTS["k5s2_split"] != 0:
             check(_call(f"conv2d_k5s2x3_nt{(cout + 15) // 16}", work, _x3("effi_conv2d_k5s2_bf16x3_f32"), _p(x), cin, _p(wpack.wx), _p(bias),
                         cout, hin, win, act, _p(out), _stream()), "effi_conv2d_k5s2_bf16x3_f32")
             return out
@@ -1248,7 +1302,7 @@ def conv2d_c1k7_relu(x, weight, bias, cout, out=None, exact=False):
     h, w = x.shape[-2:]
     if out is None:
         out = torch.empty(cout, h, w, device=x.device, dtype=torch.float32)
-    if not exact and uses_split() and os.environ.get("EFFI_C1K7_MFMA", "1") != "0":
+    if not exact and uses_split() and _PY_OPTS["c1k7_mfma"] != 0:
         check(_lib.lib().effi_conv2d_c1k7_relu_bf16x3_f32(_p(x), _p(weight), _p(bias), cout, h, w, _p(out), _stream()),
               "effi_conv2d_c1k7_relu_bf16x3_f32")
         return out

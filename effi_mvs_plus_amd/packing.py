@@ -6,7 +6,7 @@ timed path.
 """
 from __future__ import annotations
 
-import os
+from . import _lib
 
 import torch
 
@@ -118,7 +118,7 @@ def pack_conv3d_roll_bf16x3(conv, bn):
         bias = shift if bias is None else bias * scale + shift
     cout, cin = w.shape[0], w.shape[1]
     assert cin in (8, 16)
-    if cout <= 8 and os.environ.get("EFFI_ROLL_RP", "1") != "0":
+    if cout <= 8 and _lib.lib().effi_get_option(b"roll_rp") != 0:      # (A/B switch shared with the kernel's launch rule)
         return _pack_conv3d_roll_rowpair(w, bias)
     noct, nt = cin // 8, (cout + 15) // 16
     nit = 27 * noct

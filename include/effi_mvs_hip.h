@@ -572,6 +572,18 @@ int effi_conv3d_k3s1_roll_bf16x3_pair_f32_bf16(const float* const* srcs_a, const
 int effi_deconv3d_k3s2_bf16x3_f32_bf16(const float* in, int cin, const void* wpack_bf16, const float* bias, int cout,
                                   int D, int h, int w, int relu, const float* skip, float* out, effi_stream_t stream);
 
+/* ---- tuning / A-B switches.  A table of named integers, initialised ONCE per process from the environment (variable EFFI_<NAME in
+ * upper case>) and changed afterwards only through effi_set_option; no entry point reads the environment.  Names: warp_lds_kb
+ * (stage-1 warp kernel: LDS window in KB; 0 = the window kernel on global loads, -1 = the direct-gather kernel), dyn_form (1 =
+ * channel-split lanes in the stage-2/3 warp kernel), dyn_setup_exact (1 = IEEE divisions there), pixnet_mfma (0 = vector-ALU
+ * view-weight net), force_mr / mr4_min / mr4_nt2_max / mr2_min / wide_tiles (tile rule of the split-precision 3x3 convolutions),
+ * roll_mr / roll_zt / roll_rp / deconv_mr (tile rules of the 3-D convolutions), dyn_xchg (diagnostic builds only).
+ * effi_set_option returns EFFI_ERR_BADARG for an unknown name; effi_get_option returns effi_option_unset() for an unknown or unset one;
+ * effi_set_option(name, effi_option_unset()) restores "unset" (the built-in rule). */
+int effi_set_option(const char* name, long value);
+long effi_get_option(const char* name);
+long effi_option_unset(void);
+
 /* ================================================================================================================
  * Split-resident ("SR") activation maps of the GRU update block, models/update.py:33-49,69-99,109-141.
  * In split precision every 3x3 convolution reads an fp32 value x as hi = bf16(x), lo = bf16(x - hi).  The layers of the update

@@ -126,19 +126,12 @@ def test_warpcorr_views(O, C, h, w, D, N):
 
 
 def _with_env(name, value, fn):
-    import os
-    before = os.environ.get(name)
-    if value is None:
-        os.environ.pop(name, None)
-    else:
-        os.environ[name] = value
-    try:
+    """Run ``fn`` with the library switch that the environment variable ``name`` initialises (EFFI_X -> option x) set to ``value``
+    (None = unset: the built-in rule).  The library reads the environment once per process; afterwards switches go through
+    effi_set_option (ops.set_option)."""
+    from effi_mvs_plus_amd import ops
+    with ops.options(**{name[len("EFFI_"):].lower(): None if value is None else int(value)}):
         return fn()
-    finally:
-        if before is None:
-            os.environ.pop(name, None)
-        else:
-            os.environ[name] = before
 
 
 def _edge_cameras(h, w, N, kind):
@@ -195,6 +188,31 @@ def test_warpcorr_views_window_kernel(O, kind, h, w, D, N):
     check_close(f"window kernel sim [{kind} {h}x{w} D={D}]", sim, want_sim, **tol)
     check_close(f"window kernel entropy [{kind} {h}x{w} D={D}]", ent, want_ent, **tol)
     check_close(f"window vs direct-gather kernel sim [{kind}]", sim, sim_o, rtol=1e-5, atol=2e-5, frac_ok=0.999 if kind != "inside" else 0.97)
+
+
+def test_warpcorr_views_window_kernel_accepts_any_order_of_hypotheses(O):
+    """The reference accepts depth_values in any order (models/Effi_MVS_plus.py:32-61 never sorts them).  The window kernel bounds a
+    chunk's source positions by its two END depths, which holds for monotone hypotheses only: a workgroup that finds them
+    non-monotone samples every chunk from global memory.  Shuffled hypotheses: result = the monotone result permuted (the
+    similarity of a hypothesis does not depend on its neighbours) and equal to the direct-gather kernel, both to rounding."""
+    from effi_mvs_plus_amd import ops
+    h, w, D, N, C = 37, 50, 48, 4, 32
+    feats = synth.smooth_features(N, C, h, w, seed=77)
+    pm = synth.synth_cameras(h * 8, w * 8, N)["stage1"]
+    samples = 1.0 / torch.linspace(1 / 935.0, 1 / 425.0, D)
+    perm = torch.randperm(D, generator=torch.Generator().manual_seed(3))
+    nhwc = ops.to_nhwc([t(f[0], DEV) for f in feats])
+    rt = ops.compose_rel_proj(t(pm[0], DEV))
+    sim_sorted, _ = ops.warpcorr_views(nhwc[0], nhwc[1:], rt, t(samples, DEV), D)
+    sim_shuf, ent_shuf = ops.warpcorr_views(nhwc[0], nhwc[1:], rt, t(samples[perm], DEV), D)
+    # (not bitwise: a hypothesis' channel sum starts at the 8-channel group of the LANE that owns it -- position in the list mod 4)
+    check_close("shuffled hypotheses = the sorted result permuted", sim_shuf, sim_sorted.cpu()[:, perm], rtol=1e-5, atol=2e-6)
+    with ops.options(warp_lds_kb=-1):
+        sim_direct, ent_direct = ops.warpcorr_views(nhwc[0], nhwc[1:], rt, t(samples[perm], DEV), D)
+    check_close("shuffled hypotheses, window vs direct-gather kernel", sim_shuf, sim_direct, rtol=1e-5, atol=2e-5, frac_ok=0.999)
+    check_close("shuffled hypotheses, entropy", ent_shuf, ent_direct, rtol=1e-4, atol=2e-4, frac_ok=0.998)
+    want_sim, _ = _oracle_sim_views(O, feats, pm, samples[perm].view(1, D, 1, 1).expand(1, D, h, w))
+    check_close("shuffled hypotheses vs oracle", sim_shuf, want_sim, rtol=1e-4, atol=2e-4, frac_ok=0.998)
 
 
 @pytest.mark.parametrize("kind", ["rig", "rolled", "wide", "inside"])
@@ -278,21 +296,19 @@ def test_homo_warping_new_is_differentiable(O, C, h, w, D):
 
 
 @pytest.mark.parametrize("form", ["mfma", "valu"])
-def test_pixelwise_net(model, O, form, monkeypatch):
-    """Both kernels of the view-weight net (default: layers 2 / 3 on the fp32 matrix cores; EFFI_PIXNET_MFMA=0: vector ALU) against
+def test_pixelwise_net(model, O, form):
+    """Both kernels of the view-weight net (default: layers 2 / 3 on the fp32 matrix cores; option pixnet_mfma = 0: vector ALU) against
     the reference's vectors and the oracle, also on a map that is not a multiple of the 16 x 16 tile."""
+    from effi_mvs_plus_amd import ops
     net, sd = model
-    if form == "valu":
-        monkeypatch.setenv("EFFI_PIXNET_MFMA", "0")
-    else:
-        monkeypatch.delenv("EFFI_PIXNET_MFMA", raising=False)
-    g = load_golden("g03_pixelwise.npz")
-    got = net.PixelwiseNet(t(g["entropy"], DEV))
-    check_close(f"PixelwiseNet (golden, {form})", got, g["weight"], rtol=1e-4, atol=1e-5)
-    check_close(f"PixelwiseNet (oracle, {form})", got, O.pixelwise_net(sd, "PixelwiseNet", g["entropy"]), rtol=1e-4, atol=1e-5)
-    ent = torch.rand(3, 1, 37, 53, generator=torch.Generator().manual_seed(5)) * 3.0
-    check_close(f"PixelwiseNet 37x53 (oracle, {form})", net.PixelwiseNet(t(ent, DEV)), O.pixelwise_net(sd, "PixelwiseNet", ent),
-                rtol=1e-4, atol=1e-5)
+    with ops.options(pixnet_mfma=0 if form == "valu" else None):
+        g = load_golden("g03_pixelwise.npz")
+        got = net.PixelwiseNet(t(g["entropy"], DEV))
+        check_close(f"PixelwiseNet (golden, {form})", got, g["weight"], rtol=1e-4, atol=1e-5)
+        check_close(f"PixelwiseNet (oracle, {form})", got, O.pixelwise_net(sd, "PixelwiseNet", g["entropy"]), rtol=1e-4, atol=1e-5)
+        ent = torch.rand(3, 1, 37, 53, generator=torch.Generator().manual_seed(5)) * 3.0
+        check_close(f"PixelwiseNet 37x53 (oracle, {form})", net.PixelwiseNet(t(ent, DEV)), O.pixelwise_net(sd, "PixelwiseNet", ent),
+                    rtol=1e-4, atol=1e-5)
 
 
 def test_view_aggregate():
@@ -550,10 +566,11 @@ def test_getcost_initvolume(model, O):
     assert torch.equal(a, b)
 
 
-def test_getcost_initvolume_kernel_forms_agree(model, monkeypatch):
+def test_getcost_initvolume_kernel_forms_agree(model):
     """The stage-2/3 warp + correlation has a default form (a lane owns whole hypotheses, cheap projection) and switchable ones
-    (EFFI_DYN_FORM=lanes: lanes split the channels; EFFI_DYN_SETUP=exact: the reference's IEEE divisions op for op): every form
-    meets the golden vectors, and the forms agree far inside that tolerance."""
+    (option dyn_form = 1: lanes split the channels; dyn_setup_exact = 1: the reference's IEEE divisions op for op): every form
+    meets the golden vectors, and the forms agree far inside that tolerance.  No form passes a tap set-up between lanes."""
+    from effi_mvs_plus_amd import ops
     net, sd = model
     g = load_golden("g06_initvolume.npz")
     N, C, h, w = int(g["N"]), int(g["C"]), int(g["h"]), int(g["w"])
@@ -564,13 +581,10 @@ def test_getcost_initvolume_kernel_forms_agree(model, monkeypatch):
                                       depth_interval=t(g["interval"], DEV), depth_max=None, depth_min=None,
                                       view_weights=t(g["view_weights"], DEV), CostNum=8, Inverse=True, G=1)
     out = {}
-    for name, env in (("default", {}), ("lanes", {"EFFI_DYN_FORM": "lanes"}), ("exact", {"EFFI_DYN_SETUP": "exact"})):
-        for k in ("EFFI_DYN_FORM", "EFFI_DYN_SETUP", "EFFI_DYN_XCHG"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        sim, smp = run()
-        torch.cuda.synchronize()
+    for name, opts in (("default", {}), ("lanes", {"dyn_form": 1}), ("exact", {"dyn_setup_exact": 1})):
+        with ops.options(dyn_form=None, dyn_setup_exact=None), ops.options(**opts):
+            sim, smp = run()
+            torch.cuda.synchronize()
         out[name] = (sim.clone(), smp.clone())
         check_close(f"GetCost_initvolume.samples ({name})", smp, g["samples"], rtol=2e-6, atol=0)
         check_close(f"GetCost_initvolume.similarity ({name})", sim, g["similarity"], rtol=1e-4, atol=3e-4, frac_ok=0.995)

@@ -99,34 +99,30 @@ def test_cascade_vs_oracle_large_tiles(precision):
 
 
 def test_switchable_kernel_forms_agree():
-    """The A/B switches of the update block select other kernels for the same arithmetic: EFFI_ENC_TAIL=1 (encoder tail in one
-    kernel, intermediate maps in LDS) is bitwise the default two launches; EFFI_HEAD_TAPS=0 (depth head as conv1 -> hidden map ->
-    one-channel 3x3) differs from the default tap-projected head only by the summation order of conv2 (a tenth of the parity gates)."""
-    import os
+    """The A/B switches of the update block's fp32-map form (ops.set_sr(False): the split-resident form has one path) select other
+    kernels for the same arithmetic: enc_tail = 1 (encoder tail in one kernel, intermediate maps in LDS) is bitwise the default two
+    launches; head_taps = 0 (depth head as conv1 -> hidden map -> one-channel 3x3) differs from the default tap-projected head only by
+    the summation order of conv2 (a tenth of the parity gates)."""
+    from effi_mvs_plus_amd import ops
     net, sd = build_model("16,8,8", seed=4, device=DEV)
     imgs, pm, dv = synth.synth_sample(256, 320, 3, seed=5)
     feats, ctx = _features_on_cpu(sd, imgs)
     args = ([{k: t(v, DEV) for k, v in f.items()} for f in feats], {k: t(v, DEV) for k, v in ctx.items()},
             {k: t(v, DEV) for k, v in pm.items()}, t(dv, DEV))
 
-    def run(**env):
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
+    def run(**opts):
+        ops.set_sr(False)
         try:
-            with torch.no_grad():
+            with ops.options(**opts), torch.no_grad():
                 return [d.clone() for d in net.forward_hot(*args)["depth"]]
         finally:
-            for k, v in old.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+            ops.set_sr(True)
 
     base = run()
-    tail = run(EFFI_ENC_TAIL="1")
+    tail = run(enc_tail=1)
     for i, (a, b) in enumerate(zip(base, tail)):
         assert torch.equal(a, b), f"depth[{i}] differs with the one-kernel encoder tail"
-    two = run(EFFI_HEAD_TAPS="0")
+    two = run(head_taps=0)
     for i, (a, b) in enumerate(zip(base, two)):
         mean, p99, mx = _norm_err(a, b.cpu())
         assert mean <= 1e-4 and p99 <= 1e-3, (i, mean, p99, mx)       # rounding-level differences grow through nine rough-depth iterations

@@ -26,10 +26,7 @@ def main():
         hyp = (1.0 / torch.linspace(1 / 935.0, 1 / 425.0, D)).to(DEV)
         outs = {}
         for mode in modes:
-            if mode == "":
-                os.environ.pop("EFFI_WARP_LDS_KB", None)
-            else:
-                os.environ["EFFI_WARP_LDS_KB"] = mode
+            ops.set_option("warp_lds_kb", None if mode == "" else int(mode))
             for _ in range(3):
                 sim, ent = ops.warpcorr_views(nhwc[0], nhwc[1:], rt, hyp, D)
             torch.cuda.synchronize()
