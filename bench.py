@@ -29,6 +29,9 @@ WORKLOADS = {
     "cfg3": (1184, 1600, 5, "48,8,8"),       # the configuration BASELINE.json's metric is quoted on
     "cfg3b": (1184, 1600, 5, "48,32,8"),
     "cfg4": (1056, 1920, 7, "96,8,8"),
+    # the whole DTU evaluation set (22 scans x 49 reference views = 1,078 items, lists/dtu/test.txt) at cfg3's shape, sharded by item
+    # over the ranks: its own mode (run_cfg5): images -> pyramids (cached per scan) -> hot path -> batched gather
+    "cfg5": (1184, 1600, 5, "48,8,8"),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3                 # MI355X_MICROARCH.md, dense fp32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0                # dense bf16 matrix peak; a split-precision product costs three bf16 MFMAs
@@ -36,6 +39,130 @@ PEAK_HBM_GBPS = 8000.0
 DTYPE = {"split": "f32 (3x3 MFMA convs: products as 3 bf16 partial products hi*hi+hi*lo+lo*hi, f32 accumulate; all else f32)",
          "fp32": "f32",
          "bf16": "bf16 operands in the 3x3 / 3-D MFMA convs (hi*hi only), f32 accumulate; all else f32 -- NOT fp32-grade, own tolerance 1e-2"}
+
+
+def family_of(key):
+    """Kernel TEMPLATE a profile key belongs to: the per-instantiation keys of ops._call (conv2d_k3x3_nt2_epi1, conv2d_k3k1_nt1, ...)
+    of one template are one family -- the roofline brackets the family with the largest share of a view, not its largest key."""
+    if key.startswith(("conv2d_k3x3", "conv2d_k3k1")):        # conv2d_k3_bf16x3_kernel / _pair_kernel, every NT / MR / epilogue
+        return "conv2d_k3_bf16x3"
+    return key
+
+
+def path_work(H, W, N, nd):
+    """Algorithmic work of the hot path per reference view, SURVEY.md section 8(d) ("Algorithmic work per reference view"):
+    -> (FLOPs, bytes).  cfg3: 233.0 GFLOP, 569 MB; cfg2: 56.7 / 138; cfg3b: 246.7 / 655; cfg4: 269.2 / 795."""
+    S, Ds = N - 1, [int(x) for x in nd.split(",")]
+    hd, cd, C = (48, 32, 16), (12, 8, 4), (32, 16, 8)
+    mac = {48: 714240, 32: 320256, 16: 82176}                 # MACs per pixel of a stage's update block (3 iterations + mask head)
+    fl = by = 0.0
+    for s in range(3):
+        h, w = H // (8 >> s), W // (8 >> s)
+        px, D = h * w, Ds[s]
+        V = D * px
+        fl += S * V * (10 * C[s] + 20)                                                     # warp + correlate + aggregate
+        by += 4 * (S * C[s] * px + C[s] * px + D * px + px + S * (H // 8) * (W // 8)) + (8 * S * V if s == 0 else 0)
+        if s == 0:                                                                         # 3-D U-Net
+            fl += 2 * 4752 * V
+            by += 8 * V
+        else:                                                                              # the two cross-scale blocks
+            fl += 4 * 4104 * D * (h // 2) * (w // 2)
+            by += 8 * (2 * V + V / 4)
+        fl += 2 * px * mac[hd[s]]                                                          # update block
+        by += 4 * px * (2 * hd[s] + cd[s] + 2 * D + 41)
+    return fl, by
+
+
+def run_cfg5(args, torch, dist, rank, world, dev):
+    """BASELINE.json cfg5: every (scan, reference view) of an evaluation set, sharded contiguously over the ranks.
+    Inside the timed region, per item: feature pyramid of each image the rank has not seen in this scan (effi_mvs_plus_amd.scan_eval.
+    ScanFeatureCache: an image is the source of ~4 other views), context pyramid of the reference image, one hipGraph replay of the hot
+    path, copy of the two output maps into the gather's staging batch; every ``--gather-batch`` views one asynchronous gather to
+    rank 0.  Strong scaling: the set is fixed, N ranks split it."""
+    from common import build_model
+    from effi_mvs_plus_amd import _lib, ops, scan_eval, synth
+    from effi_mvs_plus_amd.graph import HotPathGraph
+    _lib.lib()
+    if args.precision:
+        ops.set_precision(args.precision)
+    precision = ops.get_precision()
+    H, W, N, nd = WORKLOADS["cfg5"]
+    net, _ = build_model(nd, seed=1, device=dev)
+    items = scan_eval.build_items(args.cfg5_scans, args.cfg5_images, N - 1)
+    _, pm, dv = synth.synth_sample(H, W, N, seed=0)          # one rig for every item: view 0 = the reference, 1.. = its sources
+    pm = {k: v.to(dev) for k, v in pm.items()}
+    dv = dv.to(dev)
+    distributed = world > 1
+
+    def image(scan, img):                                      # a synthetic "decoded image", generated on the device
+        g = torch.Generator(device=dev).manual_seed(100003 * scan + img)
+        return torch.rand(1, 3, H, W, device=dev, generator=g)
+
+    with torch.no_grad():
+        feats = scan_eval.ScanFeatureCache(lambda s_, i_: net.feature(image(s_, i_)))
+        f0 = [net.feature(image(0, v)) for v in range(N)]
+        c0 = net.cnet_depth(image(0, 0))
+        graph = HotPathGraph(net, f0, c0, pm, dv, slots=1)
+        del f0, c0
+        torch.cuda.synchronize()
+
+        def forward(item):
+            scan, ref, srcs = item
+            f = [feats.get(scan, ref)] + [feats.get(scan, v) for v in srcs]
+            ctx = net.cnet_depth(image(scan, ref))
+            out = graph(f, ctx, pm, dv)                        # device-to-device copy into the static slot + one graph launch
+            return out["depth"][-1][0], out["photometric_confidence"][0]
+
+        # untimed warm-up on a scan of its own (same shapes; its cache entries are dropped by the first timed item)
+        for it in scan_eval.build_items(1, min(args.cfg5_images, max(args.warmup, N + 1)), N - 1)[:max(1, args.warmup)]:
+            forward((10 ** 6, it[1], it[2]))
+        feats.hits = feats.misses = feats.max_entries = 0
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res, n_mine = scan_eval.run_scans(items, forward, gather_batch=args.gather_batch, dst=0, to_host=(distributed and args.backend != "nccl"))
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    peak = torch.cuda.max_memory_allocated()
+    stats = torch.tensor([dt, float(peak), float(feats.misses), float(feats.hits), float(n_mine)], dtype=torch.float64,
+                         device=dev if (not distributed or args.backend == "nccl") else "cpu")
+    if distributed:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    else:
+        mx = sm = stats
+    if rank == 0:
+        dt = float(mx[0])
+        ok = res is not None and res["depth"].shape[0] == len(items) and bool(torch.isfinite(res["depth"]).all())
+        print(json.dumps({
+            "metric": "ref-views/sec (whole evaluation set: pyramids + cost-volume hot path + batched gather to rank 0)",
+            "value": len(items) / dt, "unit": "views/s", "n_gpus": world, "steps": len(items), "warmup": max(1, args.warmup),
+            "ms_per_step": dt / len(items) * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": DTYPE[precision], "data": "synthetic",
+            "config": {"workload": f"cfg5: {args.cfg5_scans} scans x {args.cfg5_images} reference views = {len(items)} items at {W}x{H}, N={N} "
+                                   f"(S={N - 1} sources from a ring pair list), ndepths={nd}, GRU iters 3,3,3, seeded-random weights, synthetic images "
+                                   "generated on the device inside the timed region",
+                       "launch": "per item: pyramids of uncached images (eager), context pyramid, one hipGraph replay of the hot path",
+                       "parallelism": (f"items sharded contiguously over {world} ranks, {'RCCL' if args.backend == 'nccl' else 'gloo (rehearsal)'} "
+                                       f"gather of depth + confidence to rank 0 every {args.gather_batch} views, asynchronous, inside the timed region")
+                                      if world > 1 else "single GPU (same code path: staging batches, no collective)"},
+            "seconds_for_the_set": dt, "views_per_rank_max": int(mx[4]),
+            "feature_cache": {"pyramids_computed_all_ranks": int(sm[2]), "pyramids_reused_all_ranks": int(sm[3]),
+                              "note": "an image's feature pyramid is computed once per rank and scan and reused while it is a source view"},
+            "hbm_high_water_bytes_max_over_ranks": int(mx[1]),
+            "gathered_on_rank0": {"depth": list(res["depth"].shape), "confidence": list(res["confidence"].shape), "finite": ok},
+            "scaling_curve": "NOT measured by this run: one run is one N.  Comparing N = 1, 2, 4, 8 needs the driver's multi-GPU node; "
+                             "no efficiency is claimed here" if world == 1 else "one point of the curve (this N); efficiency is the driver's to compute",
+        }))
+        if not ok:
+            sys.exit(4)
 
 
 def self_launch(n, backend, ndev):
@@ -94,6 +221,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1: nccl (= RCCL over xGMI, the real path) or gloo (rehearsal of the "
                          "multi-rank plumbing on a box with fewer GPUs than ranks; ranks then share devices)")
+    ap.add_argument("--cfg5-scans", type=int, default=22, help="--workload cfg5: scans in the evaluation set (DTU test list: 22)")
+    ap.add_argument("--cfg5-images", type=int, default=49, help="--workload cfg5: images = reference views per scan (DTU: 49)")
+    ap.add_argument("--gather-batch", type=int, default=8, help="--workload cfg5: views per asynchronous gather to rank 0")
     ap.add_argument("--fusion-torch-baseline", action="store_true",
                     help="also time the reference's fusion op sequence on the GPU (element-wise 3x3 algebra instead of the 19 M-batch "
                          "GEMM that faulted in round 1); opt-in, never part of the default run")
@@ -126,6 +256,12 @@ def main():
             dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
         else:
             dist.init_process_group(backend="gloo")
+
+    if args.workload == "cfg5":
+        run_cfg5(args, torch, dist, rank, world, dev)
+        if distributed:
+            dist.destroy_process_group()
+        return
 
     from common import build_model
     from effi_mvs_plus_amd import _lib, ops, shard, synth
@@ -199,13 +335,17 @@ def main():
         ops.set_profile(None)
         ops.set_branches(br0)
         disc = prof.summary()
-        key = args.profile_key or max(disc, key=lambda k: disc[k]["ms"])
+        fam_ms = {}
+        for k_, v_ in disc.items():
+            fam_ms[family_of(k_)] = fam_ms.get(family_of(k_), 0.0) + v_["ms"]
+        key = args.profile_key or max(fam_ms, key=lambda k: fam_ms[k])      # the kernel TEMPLATE with the largest share of a view
+        fam_keys = sorted(k_ for k_ in disc if family_of(k_) == key or k_ == key)
         step(1)                                   # last warm-up step, no instrumentation
 
         # ---- timed region: exactly K steps + the final gather ---------------------------------------
         # eager launches: the dominant kernel's launches are bracketed with HIP events inside the timed region;
         # graph replay has no per-kernel events, there the same K steps are repeated eagerly right after it
-        prof = ops.KernelProfile(keys=[key])
+        prof = ops.KernelProfile(keys=fam_keys)
         if graphed is None:
             ops.set_profile(prof)
         finals, confs = [], []
@@ -316,7 +456,8 @@ def main():
         tmax = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    ksum = prof.summary()[key]
+    kinst = prof.summary()                        # per instantiation (profile key) of the bracketed kernel template
+    ksum = {f_: sum(v_[f_] for v_ in kinst.values()) for f_ in ("launches", "ms", "flops", "bytes")}
 
     result = None
     bf16_outputs = None
@@ -326,25 +467,44 @@ def main():
         flops_per_launch = ksum["flops"] / ksum["launches"]
         bytes_per_launch = ksum["bytes"] / ksum["launches"]
         intensity = flops_per_launch / max(bytes_per_launch, 1.0)
-        # split-precision kernels: three bf16 MFMAs per fp32-equivalent product
-        split_keys = ("conv2d_k3x3", "conv2d_k3k1", "conv3d_x3", "conv3d_roll", "deconv3d_x3")
-        mfma_peak = PEAK_BF16_MFMA_TFLOPS / 3.0 if key.startswith(split_keys) else PEAK_FP32_MFMA_TFLOPS
+        # split-precision kernels: three bf16 MFMAs per fp32-equivalent product (plain bf16 operands: one)
+        split_keys = ("conv2d_k3", "conv3d_x3", "conv3d_roll", "deconv3d_x3")
+        per_product = {"split": 3.0, "bf16": 1.0}.get(precision)
+        mfma_peak = PEAK_BF16_MFMA_TFLOPS / per_product if (per_product and key.startswith(split_keys)) else PEAK_FP32_MFMA_TFLOPS
+        tflops = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        gbps = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         if key.startswith(("conv", "deconv")) and intensity > mfma_peak * 1e12 / (PEAK_HBM_GBPS * 1e9):
-            roof = {"bound": "mfma", "achieved": flops_per_launch / (avg_ms * 1e-3) / 1e12, "peak": mfma_peak,
-                    "unit": "TFLOP/s"}
+            roof = {"bound": "mfma", "achieved": tflops, "peak": mfma_peak, "unit": "TFLOP/s"}
         else:
-            roof = {"bound": "hbm", "achieved": bytes_per_launch / (avg_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBPS, "unit": "GB/s"}
+            roof = {"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s"}
         roof["frac"] = roof["achieved"] / roof["peak"]
-        # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE), collected offline in separate
-        # rocprofv3 --pmc passes of this same command and summarised by tools/pmc_traffic.py (see profiles/)
+        # both roofs of the bracketed kernel, whichever binds by intensity: FLOP-based against the matrix peak of its arithmetic, byte-based
+        # against HBM (algorithmic FLOPs / bytes of all its launches in a view / their summed duration)
+        roof["frac_mfma"] = tflops / mfma_peak
+        roof["frac_hbm"] = gbps / PEAK_HBM_GBPS
+        roof["achieved_tflops"], roof["achieved_gbps"], roof["mfma_peak_tflops"] = tflops, gbps, mfma_peak
+        roof["intensity_flop_per_byte"] = intensity
+        roof["instances"] = {k_: {"launches": v_["launches"], "avg_launch_us": v_["ms"] / v_["launches"] * 1e3,
+                                  "tflops": v_["flops"] / (v_["ms"] * 1e-3) / 1e12, "gbps": v_["bytes"] / (v_["ms"] * 1e-3) / 1e9}
+                             for k_, v_ in sorted(kinst.items(), key=lambda kv: -kv[1]["ms"]) if v_["launches"]}
+        # HBM bytes from the PMC counters (FETCH_SIZE / WRITE_SIZE), collected offline in separate rocprofv3 --pmc passes of this
+        # same command and summarised by tools/pmc_traffic.py (profiles/pmc_traffic_<workload>.json): per launch of the bracketed
+        # kernel (launch-weighted over its instantiations), and for the whole view against the path's algorithmic bytes
         roof["traffic"] = None
         tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.workload}.json")
+        pmc = None
         if os.path.exists(tpath):
             with open(tpath) as f:
-                tr = json.load(f).get(key)
-            if tr:
-                roof["traffic"] = tr["fetch_bytes"] + tr["write_bytes"]
-                roof["traffic_detail"] = tr
+                pmc = json.load(f)
+            tb = tl_ = 0.0
+            for k_, v_ in kinst.items():
+                tr = pmc.get(k_)
+                if tr and v_["launches"]:
+                    tb += (tr["fetch_bytes"] + tr["write_bytes"]) * v_["launches"]
+                    tl_ += v_["launches"]
+            if tl_:
+                roof["traffic"] = tb / tl_
+                roof["traffic_detail"] = {k_: pmc[k_] for k_ in kinst if k_ in pmc}
         roof["kernel"] = key
         roof["events"] = ("HIP events around the kernel's launches inside the timed region" if graphed is None else
                           "HIP events around the kernel's launches in the same K steps enqueued eagerly on one stream right after the "
@@ -366,7 +526,24 @@ def main():
         roof["algorithmic_flops_per_launch"] = flops_per_launch
         roof["algorithmic_bytes_per_launch"] = bytes_per_launch
         total_ms = sum(v["ms"] for v in disc.values())
-        roof["share_of_kernel_time"] = disc[key]["ms"] / max(total_ms, 1e-9)
+        roof["share_of_kernel_time"] = fam_ms.get(key, disc.get(key, {"ms": 0.0})["ms"] if key in disc else 0.0) / max(total_ms, 1e-9)
+        # the whole path of one view: algorithmic FLOPs and bytes over the single-stream time of a view
+        p_fl, p_by = path_work(H, W, N, nd)
+        ss_ms = (single_stream or {}).get("ms_per_view") or dt / args.steps * 1e3
+        path_peak = PEAK_BF16_MFMA_TFLOPS / per_product if per_product else PEAK_FP32_MFMA_TFLOPS
+        roof["path"] = {"flops": p_fl, "bytes": p_by, "ms_single_stream": ss_ms,
+                        "tflops": p_fl / (ss_ms * 1e-3) / 1e12, "gbps": p_by / (ss_ms * 1e-3) / 1e9,
+                        "frac_mfma": p_fl / (ss_ms * 1e-3) / 1e12 / path_peak, "frac_hbm": p_by / (ss_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                        "mfma_peak_tflops": path_peak,
+                        "note": "algorithmic work of one reference view (SURVEY.md 8(d)) / time of one view, one view after the other"}
+        roof["traffic_per_view"] = None
+        if pmc and pmc.get("_meta", {}).get("views"):
+            tv = sum((v_["fetch_bytes"] + v_["write_bytes"]) * v_["launches_profiled"] for k_, v_ in pmc.items() if k_ != "_meta")
+            tv /= pmc["_meta"]["views"]
+            roof["traffic_per_view"] = {"bytes": tv, "ratio_to_algorithmic": tv / p_by,
+                                        "note": "sum over ALL kernels of a view of (FETCH_SIZE x calibration + WRITE_SIZE) x launches / views "
+                                                "(tools/pmc_traffic.sh); the excess over the path's algorithmic bytes is what the layer-by-layer "
+                                                "update block writes and reads back"}
         result = {
             "metric": "ref-views/sec (cost-volume hot path: warp + cost volume + 3-D regularisation + cascaded GRU refinement)",
             "value": views / dt, "unit": "views/s", "n_gpus": (dist.get_world_size() if distributed else 1),       # as the process group reports it
@@ -383,6 +560,10 @@ def main():
                        "parallelism": f"view-sharded x{world}, {'RCCL' if args.backend == 'nccl' else 'gloo (rehearsal)'} gather of "
                                       f"depth+confidence to rank 0 inside the timed region" if world > 1 else "single GPU"},
             "in_flight": (max(1, args.in_flight) if graphed is not None else 1),
+            # one view after the other (a view's latency) next to the headline's views in flight; strict-fp32 figure filled in below
+            "value_single_stream": (single_stream or {}).get("value"),
+            "ms_per_view_single_stream": (single_stream or {}).get("ms_per_view"),
+            "value_fp32": None,
             **({"single_stream": single_stream} if single_stream is not None else {}),
             "ms_per_cost_volume_stage": stage_ms,
             "ms_per_cost_volume_stage_note": "sum of the stage's kernel durations (per-launch HIP events, eager single-stream passes) = its "
@@ -478,6 +659,8 @@ def main():
             finally:
                 ops.set_precision(precision)
             torch.cuda.empty_cache()
+        if other == "fp32" and other_graph and "value" in other_graph:
+            result["value_fp32"] = other_graph["value"]           # exact fp32 products everywhere, one view after the other (graph replay)
         result["other_precision"] = {"mode": other, "dtype": DTYPE[other],
                                      "graph_replay": other_graph,        # one view after the other: like-for-like with 'single_stream' (or the headline when --in-flight 1)
                                      "eager": {"value": args.steps / dt_other, "unit": "views/s", "ms_per_step": dt_other / args.steps * 1e3},

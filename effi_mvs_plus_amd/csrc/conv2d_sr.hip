@@ -14,7 +14,10 @@ int fill_sr(Conv2dArgs& a, const void* const* srcs, const int* src_channels, int
             int cout, int h, int w, int hp, int wp) {
     if (!srcs || !src_channels || n_src < 1 || n_src > EFFI_MAX_SRC || !wpack_bf16 || !bias) return EFFI_ERR_BADARG;
     if (cout < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
-    if (hp < ((h + 15) & ~15) + 2 || wp < ((w + 63) & ~63) + 2) return EFFI_ERR_BADARG;       // border + tile overhang (effi_sr_geometry)
+    // border + overhang of the widest tile the launch rule can pick for this map (effi_sr_geometry): 4 x 64 tiles only from 512 columns
+    // on (or when option wide_tiles forces them), 16-column tiles otherwise
+    const bool wide_possible = w >= 512 || effi_option(EFFI_OPT_WIDE_TILES) == 1;
+    if (hp < ((h + 15) & ~15) + 2 || wp < (wide_possible ? ((w + 63) & ~63) : ((w + 15) & ~15)) + 2) return EFFI_ERR_BADARG;
     if ((long)hp * wp * 4 >= (1L << 31)) return EFFI_ERR_UNSUPPORTED;                          // 32-bit unit offsets inside a chunk
     a.cin = 0;
     for (int i = 0; i < EFFI_MAX_SRC; ++i) {

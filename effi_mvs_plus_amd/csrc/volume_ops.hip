@@ -903,7 +903,9 @@ __global__ __launch_bounds__(TPB) void split_tanh_relu_stages_sr_kernel(SplitSta
 extern "C" int effi_sr_geometry(int h, int w, int* hp, int* wp) {
     if (h < 1 || w < 1 || !hp || !wp) return EFFI_ERR_BADARG;
     *hp = ((h + 15) & ~15) + 2;            // one zero row above, rows down to the bottom of the last 16-row tile + 1 below
-    *wp = ((w + 63) & ~63) + 2;            // one zero column left, columns up to the right edge of the last 64-column tile + 1
+    // one zero column left, columns up to the right edge of the last tile + 1: the 4 x 64 tiles are only used from 512 columns on
+    // (conv2d_x3.hpp: launch_bf16x3), below that tiles are 16 columns wide
+    *wp = (w >= 512 ? ((w + 63) & ~63) : ((w + 15) & ~15)) + 2;
     return EFFI_OK;
 }
 

@@ -1005,7 +1005,7 @@ _SR_MAX_PX = int(os.environ.get("EFFI_MVS_SR_MAX_PX", str(1 << 40)))
 
 def sr_geometry(h, w):
     """(hp, wp) of an SR plane for an h x w map: effi_sr_geometry."""
-    return ((h + 15) // 16) * 16 + 2, ((w + 63) // 64) * 64 + 2
+    return ((h + 15) // 16) * 16 + 2, (((w + 63) // 64) * 64 if w >= 512 else ((w + 15) // 16) * 16) + 2
 
 
 class SRMap:

@@ -594,7 +594,7 @@ long effi_option_unset(void);
  * instructions, applied once by the producer instead of by every consumer).  Maps are caller-owned; the border is zeroed with
  * effi_sr_clear_border once per allocation (producers never write outside rows 1..h, columns 1..w).
  * ================================================================================================================ */
-/* plane size the kernels expect for an h x w map: hp = roundup(h, 16) + 2, wp = roundup(w, 64) + 2 */
+/* plane size the kernels expect for an h x w map: hp = roundup(h, 16) + 2, wp = roundup(w, w >= 512 ? 64 : 16) + 2 (larger is fine) */
 int effi_sr_geometry(int h, int w, int* hp, int* wp);
 /* zero the border of n_groups (<= 4) blocks of planes[g] consecutive planes of geometry (h, w, hp, wp)[g]: one launch */
 int effi_sr_clear_border(void* const* maps, const int* planes, const int* h, const int* w, const int* hp, const int* wp, int n_groups,

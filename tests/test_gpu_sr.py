@@ -61,7 +61,8 @@ def test_every_layer_of_a_gru_iteration_is_bitwise_the_planar_layer(model, split
     rnd = lambda c: torch.randn(c, h, w, generator=g).to(DEV)
     e = blk.encoder
     # geometry / conversion / border
-    assert ops.sr_geometry(h, w) == (((h + 15) // 16) * 16 + 2, ((w + 63) // 64) * 64 + 2)
+    assert ops.sr_geometry(h, w) == (((h + 15) // 16) * 16 + 2, ((w + 15) // 16) * 16 + 2)       # (w < 512: 16-column tiles only)
+    assert ops.sr_geometry(592, 800) == (594, 834)
     maps = ops.sr_alloc(6, hd, h, w, DEV, clear=False)
     for m in maps:
         m.t.fill_(7.0)                           # poison: the border clear and the producers must overwrite what they own

@@ -7,10 +7,12 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
+# PMC traffic first: bench.py's roofline.traffic / traffic_per_view read profiles/pmc_traffic_<workload>.json of THIS build
+tools/pmc_traffic.sh cfg3 > $O/${tag}_pmc_traffic_summary.txt 2>&1 || exit 1
+cp $O/pmc_traffic_cfg3.json $R/profiles/pmc_traffic_cfg3.json
+echo "pmc done"
 python bench.py > $O/${tag}_bench_cfg3.json 2> $O/${tag}_bench.err || exit 1
 echo "bench done"
-tools/pmc_traffic.sh cfg3 > $O/${tag}_pmc_traffic_summary.txt 2>&1 || exit 1
-echo "pmc done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_prof_graph -o p -- python3 $R/bench.py --in-flight 1 --no-cpu-baseline --torch-baseline-views 0 --no-whole-forward --no-other-precision --steps 10 > $O/${tag}_prof_graph.log 2>&1 || exit 1
 EFFI_MVS_BRANCHES=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_prof_serial -o p -- python3 $R/bench.py --launch eager --no-cpu-baseline --torch-baseline-views 0 --no-whole-forward --no-other-precision --steps 20 > $O/${tag}_bench_cfg3_eager_serial.json 2> $O/${tag}_prof_serial.log || exit 1

@@ -29,13 +29,19 @@ def key_of(name):
     m = re.match(r"conv2d_mfma_v2_kernel<(\d+), (\d+), (\d+), (\d+)", n)
     if m:
         return f"conv2d_k{m.group(1)}_nt{m.group(2)}_epi{m.group(4)}", 1.0          # 16-px tiles: ~96-byte row segments
-    m = re.match(r"conv2d_k3_bf16x3_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)", n)
+    m = re.match(r"conv2d_k3_bf16x3_kernel<(\d+), (\d+), (\d+), (true|false), (true|false)(?:, (true|false))?", n)
     if m:
-        wide_scale = {1: 1.0, 2: 1.25, 4: 1.5}.get(int(m.group(2)), 1.0) if m.group(5) == "true" else 1.0   # (16 MR + 8) px segments
-        return (f"conv2d_k3x3_nt{m.group(1)}_epi{m.group(3)}" if m.group(4) == "false" else f"conv3d_x3_nt{m.group(1)}"), wide_scale
-    m = re.match(r"conv2d_k3_bf16x3_pair_kernel<(\d+), (\d+), (true|false)", n)
+        wide, sr = m.group(5) == "true", m.group(6) == "true"
+        # fp32 maps: (16 MR + 8)-pixel row segments of 4 bytes; split-resident maps: (16 MR + 2) pixels of 16 bytes = 288-byte segments
+        # for the 16-wide tiles (calibrated x1.5), > 1 KB for the 4 x 64 tiles (long runs: x2)
+        scale = ((2.0 if wide else 1.5) if sr else ({1: 1.0, 2: 1.25, 4: 1.5}.get(int(m.group(2)), 1.0) if wide else 1.0))
+        epi = m.group(3)
+        name = {"6": f"conv2d_k3k1_nt{m.group(1)}", "8": f"conv2d_k3k1up_nt{m.group(1)}"}.get(epi, f"conv2d_k3x3_nt{m.group(1)}_epi{epi}")
+        return (name if m.group(4) == "false" else f"conv3d_x3_nt{m.group(1)}"), scale
+    m = re.match(r"conv2d_k3_bf16x3_pair_kernel<(\d+), (\d+), (true|false)(?:, (true|false))?", n)
     if m:
-        return f"conv2d_k3x3_pair_nt{m.group(1)}", ({1: 1.0, 2: 1.25, 4: 1.5}.get(int(m.group(2)), 1.0) if m.group(3) == "true" else 1.0)
+        wide, sr = m.group(3) == "true", m.group(4) == "true"
+        return f"conv2d_k3x3_pair_nt{m.group(1)}", ((2.0 if wide else 1.5) if sr else ({1: 1.0, 2: 1.25, 4: 1.5}.get(int(m.group(2)), 1.0) if wide else 1.0))
     if n.startswith("encoder_inputs_kernel"):
         return "encoder_inputs", 2.0                                                   # 4 B per lane, 256-byte runs of the cost volumes
     m = re.match(r"conv3d_roll(?:_rp)?_bf16x3_pair_kernel<(\d+)", n)
@@ -74,10 +80,13 @@ def key_of(name):
         return f"deconv3d_c{1 if m.group(1) == '1' else 8}_s{m.group(2)}", 1.0
     if n.startswith("warpcorr_views_win_kernel"):
         return "warpcorr_views_c32", 2.0                                               # window rows: long contiguous runs
+    m = re.match(r"warpcorr_dyn_hyp_kernel<(\d+)", n)                                  # a lane reads the C * 4 contiguous bytes of a tap
+    if m:
+        return f"warpcorr_dyn_c{m.group(1)}", {16: 1.0, 8: 0.5}[int(m.group(1))]
     m = re.match(r"warpcorr_(views|dyn)_kernel<(\d+)", n)
     if m:
         return f"warpcorr_{m.group(1)}_c{m.group(2)}", {32: 2.0, 16: 1.0, 8: 0.5}[int(m.group(2))]     # taps of 128 / 64 / 32 bytes
-    return None, 1.0
+    return "other:" + n.split("(")[0].split("<")[0][:48], 1.0          # everything else of a view (uncalibrated): the per-view total is complete
 
 
 # families whose dominant read shape is one of the calibrated ones (see the module docstring)
@@ -91,8 +100,6 @@ def collect(path):
     dur = collections.defaultdict(float)
     for r in csv.DictReader(open(path)):
         k, scale = key_of(r["Kernel_Name"])
-        if k is None:
-            continue
         per[k][r["Counter_Name"]] += float(r["Counter_Value"])
         per[k]["_scale"] = scale
         if r["Dispatch_Id"] not in disp[k]:
@@ -119,6 +126,12 @@ def main(fetch_csv, write_csv, out_json):
                   "l2_hit_rate": hit / (hit + miss) if hit + miss else None}
         print(f"{k:24s} n={n:3d} {us:8.1f} us  fetch {raw * scale / 1e6:8.1f} MB (raw {raw / 1e6:7.1f}) write {wr / 1e6:7.1f} MB"
               f"  L2 hit {100 * (hit / (hit + miss) if hit + miss else 0):5.1f}%  clk~{clk:4.2f} GHz")
+    # reference views in the profiled run: one stage1_hypotheses launch each
+    views = len(df.get("other:stage1_hypotheses_kernel", ()))
+    out["_meta"] = {"views": views, "note": "launches_profiled / views = launches per view; bench.py's roofline.traffic_per_view sums "
+                                            "(fetch_bytes + write_bytes) x launches over all kernels / views"}
+    tot = sum((v["fetch_bytes"] + v["write_bytes"]) * v["launches_profiled"] for k, v in out.items() if k != "_meta")
+    print(f"views profiled: {views}; traffic per view {tot / max(views, 1) / 1e6:.1f} MB")
     with open(out_json, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
 
