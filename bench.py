@@ -787,7 +787,29 @@ def main():
                 tq = time.perf_counter() - t0
             result["fusion_filter"]["cpu_reference_ops"] = {"ms_per_ref_view": tq * 1e3, "size": f"{wq}x{hq} (a quarter of the pixels)",
                                                             "cores": torch.get_num_threads(), "kind": "port"}
-        del dmaps
+        # DTU branch of the same row (test_dtu_dypcd.py:164-333; parity unpinned -- cv2 is absent): integer pixel grid, double-precision
+        # projection chain, cv2.remap's 1/32-pixel bilinear sampling, ten threshold pairs; the reference runs it with numpy on the host
+        ddm, dcams = synth.synth_depth_maps(H, W, Vf + 1, seed=4, noise_mm=0.03, pixel_center=0.0)
+        ddm, dcams = ddm.to(dev), dcams.to(dev)
+        with torch.no_grad():
+            dtu_ms = timed(lambda: ops.fusion_dtu_filter(ddm[0].contiguous(), ddm[1:].contiguous(), dcams[0].contiguous(), dcams[1:].contiguous(),
+                                                         fconf[:H // 2, :W // 2].contiguous(), 0.5), n=10)
+        result["fusion_filter_dtu"] = {"views_per_s": 1e3 / dtu_ms, "ms_per_ref_view": dtu_ms, "src_views": Vf,
+                                       "note": f"{W}x{H} depth maps, {Vf} source views, thresholds s=1..10 (dist_base 0.5, diff_base 0.25), one "
+                                               "fused kernel per reference view; PARITY UNPINNED (no cv2 here, no reference fixtures)"}
+        if not args.no_cpu_baseline:
+            from oracle import effi_dtu_filter_oracle as Od
+            hq, wq = H // 4, W // 4
+            dq, cq = synth.synth_depth_maps(hq, wq, Vf + 1, seed=4, noise_mm=0.03, pixel_center=0.0)
+            Kq = [cq[v, 1, :3, :3].numpy() for v in range(Vf + 1)]
+            Eq = [cq[v, 0].numpy() for v in range(Vf + 1)]
+            t0 = time.perf_counter()
+            Od.filter_depth_arrays(dq[0].numpy(), Kq[0], Eq[0], [dq[v].numpy() for v in range(1, Vf + 1)], Kq[1:], Eq[1:],
+                                   torch.rand(hq // 2, wq // 2).numpy())
+            tq = time.perf_counter() - t0
+            result["fusion_filter_dtu"]["cpu_reference_ops"] = {"ms_per_ref_view": tq * 1e3, "size": f"{wq}x{hq} (1/16 of the pixels)", "cores": 1,
+                                                                "kind": "port", "note": "numpy restatement of the reference's filter (its remap restated)"}
+        del dmaps, ddm
 
     # ---- secondary (rank 0, N = 1): scope row n4, the producer of the path's inputs -- decoded 8-bit images resident in HBM ->
     # [N,3,H,W] fp32 planes (/255, bilinear resize as scale_mvs_input does it, HWC -> CHW; datasets/general_eval.py:83-117,189)

@@ -220,24 +220,28 @@ __device__ __forceinline__ void split_octet(const f32x4 (&pa)[8], int px, bf16x8
 // columns per 16 outputs).  The LDS image is ONE array of 16-byte units [part][octet][pixel] (octet planes padded to a multiple of
 // 16 pixels: a ds_read_b128 lane group mixes two lane quarters, i.e. two octet planes, and stays conflict-free only if the planes
 // are congruent mod 16 slots), filled by unit u = tid + 256 j; units beyond the image (the last pass) land in its padding.
-template <int NT, int MR, int EPI, bool ZB, bool WIDE, bool SR = false>
+// NW: waves per workgroup (4, or 8 for SR kernels: twice the rows behind ONE copy of the weight fragments -- at the same LDS budget
+// per CU six waves per SIMD instead of four, and half the L2 -> LDS weight traffic).
+template <int NT, int MR, int EPI, bool ZB, bool WIDE, bool SR = false, int NW = 4>
 __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int tiles_x, int ntiles, int bid, int nbid, int bidy) {
-    constexpr int TR = WIDE ? 4 : 4 * MR, TW = WIDE ? 16 * MR : 16;
+    constexpr int NTHR = NW * 64;
+    static_assert(NW == 4 || (SR && NW == 8), "eight waves: split-resident kernels only");
+    constexpr int TR = WIDE ? NW : NW * MR, TW = WIDE ? 16 * MR : 16;
     constexpr int AR = TR + 2, AW = SR ? TW + 2 : TW + 8, AQ = AW / 4, XOFF = SR ? 0 : 3, XLEFT = 4, CCH = 16, NKS = 5;
     constexpr int MROW = WIDE ? 0 : AW * 8, MCOL = WIDE ? 16 * 8 : 0;   // LDS element step between a wave's MR sub-tiles
     constexpr int APIX = AR * AW, NITEMS = (APIX / 4) * 2;             // staging work items: (pixel quad, octet)
     constexpr int APIXP = SR ? ((APIX + 15) & ~15) : APIX;             // pixels per octet plane of the LDS image
     constexpr int NPART = kHiOnly ? 1 : 2;
-    constexpr int NUA = SR ? (NPART * 2 * APIXP + 255) / 256 : 1;      // SR: staging passes of 256 16-byte units
+    constexpr int NUA = SR ? (NPART * 2 * APIXP + NTHR - 1) / NTHR : 1; // SR: staging passes of NTHR 16-byte units
     constexpr int NBF = NKS * NT * 2 * 64;                             // 16-byte units of B per chunk
-    constexpr int NB4 = (NBF + 255) / 256;
+    constexpr int NB4 = (NBF + NTHR - 1) / NTHR;
     static_assert(SR || NITEMS <= 256, "one staging item per thread");
     static_assert(!(SR && ZB), "split-resident maps are 2-D");
     static_assert(EPI != EFFI_EPI_HEAD && EPI != EFFI_EPI_ADD_UP2, "epilogue not instantiated for the split-precision kernel");
     static_assert((EPI != EFFI_EPI_K1 && EPI != EFFI_EPI_K1UP) || !ZB, "the fused 1x1 epilogue is 2-D only");
-    __shared__ __attribute__((aligned(16))) unsigned short lds_ah[SR ? NUA * 256 * 8 : APIX * CCH];
+    __shared__ __attribute__((aligned(16))) unsigned short lds_ah[SR ? NUA * NTHR * 8 : APIX * CCH];
     __shared__ __attribute__((aligned(16))) unsigned short lds_al[SR ? 8 : APIX * CCH];
-    __shared__ __attribute__((aligned(16))) unsigned short lds_b[NB4 * 256 * 8];
+    __shared__ __attribute__((aligned(16))) unsigned short lds_b[NB4 * NTHR * 8];
     const unsigned short* const lds_al_rd = SR ? lds_ah + 2 * APIXP * 8 : lds_al;      // SR: part 1 of the one image
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -270,7 +274,7 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
     if (SR) {
 #pragma unroll
         for (int j = 0; j < NUA; ++j) {
-            const int u = tid + j * 256;
+            const int u = tid + j * NTHR;
             const int part = u / (2 * APIXP), r_ = u - part * (2 * APIXP);
             const int oct = r_ / APIXP, p = r_ - oct * APIXP;
             const int row = p / AW, col = p - row * AW;
@@ -331,12 +335,12 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
         f32x4 tb[NB4];
 #pragma unroll
         for (int j = 0; j < NB4; ++j) {
-            const int u = min(tid + j * 256, NBF - 1);
+            const int u = min(tid + j * NTHR, NBF - 1);
             tb[j] = *reinterpret_cast<const f32x4*>(wbf + ((long)ch * NBF + u) * 8);
         }
         if constexpr (SR) {
 #pragma unroll
-            for (int j = 0; j < NUA; ++j) *reinterpret_cast<f32x4*>(&lds_ah[(tid + j * 256) * 8]) = pa[j];
+            for (int j = 0; j < NUA; ++j) *reinterpret_cast<f32x4*>(&lds_ah[(tid + j * NTHR) * 8]) = pa[j];
         } else if (stager) {
 #pragma unroll
             for (int px = 0; px < 4; ++px) {
@@ -347,7 +351,7 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
             }
         }
 #pragma unroll
-        for (int j = 0; j < NB4; ++j) *reinterpret_cast<f32x4*>(&lds_b[(tid + j * 256) * 8]) = tb[j];
+        for (int j = 0; j < NB4; ++j) *reinterpret_cast<f32x4*>(&lds_b[(tid + j * NTHR) * 8]) = tb[j];
     };
 
     // fragment addressing: lane (pixel li, quarter lk) owns item 4s + lk = (tap, octet) of K-step s
@@ -579,17 +583,17 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
     }
 }
 
-template <int NT, int MR, int EPI, bool ZB = false, bool WIDE = false, bool SR = false>
-__global__ __launch_bounds__(256) void conv2d_k3_bf16x3_kernel(const Conv2dArgs a, int tiles_x, int ntiles) {
-    conv2d_k3_bf16x3_tile<NT, MR, EPI, ZB, WIDE, SR>(a, tiles_x, ntiles, blockIdx.x, gridDim.x, blockIdx.y);
+template <int NT, int MR, int EPI, bool ZB = false, bool WIDE = false, bool SR = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void conv2d_k3_bf16x3_kernel(const Conv2dArgs a, int tiles_x, int ntiles) {
+    conv2d_k3_bf16x3_tile<NT, MR, EPI, ZB, WIDE, SR, NW>(a, tiles_x, ntiles, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
 // Two independent convolutions of the same shape (NT, h, w) in one launch: blockIdx.y picks the argument set.  Used for the
 // update block's convc2 / convd2 (models/update.py:87,91), which would otherwise be forked onto two streams.
-template <int NT, int MR, bool WIDE, bool SR = false>
-__global__ __launch_bounds__(256) void conv2d_k3_bf16x3_pair_kernel(const Conv2dArgs a0, const Conv2dArgs a1, int tiles_x, int ntiles) {
-    if (blockIdx.y == 0) conv2d_k3_bf16x3_tile<NT, MR, EFFI_EPI_PLAIN, false, WIDE, SR>(a0, tiles_x, ntiles, blockIdx.x, gridDim.x, 0);
-    else conv2d_k3_bf16x3_tile<NT, MR, EFFI_EPI_PLAIN, false, WIDE, SR>(a1, tiles_x, ntiles, blockIdx.x, gridDim.x, 0);
+template <int NT, int MR, bool WIDE, bool SR = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void conv2d_k3_bf16x3_pair_kernel(const Conv2dArgs a0, const Conv2dArgs a1, int tiles_x, int ntiles) {
+    if (blockIdx.y == 0) conv2d_k3_bf16x3_tile<NT, MR, EFFI_EPI_PLAIN, false, WIDE, SR, NW>(a0, tiles_x, ntiles, blockIdx.x, gridDim.x, 0);
+    else conv2d_k3_bf16x3_tile<NT, MR, EFFI_EPI_PLAIN, false, WIDE, SR, NW>(a1, tiles_x, ntiles, blockIdx.x, gridDim.x, 0);
 }
 
 // ---- split-bf16 3x3 convolution entry --------------------------------------------------------------------------
@@ -628,6 +632,16 @@ static int launch_bf16x3(const Conv2dArgs& a, hipStream_t st) {
         else hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 1, EPI, ZB, true, SR>), grid, dim3(256), 0, st, a, tiles_x, ntiles);
         return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
     }
+    if constexpr (SR) {
+        // eight waves per workgroup (option sr_waves = 8; A/B): the tile of 4-row waves' workgroup at half the rows per wave
+        if (effi_option(EFFI_OPT_SR_WAVES) == 8 && mr <= 2) {
+            const int tiles_x = (int)cols, ntiles = tiles_x * effi_cdiv(a.h, 8 * mr);
+            const dim3 grid(ntiles, 1);
+            if (mr == 2) hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 2, EPI, false, false, true, 8>), grid, dim3(512), 0, st, a, tiles_x, ntiles);
+            else hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 1, EPI, false, false, true, 8>), grid, dim3(512), 0, st, a, tiles_x, ntiles);
+            return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+        }
+    }
     const int tiles_x = (int)cols, ntiles = tiles_x * effi_cdiv(a.h, 4 * mr);
     const dim3 grid(ntiles, (unsigned)planes);
     if (mr == 4) hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 4, EPI, ZB, false, SR>), grid, dim3(256), 0, st, a, tiles_x, ntiles);
@@ -663,6 +677,15 @@ static int launch_bf16x3_pair(const Conv2dArgs& a0, const Conv2dArgs& a1, hipStr
         const int tiles_x = effi_cdiv(a0.w, 64), ntiles = tiles_x * effi_cdiv(a0.h, 4);
         hipLaunchKernelGGL((conv2d_k3_bf16x3_pair_kernel<NT, 4, true, SR>), dim3(ntiles, 2), dim3(256), 0, st, a0, a1, tiles_x, ntiles);
         return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+    }
+    if constexpr (SR) {
+        if (effi_option(EFFI_OPT_SR_WAVES) == 8 && mr <= 2) {
+            const int tiles_x = (int)cols, ntiles = tiles_x * effi_cdiv(a0.h, 8 * mr);
+            const dim3 grid(ntiles, 2);
+            if (mr == 2) hipLaunchKernelGGL((conv2d_k3_bf16x3_pair_kernel<NT, 2, false, true, 8>), grid, dim3(512), 0, st, a0, a1, tiles_x, ntiles);
+            else hipLaunchKernelGGL((conv2d_k3_bf16x3_pair_kernel<NT, 1, false, true, 8>), grid, dim3(512), 0, st, a0, a1, tiles_x, ntiles);
+            return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+        }
     }
     const int tiles_x = (int)cols, ntiles = tiles_x * effi_cdiv(a0.h, 4 * mr);
     const dim3 grid(ntiles, 2);

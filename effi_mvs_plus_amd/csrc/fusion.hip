@@ -192,7 +192,179 @@ __global__ __launch_bounds__(256) void fusion_dynamic_filter_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// DTU branch of row n3: reproject_with_depth + check_geometric_consistency + the array part of filter_depth of the reference's
+// test_dtu_dypcd.py:164-333 (the numpy / cv2 filter its DTU driver runs per scan on the host, in a multiprocessing pool), one thread
+// per reference pixel walking the source views.  Differences from the Tanks-and-Temples kernel above that matter for parity: pixel
+// coordinates are INTEGERS (no half-pixel offset), the projection chain is evaluated in DOUBLE (numpy promotes int64 grid x
+// float32 depth to float64) and rounded to float32 exactly where the reference calls .astype(np.float32), the source depth is
+// sampled with cv2.remap(INTER_LINEAR)'s arithmetic (coordinates rounded to 1/32 pixel, table weights, zero outside), and ten
+// (distance, depth-difference) threshold pairs i = s .. e-1 are counted.  PARITY UNPINNED: cv2 is not installed in the build image
+// and the reference holds no fixtures for this code; the checker is oracle/effi_dtu_filter_oracle.py (the numpy lines restated with
+// their dtypes, OpenCV's published remap algorithm restated).  Matrix inverses / products are formed once per view in double and
+// rounded to float32 (the reference: single-precision LAPACK / float32 matmul; ~1e-7 relative apart).
+// per view: ref: K[9] Kinv[9] E[16] Einv[16]; source s: K[9] Kinv[9] T_ref->src[16] = E_s . E_ref^-1, T_src->ref[16] = E_ref . E_s^-1
+__global__ void fusion_dtu_prepare_kernel(const float* __restrict__ ref_cam, const float* __restrict__ src_cams, int V,
+                                          float* __restrict__ mats) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v > V) return;
+    auto load = [](const float* cam, double* K, double* E) {
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) K[r * 3 + c] = (double)cam[16 + r * 4 + c];
+        for (int i = 0; i < 16; ++i) E[i] = (double)cam[i];
+    };
+    double K[9], Ki[9], E[16], Ei[16], Kr[9], Er[16], Eri[16];
+    load(ref_cam, Kr, Er);
+    fus_invert(Er, 4, Eri);
+    float* m = mats + (long)v * MAT_STRIDE;
+    if (v == 0) {
+        fus_invert(Kr, 3, Ki);
+        for (int i = 0; i < 9; ++i) { m[i] = (float)Kr[i]; m[9 + i] = (float)Ki[i]; }
+        for (int i = 0; i < 16; ++i) { m[18 + i] = (float)Er[i]; m[34 + i] = (float)Eri[i]; }
+        return;
+    }
+    load(src_cams + (long)(v - 1) * 32, K, E);
+    fus_invert(K, 3, Ki);
+    fus_invert(E, 4, Ei);
+    for (int i = 0; i < 9; ++i) { m[i] = (float)K[i]; m[9 + i] = (float)Ki[i]; }
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) {
+            double a = 0.0, b = 0.0;
+            for (int k = 0; k < 4; ++k) {
+                a += (double)(float)E[r * 4 + k] * (double)(float)Eri[k * 4 + c];       // operands as float32, as the reference holds them
+                b += (double)(float)Er[r * 4 + k] * (double)(float)Ei[k * 4 + c];
+            }
+            m[18 + r * 4 + c] = (float)a;
+            m[34 + r * 4 + c] = (float)b;
+        }
+}
+
+struct D3 { double x, y, z; };
+__device__ __forceinline__ D3 dmul3(const float* M, double x, double y, double z) {
+    return {(double)M[0] * x + (double)M[1] * y + (double)M[2] * z, (double)M[3] * x + (double)M[4] * y + (double)M[5] * z,
+            (double)M[6] * x + (double)M[7] * y + (double)M[8] * z};
+}
+__device__ __forceinline__ D3 dmul4_xyz(const float* M, D3 p) {          // rows 0..2 of M . [p; 1]
+    return {(double)M[0] * p.x + (double)M[1] * p.y + (double)M[2] * p.z + (double)M[3],
+            (double)M[4] * p.x + (double)M[5] * p.y + (double)M[6] * p.z + (double)M[7],
+            (double)M[8] * p.x + (double)M[9] * p.y + (double)M[10] * p.z + (double)M[11]};
+}
+
+// cv2.remap(src, map_x, map_y, INTER_LINEAR), BORDER_CONSTANT 0, one sample (OpenCV imgwarp.cpp: INTER_BITS = 5)
+__device__ __forceinline__ float cv_remap_linear(const float* __restrict__ img, int h, int w, float mx, float my) {
+    auto fix = [](float v) -> long {
+        double f = (double)v * 32.0;
+        if (!(f == f)) return -2147483648L;                    // NaN: cvRound gives INT_MIN
+        f = fmin(fmax(f, -2147483648.0), 2147483647.0);
+        return (long)rint(f);                                   // cvRound: round half to even
+    };
+    const long sx = fix(mx), sy = fix(my);
+    const int ax = (int)(sx & 31), ay = (int)(sy & 31);
+    const long x0 = min(max(sx >> 5, -32768L), 32767L), y0 = min(max(sy >> 5, -32768L), 32767L);      // saturate_cast<short>
+    const float tx = (float)ax * (1.0f / 32.0f), ty = (float)ay * (1.0f / 32.0f);
+    const float wx0 = 1.0f - tx, wy0 = 1.0f - ty;
+    auto at = [&](long yy, long xx) { return (yy >= 0 && yy < h && xx >= 0 && xx < w) ? img[yy * w + xx] : 0.0f; };
+    return at(y0, x0) * (wy0 * wx0) + at(y0, x0 + 1) * (wy0 * tx) + at(y0 + 1, x0) * (ty * wx0) + at(y0 + 1, x0 + 1) * (ty * tx);
+}
+
+constexpr int DTU_MAX_THR = 16;
+
+__global__ __launch_bounds__(256) void fusion_dtu_filter_kernel(
+    const float* __restrict__ ref_depth, const float* __restrict__ src_depths, int V, int h, int w, const float* __restrict__ mats,
+    const float* __restrict__ conf, float conf_thr, float conf_keep, int s_lo, int e_hi, float dist_base, float diff_base,
+    float* __restrict__ out_depth, unsigned char* __restrict__ out_photo, unsigned char* __restrict__ out_geo,
+    unsigned char* __restrict__ out_final, float* __restrict__ out_points) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const long hw = (long)h * w;
+    if (p >= hw) return;
+    const int y = p / w, x = p - y * w;
+    const double xd = (double)x, yd = (double)y;
+    const float* Mr = mats;
+    const float dref = ref_depth[p];
+    // reference 3-D point: K_ref^-1 . ([x y 1] * depth)                                                     (:172-173)
+    const D3 xyz_ref = dmul3(Mr + 9, xd * (double)dref, yd * (double)dref, (double)dref);
+    const int nthr = e_hi - s_lo;
+    float thr_diff[DTU_MAX_THR];
+    double thr_dist[DTU_MAX_THR];
+    int counts[DTU_MAX_THR];
+#pragma unroll
+    for (int k = 0; k < DTU_MAX_THR; ++k) {
+        const int i = s_lo + k;
+        counts[k] = 0;
+        thr_dist[k] = (double)i * (double)dist_base;                                                          // i * dist_base (:227)
+        thr_diff[k] = (float)(log(fmax((double)i, 1.05)) / log(10.0) * (double)diff_base);    // math.log(max(i, 1.05), 10) * diff_base; float32 comparison
+    }
+    float num = 0.0f;                          // sum(all_srcview_depth_ests): float32, in view order (:299)
+    int nlast = 0;
+    for (int sv = 0; sv < V; ++sv) {
+        const float* Ms = mats + (long)(sv + 1) * MAT_STRIDE;
+        const D3 xs = dmul4_xyz(Ms + 18, xyz_ref);                                                             // (:175-176)
+        const D3 kx = dmul3(Ms, xs.x, xs.y, xs.z);                                                             // (:178-179)
+        const double u = kx.x / kx.z, v = kx.y / kx.z;
+        const float samp = cv_remap_linear(src_depths + (long)sv * hw, h, w, (float)u, (float)v);              // (:182-184)
+        const D3 s3 = dmul3(Ms + 9, u * (double)samp, v * (double)samp, (double)samp);                         // (:190-191)
+        const D3 rp = dmul4_xyz(Ms + 34, s3);                                                                  // (:193-194)
+        const float depth_rep = (float)rp.z;                                                                   // (:196)
+        D3 kr = dmul3(Mr, rp.x, rp.y, rp.z);                                                                   // (:197)
+        if (kr.z == 0.0) kr.z += 0.00001;                                                                      // (:198)
+        const float xr = (float)(kr.x / kr.z), yr = (float)(kr.y / kr.z);                                      // (:199-201)
+        const double dxr = (double)xr - xd, dyr = (double)yr - yd;
+        const double dist = sqrt(dxr * dxr + dyr * dyr);                                                       // (:218) float32 - int64 -> float64
+        const float ddiff = fabsf(depth_rep - dref);                                                           // (:225)
+        bool last = false;
+#pragma unroll
+        for (int k = 0; k < DTU_MAX_THR; ++k) {
+            if (k < nthr) {
+                const bool m = (dist < thr_dist[k]) & (ddiff < thr_diff[k]);
+                counts[k] += m ? 1 : 0;
+                if (k == nthr - 1) last = m;
+            }
+        }
+        if (last) {                            // depth_reprojected[~mask] = 0 with mask = the LAST (loosest) pair (:229)
+            num = num + depth_rep;
+            nlast += 1;
+        }
+    }
+    double davg = (double)(num + dref) / (double)(nlast + 1);                                                  // (:299) float32 / int -> float64
+    const float c = conf ? conf[p] : 1.0f;
+    if (c > conf_keep) davg = (double)dref;                                                                    // (:300)
+    bool geo = nlast >= e_hi;                                                                                  // (:303) dy_range = e
+#pragma unroll
+    for (int k = 0; k < DTU_MAX_THR; ++k)
+        if (k < nthr) geo = geo | (counts[k] >= s_lo + k);                                                     // (:304-305)
+    const bool photo = c > conf_thr;                                                                           // (:261)
+    out_depth[p] = (float)davg;
+    if (out_photo) out_photo[p] = photo ? 1 : 0;
+    if (out_geo) out_geo[p] = geo ? 1 : 0;
+    if (out_final) out_final[p] = (photo & geo) ? 1 : 0;
+    if (out_points) {                                                                                          // (:327-330)
+        const D3 pc = dmul3(Mr + 9, xd * davg, yd * davg, davg);
+        const D3 pw = dmul4_xyz(Mr + 34, pc);
+        out_points[p] = (float)pw.x;
+        out_points[hw + p] = (float)pw.y;
+        out_points[2 * hw + p] = (float)pw.z;
+    }
+}
+
 }  // namespace
+
+extern "C" int effi_fusion_dtu_filter_f32(const float* ref_depth, const float* src_depths, const float* ref_cam, const float* src_cams,
+                                          int n_src, int h, int w, const float* confidence, float conf_threshold, float conf_keep,
+                                          int s, int e, float dist_base, float diff_base, float* mats_scratch, float* out_depth,
+                                          unsigned char* out_photo_mask, unsigned char* out_geo_mask, unsigned char* out_final_mask,
+                                          float* out_points, effi_stream_t stream) {
+    if (!ref_depth || !src_depths || !ref_cam || !src_cams || !mats_scratch || !out_depth) return EFFI_ERR_BADARG;
+    if (n_src < 1 || h < 2 || w < 2 || s < 1 || e <= s || dist_base <= 0.0f || diff_base <= 0.0f) return EFFI_ERR_BADARG;
+    if (n_src > FUS_MAX_VIEWS || e - s > DTU_MAX_THR) return EFFI_ERR_UNSUPPORTED;
+    hipStream_t st = effi_s(stream);
+    hipLaunchKernelGGL(fusion_dtu_prepare_kernel, dim3(1), dim3(64), 0, st, ref_cam, src_cams, n_src, mats_scratch);
+    EFFI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fusion_dtu_filter_kernel, dim3(effi_cdiv((long)h * w, 256)), dim3(256), 0, st, ref_depth, src_depths, n_src, h, w,
+                       mats_scratch, confidence, conf_threshold, conf_keep, s, e, dist_base, diff_base, out_depth, out_photo_mask,
+                       out_geo_mask, out_final_mask, out_points);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
 
 extern "C" int effi_fusion_dynamic_filter_f32(const float* ref_depth, const float* src_depths, const float* ref_cam,
                                               const float* src_cams, int n_src, int h, int w, const float* ref_conf, int conf_h,

@@ -99,7 +99,7 @@ _PY_OPTION_DEFAULTS = {"c1k7_mfma": 1, "k5s2_split": 1, "roll": 1, "conv3d_unali
                        "fpn_split_head": 1, "csp_pair": 1, "head_taps": 1, "enc_tail": 0}
 _PY_OPTS = {k: int(os.environ.get("EFFI_" + k.upper(), v)) for k, v in _PY_OPTION_DEFAULTS.items()}
 LIB_OPTIONS = ("warp_lds_kb", "dyn_form", "dyn_setup_exact", "dyn_xchg", "pixnet_mfma", "force_mr", "mr4_min", "mr4_nt2_max", "mr2_min",
-               "wide_tiles", "roll_mr", "roll_zt", "roll_rp", "deconv_mr")
+               "wide_tiles", "roll_mr", "roll_zt", "roll_rp", "deconv_mr", "sr_waves")
 
 
 def option(name):
@@ -652,6 +652,36 @@ def fusion_dynamic_filter(ref_depth, src_depths, ref_cam, src_cams, ref_conf=Non
                 float(dist_base), float(rel_diff_base), int(bool(relative)), _p(scratch), _p(out["depth"]), _p(out["geo_mask"]),
                 _p(out["prob_mask"]), _p(out["mask"]), _p(out["points"]), _p(out["reproj_xyd"]), _stream()),
           "effi_fusion_dynamic_filter_f32")
+    return out
+
+
+def fusion_dtu_filter(ref_depth, src_depths, ref_cam, src_cams, confidence=None, conf_threshold=0.5, conf_keep=0.75, s=1, e=11,
+                      dist_base=0.5, diff_base=0.25, want_points=True):
+    """Scope row n3, DTU branch (test_dtu_dypcd.py:164-333; PARITY UNPINNED, see the header): one reference view through the dynamic
+    geometric-consistency filter.  ref_depth [h,w]; src_depths [V,h,w]; ref_cam [2,4,4]; src_cams [V,2,4,4]; confidence [ch,cw] (any
+    size: resized to the depth size as cv2.resize does) or None -> dict(depth [h,w], photo_mask / geo_mask / mask [h,w] uint8,
+    points [3,h,w] or None)."""
+    for name, t_ in (("ref_depth", ref_depth), ("src_depths", src_depths), ("ref_cam", ref_cam), ("src_cams", src_cams)):
+        _t(t_, name)
+    V, h, w = src_depths.shape
+    dev = ref_depth.device
+    if tuple(ref_depth.shape) != (h, w) or tuple(ref_cam.shape) != (2, 4, 4) or tuple(src_cams.shape) != (V, 2, 4, 4):
+        raise ValueError("fusion_dtu_filter: ref_depth [h,w], src_depths [V,h,w], ref_cam [2,4,4], src_cams [V,2,4,4]")
+    conf = None
+    if confidence is not None:
+        _t(confidence, "confidence")
+        conf = confidence if tuple(confidence.shape) == (h, w) else resize_planar(confidence.reshape(1, *confidence.shape[-2:]).contiguous(), h, w)[0]
+    out = {"depth": torch.empty(h, w, device=dev, dtype=torch.float32),
+           "photo_mask": torch.empty(h, w, device=dev, dtype=torch.uint8),
+           "geo_mask": torch.empty(h, w, device=dev, dtype=torch.uint8),
+           "mask": torch.empty(h, w, device=dev, dtype=torch.uint8),
+           "points": torch.empty(3, h, w, device=dev, dtype=torch.float32) if want_points else None}
+    scratch = torch.empty(52 * (V + 1), device=dev, dtype=torch.float32)
+    work = lambda: {"flops": 0.0, "bytes": 4.0 * h * w * (1 + V + 1 + 1 + (3 if want_points else 0)) + 3.0 * h * w}
+    check(_call("fusion_dtu_filter", work, _lib.lib().effi_fusion_dtu_filter_f32, _p(ref_depth), _p(src_depths), _p(ref_cam), _p(src_cams),
+                V, h, w, _p(conf), float(conf_threshold), float(conf_keep), int(s), int(e), float(dist_base), float(diff_base), _p(scratch),
+                _p(out["depth"]), _p(out["photo_mask"]), _p(out["geo_mask"]), _p(out["mask"]), _p(out["points"]), _stream()),
+          "effi_fusion_dtu_filter_f32")
     return out
 
 

@@ -106,7 +106,7 @@ def randomize_state_dict(sd, seed=0):
     return out
 
 
-def synth_depth_maps(H, W, N, seed=0, noise_mm=0.4, outlier_frac=0.05):
+def synth_depth_maps(H, W, N, seed=0, noise_mm=0.4, outlier_frac=0.05, pixel_center=0.5):
     """Depth maps of ONE analytic scene (a tilted plane with a smooth bump field evaluated per view) for the ring of
     ``synth_cameras``: (depths [N,H,W] fp32, cams [N,2,4,4] fp32 at full resolution "stage3").  Used by the depth-fusion
     tests / bench: views agree up to ``noise_mm`` except in random blocks (``outlier_frac`` of the image) that are offset by
@@ -116,7 +116,10 @@ def synth_depth_maps(H, W, N, seed=0, noise_mm=0.4, outlier_frac=0.05):
     nrm = torch.tensor([0.08, -0.05, 1.0], dtype=torch.float64)
     nrm = nrm / nrm.norm()
     dpl = float(nrm[2]) * 680.0
-    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64) + 0.5, torch.arange(W, dtype=torch.float64) + 0.5, indexing="ij")
+    # pixel_center: where a pixel's ray passes -- 0.5 for the Tanks-and-Temples filter (misc/fusion.py adds 0.5), 0 for the DTU
+    # filter (test_dtu_dypcd.py:169-173 uses the integer grid)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float64) + pixel_center, torch.arange(W, dtype=torch.float64) + pixel_center,
+                            indexing="ij")
     pix = torch.stack([xs, ys, torch.ones_like(xs)], 0).reshape(3, -1)
     depths = []
     for v in range(N):

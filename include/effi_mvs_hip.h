@@ -572,6 +572,21 @@ int effi_conv3d_k3s1_roll_bf16x3_pair_f32_bf16(const float* const* srcs_a, const
 int effi_deconv3d_k3s2_bf16x3_f32_bf16(const float* in, int cin, const void* wpack_bf16, const float* bias, int cout,
                                   int D, int h, int w, int relu, const float* skip, float* out, effi_stream_t stream);
 
+/* ---- scope row n3, DTU branch: reproject_with_depth + check_geometric_consistency + the array part of filter_depth,
+ * test_dtu_dypcd.py:164-333 (the reference runs it with numpy / cv2 on the host, one scan per pool worker).  PARITY UNPINNED: cv2
+ * (cv2.remap, cv2.resize) is absent from the build image and the reference holds no fixtures; checked against
+ * oracle/effi_dtu_filter_oracle.py (numpy lines restated with their dtypes, OpenCV's published INTER_LINEAR remap restated).
+ * ref_depth [h][w], src_depths [n_src][h][w] (the SAME size: the reference filters full-resolution maps), cameras as
+ * effi_fusion_dynamic_filter_f32 ([2][4][4]: extrinsic, intrinsic in the top-left 3x3), confidence [h][w] ALREADY resized to the
+ * depth size (cv2.resize, :259 = effi_resize_linear_f32) or NULL (= 1 everywhere); conf_threshold = args.conf (:261),
+ * conf_keep = 0.75 (:300), s / e / dist_base / diff_base the module constants of :33-37 (1, 11, 0.5, 0.25).
+ * Outputs: out_depth = depth_est_averaged, masks (or NULL) as bytes, out_points (or NULL) [3][h][w] = world point of every pixel
+ * (the reference keeps those where the final mask is set).  mats_scratch: 52 * (n_src + 1) floats. */
+int effi_fusion_dtu_filter_f32(const float* ref_depth, const float* src_depths, const float* ref_cam, const float* src_cams, int n_src,
+                               int h, int w, const float* confidence, float conf_threshold, float conf_keep, int s, int e,
+                               float dist_base, float diff_base, float* mats_scratch, float* out_depth, unsigned char* out_photo_mask,
+                               unsigned char* out_geo_mask, unsigned char* out_final_mask, float* out_points, effi_stream_t stream);
+
 /* ---- tuning / A-B switches.  A table of named integers, initialised ONCE per process from the environment (variable EFFI_<NAME in
  * upper case>) and changed afterwards only through effi_set_option; no entry point reads the environment.  Names: warp_lds_kb
  * (stage-1 warp kernel: LDS window in KB; 0 = the window kernel on global loads, -1 = the direct-gather kernel), dyn_form (1 =

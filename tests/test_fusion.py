@@ -133,3 +133,107 @@ def test_hip_filter_edge_cases():
     with pytest.raises(EffiLibraryError):            # more than 16 source views
         dd, cc = synth.synth_depth_maps(16, 16, 18, seed=1)
         ops.fusion_dynamic_filter(t(dd[0], DEV), t(dd[1:], DEV), t(cc[0], DEV), t(cc[1:], DEV))
+
+
+# ---- DTU branch (test_dtu_dypcd.py:164-350): PARITY UNPINNED -- cv2 is absent and the reference holds no fixtures; the checker is a
+# restatement of the numpy lines (with their dtypes) and of OpenCV's published remap arithmetic (oracle/effi_dtu_filter_oracle.py) -----
+def _dtu_case(H, W, N, seed):
+    import numpy as np
+    d, cams = synth.synth_depth_maps(H, W, N, seed=seed, noise_mm=0.03, outlier_frac=0.08, pixel_center=0.0)
+    g = torch.Generator().manual_seed(seed + 7)
+    conf = torch.rand(H // 2, W // 2, generator=g)
+    K = [cams[v, 1, :3, :3].numpy().astype(np.float32) for v in range(N)]
+    E = [cams[v, 0].numpy().astype(np.float32) for v in range(N)]
+    return d, cams, conf, K, E
+
+
+def test_dtu_filter_parity_unpinned_oracle_self_checks():
+    """Properties the restated pieces must have whatever OpenCV's build does: remap at integer coordinates returns the pixel, at
+    k/32 fractions the table's linear blend, zero outside; identical cameras and depth maps reproject every pixel onto itself."""
+    import numpy as np
+    from oracle import effi_dtu_filter_oracle as D
+    rng = np.random.default_rng(0)
+    img = rng.random((7, 9), dtype=np.float32)
+    ys, xs = np.meshgrid(np.arange(7, dtype=np.float32), np.arange(9, dtype=np.float32), indexing="ij")
+    assert np.array_equal(D.cv_remap_linear(img, xs, ys), img)
+    half = D.cv_remap_linear(img, xs[:, :-1] + 0.5, ys[:, :-1])
+    assert np.allclose(half, 0.5 * img[:, :-1] + 0.5 * img[:, 1:], rtol=1e-6)
+    assert D.cv_remap_linear(img, np.full((1, 1), -3.0, np.float32), np.full((1, 1), 2.0, np.float32))[0, 0] == 0.0
+    assert np.isclose(D.cv_remap_linear(img, np.full((1, 1), 8.5, np.float32), np.full((1, 1), 0.0, np.float32))[0, 0], 0.5 * img[0, 8])   # half outside
+    # coordinates are quantised to 1/32 pixel: 0.51 samples like 0.5 (16/32), 0.52 like 17/32
+    q = D.cv_remap_linear(img, np.array([[0.51, 0.52]], np.float32), np.zeros((1, 2), np.float32))
+    assert np.isclose(q[0, 0], 0.5 * img[0, 0] + 0.5 * img[0, 1]) and np.isclose(q[0, 1], (15 / 32) * img[0, 0] + (17 / 32) * img[0, 1])
+    d, cams, conf, K, E = _dtu_case(48, 64, 3, seed=1)
+    dn = d[0].numpy()
+    dep, xr, yr, xs_, ys_ = D.reproject_with_depth(dn, K[0], E[0], dn, K[0], E[0])
+    gx, gy = np.meshgrid(np.arange(64), np.arange(48))
+    assert np.abs(xr - gx).max() < 1e-3 and np.abs(yr - gy).max() < 1e-3 and np.abs(dep - dn).max() < 1e-3
+    out = D.filter_depth_arrays(dn, K[0], E[0], [dn, dn], [K[0]] * 2, [E[0]] * 2, np.ones((24, 32), np.float32))
+    assert out["geo_mask"].all() and out["final_mask"].all() and np.allclose(out["depth_est_averaged"], dn)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,N,seed", [(96, 128, 5, 3), (75, 101, 3, 5), (128, 160, 11, 8)])
+def test_dtu_filter_parity_unpinned_kernel_vs_oracle(H, W, N, seed):
+    """effi_fusion_dtu_filter_f32 against the numpy restatement: continuous outputs to fp32 rounding, masks to an agreement fraction
+    (a pixel whose reprojection error sits within rounding of one of the ten thresholds may flip: the kernel inverts the camera
+    matrices in double, the reference in single precision)."""
+    import numpy as np
+    from effi_mvs_plus_amd import dtu_fusion
+    from oracle import effi_dtu_filter_oracle as D
+    d, cams, conf, K, E = _dtu_case(H, W, N, seed)
+    want = D.filter_depth_arrays(d[0].numpy(), K[0], E[0], [d[v].numpy() for v in range(1, N)], K[1:], E[1:], conf.numpy(), conf=0.5)
+    got = dtu_fusion.filter_view(t(d[0], DEV), K[0], E[0], t(d[1:], DEV), K[1:], E[1:], t(conf, DEV), conf=0.5)
+    for k in ("photo_mask", "geo_mask", "final_mask"):
+        agree = float((got[k].cpu().numpy() == want[k]).mean())
+        print(f"[dtu filter {H}x{W} N={N}] {k}: agreement {agree:.5f}, set fraction {want[k].mean():.3f}")
+        assert agree >= 0.998, (k, agree)
+    assert 0.05 < want["geo_mask"].mean() < 0.999, "the case must exercise both outcomes"
+    same = got["geo_mask"].cpu().numpy() == want["geo_mask"]
+    dd = np.abs(got["depth_est_averaged"].cpu().numpy() - want["depth_est_averaged"])
+    assert dd[same].max() <= 2e-3 and np.median(dd) <= 1e-4, (dd[same].max(), np.median(dd))          # mm, depths ~ 600 mm
+    pw = np.abs(got["xyz_world"].cpu().numpy() - want["xyz_world"])
+    assert pw[:, same].max() <= 5e-3
+
+
+@pytest.mark.gpu
+def test_dtu_filter_parity_unpinned_scan_directory_end_to_end(tmp_path):
+    """filter_depth with the reference's arguments on a synthetic scan directory in the reference's formats (pair.txt, *_cam.txt,
+    JPEG images, PFM depth / confidence maps): three mask PNGs per view and a binary PLY whose vertices are the masked pixels."""
+    import numpy as np
+    from PIL import Image
+    from effi_mvs_plus_amd import dtu_fusion
+    from effi_mvs_plus_amd.datasets.data_io import save_pfm
+    H, W, N = 64, 96, 4
+    d, cams, conf, K, E = _dtu_case(H, W, N, seed=2)
+    scan, pairs = tmp_path / "out" / "scan1", tmp_path / "data" / "scan1"
+    for sub in ("cams", "images", "depth_est", "confidence"):
+        (scan / sub).mkdir(parents=True, exist_ok=True)
+    pairs.mkdir(parents=True)
+    rng = np.random.default_rng(1)
+    with open(pairs / "pair.txt", "w") as f:
+        f.write(f"{N}\n")
+        for v in range(N):
+            srcs = [u for u in range(N) if u != v]
+            f.write(f"{v}\n{len(srcs)} " + " ".join(f"{u} {100.0 - u}" for u in srcs) + "\n")
+    for v in range(N):
+        with open(scan / "cams" / f"{v:08d}_cam.txt", "w") as f:
+            f.write("extrinsic\n" + "\n".join(" ".join(repr(float(x)) for x in row) for row in E[v]) + "\n\nintrinsic\n")
+            f.write("\n".join(" ".join(repr(float(x)) for x in row) for row in K[v]) + "\n\n425.0 2.5\n")
+        Image.fromarray(rng.integers(0, 256, (H, W, 3), dtype=np.uint8)).save(scan / "images" / f"{v:08d}.jpg")
+        save_pfm(str(scan / "depth_est" / f"{v:08d}.pfm"), d[v].numpy())
+        save_pfm(str(scan / "confidence" / f"{v:08d}.pfm"), torch.rand(H // 2, W // 2, generator=torch.Generator().manual_seed(v)).numpy())
+    ply = str(tmp_path / "out" / "mvsnet001_l3.ply")
+    dtu_fusion.filter_depth(str(pairs), str(scan), str(scan), ply, conf=0.3, device=DEV)
+    n_final = 0
+    for v in range(N):
+        for kind in ("photo", "geo", "final"):
+            m = np.array(Image.open(scan / "mask" / f"{v:08d}_{kind}.png"))
+            assert m.shape == (H, W) and set(np.unique(m)) <= {0, 255}
+        n_final += int((np.array(Image.open(scan / "mask" / f"{v:08d}_final.png")) > 0).sum())
+    raw = open(ply, "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    assert head.startswith(b"ply\nformat binary_little_endian 1.0\n") and f"element vertex {n_final}\n".encode() in head
+    assert len(body) == n_final * 15 and n_final > 0
+    xyz = np.frombuffer(body, dtype=[("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("r", "u1"), ("g", "u1"), ("b", "u1")])
+    assert np.isfinite(xyz["z"]).all()
