@@ -133,6 +133,56 @@ __device__ __forceinline__ float effi_depth_to_inv(float depth, float lo, float 
     return (s_ - min_disp) / den;
 }
 
+// the sampling position of a query in a Dp-long vector: first tap x0 and the two weights (the arithmetic depends on Dp, not on the volume)
+__device__ __forceinline__ void lookup1d_index(int Dp, float q_depth, float dmin, float dmax, int& x0, float& w0, float& w1) {
+    const float scaled = 1.0f / q_depth;                               // depth_to_disp, :156-164
+    const float min_disp = 1.0f / dmax, max_disp = 1.0f / dmin;
+    const float disp = (scaled - min_disp) / ((max_disp - min_disp) + 1e-10f);
+    const float dm1 = (float)(Dp - 1);
+    const float t = disp * dm1;                                        // :123
+    const float g = 2.0f * t / dm1 - 1.0f;                             // :107
+    float ix = ((g + 1.0f) / 2.0f) * dm1;                              // grid_sample, align_corners=True
+    ix = fminf(fmaxf(ix, -2.0f), dm1 + 2.0f);                          // neutral: both taps stay out of range
+    const float x0f = floorf(ix);
+    x0 = (int)x0f;
+    w1 = ix - x0f;
+    w0 = (x0f + 1.0f) - ix;
+}
+__device__ __forceinline__ float lookup1d_fetch(const float* __restrict__ vol, long dstride, int Dp, int x0, float w0, float w1) {
+    float r = 0.0f;
+    if (x0 >= 0 && x0 <= Dp - 1) r = vol[x0 * dstride] * w0;
+    if (x0 + 1 >= 0 && x0 + 1 <= Dp - 1) r = r + vol[(x0 + 1) * dstride] * w1;
+    return r;
+}
+// GetCost.forward for ONE pixel (models/Effi_MVS_plus.py:257-303 behind scale_inv_depth :138-148): NQ hypotheses at inverse depth
+// +-(NQ/2) intervals around the current estimate (module.py:554-570), looked up in the stage's two cached volumes -> cost[0..NQ) from
+// cur_vol, cost[NQ..2NQ) from reg_vol.  cur / reg point at the pixel's vector (element stride cds / rds).  Shared by
+// getcost_conv1x1_block (volume_ops.hip) and the generated-input convolution (conv2d_x3.hpp): one arithmetic, bitwise.
+template <int NQ>
+__device__ __forceinline__ void effi_getcost_pixel(float inv_or_depth, int input_is_depth, const float* __restrict__ disp_range, int n_range,
+                                                   float itv, const float* __restrict__ cur, long cds, int Dcur,
+                                                   const float* __restrict__ reg, long rds, int Dreg, float rlo, float rhi, float (&cost)[2 * NQ]) {
+    float depth = inv_or_depth;
+    if (!input_is_depth) depth = effi_inv_to_depth(depth, disp_range[0], disp_range[n_range - 1]);
+    const float dv = 1.0f / depth;
+    const float half = (float)(NQ / 2) * itv;
+    const float smin = fmaxf(dv - half, 1e-4f);
+    const float smax = fminf(fmaxf(dv + half, 1e-4f), 1e4f);
+    const float step = (smax - smin) / (float)(NQ - 1);
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        const float s = fmaxf(smin + (float)k * step, 1e-5f);
+        const float qd = 1.0f / s;
+        // both volumes of a stage are equally long on the path: one position per query serves both (bitwise the same values)
+        int x0;
+        float w0, w1;
+        lookup1d_index(Dcur, qd, rlo, rhi, x0, w0, w1);
+        cost[k] = lookup1d_fetch(cur, cds, Dcur, x0, w0, w1);
+        if (Dreg != Dcur) lookup1d_index(Dreg, qd, rlo, rhi, x0, w0, w1);
+        cost[NQ + k] = lookup1d_fetch(reg, rds, Dreg, x0, w0, w1);
+    }
+}
+
 // tile of the 7x7 kernels (64 x 4, i.e. one 256-byte row run per wave store instead of two 128-byte ones, measured the same: 25.2 us)
 #define EFFI_C1K7_TX 32
 #define EFFI_C1K7_TY 8

@@ -112,6 +112,43 @@ extern "C" int EFFI_FN(effi_conv2d_k3_bf16x3_pair_sr)(const void* const* srcs_a,
     }
 }
 
+// encoder_inputs + the pair above in ONE launch (models/update.py:86-91): relu(convc2(relu(convc1(GetCost(inv_depth))))) -> out_sr_c2,
+// relu(convd2(relu(convd1(inv_depth)))) -> out_sr_d2.  The 1x1 / 7x7 results are generated per tile inside the 3x3 kernel (EncGenArgs,
+// conv2d_x3.hpp) and never reach memory; arguments as effi_encoder_inputs_bf16x3_sr (volume_ops.hip) + the pair's weights.  Bitwise equal
+// to the two launches it replaces.
+extern "C" int EFFI_FN(effi_encoder_pair_gen_bf16x3_sr)(const float* inv_depth, const float* disp_range, int n_range, const float* interval,
+                                                        const float* cur_vol, long cds, long cps, int Dcur, const float* reg_vol, long rds,
+                                                        long rps, int Dreg, const float* dmin, const float* dmax, long range_ps, int nq,
+                                                        int h, int w, const float* weight_c1, const float* bias_c1, const float* weight_d1,
+                                                        const float* bias_d1, int hd, const void* wpack_c2, const float* bias_c2,
+                                                        void* out_sr_c2, const void* wpack_d2, const float* bias_d2, void* out_sr_d2,
+                                                        int cout, int hp, int wp, int act, effi_stream_t stream) {
+    if (!inv_depth || !interval || !cur_vol || !reg_vol || !dmin || !dmax || !weight_c1 || !bias_c1 || !weight_d1 || !bias_d1 || !disp_range ||
+        n_range < 2 || Dcur < 2 || Dreg < 2)
+        return EFFI_ERR_BADARG;
+    if (act < EFFI_ACT_NONE || act > EFFI_ACT_TANH || (cout & 15) || !out_sr_c2 || !out_sr_d2) return EFFI_ERR_BADARG;
+    if ((reinterpret_cast<uintptr_t>(out_sr_c2) | reinterpret_cast<uintptr_t>(out_sr_d2)) & 15) return EFFI_ERR_BADARG;
+    if (nq != 3 || (hd != 16 && hd != 32 && hd != 48)) return EFFI_ERR_UNSUPPORTED;
+    Conv2dArgs a0, a1;
+    const void* dummy[1] = {out_sr_c2};            // the source list only carries the channel count here: nothing is read through it
+    int rc = fill_sr(a0, dummy, &hd, 1, wpack_c2, bias_c2, cout, h, w, hp, wp);
+    if (rc != EFFI_OK) return rc;
+    rc = fill_sr(a1, dummy, &hd, 1, wpack_d2, bias_d2, cout, h, w, hp, wp);
+    if (rc != EFFI_OK) return rc;
+    a0.act = a1.act = act;
+    a0.out_sr = reinterpret_cast<unsigned short*>(out_sr_c2);
+    a1.out_sr = reinterpret_cast<unsigned short*>(out_sr_d2);
+    const EncGenArgs g{inv_depth, disp_range, n_range, interval, cur_vol, cds, cps, Dcur, reg_vol, rds, rps, Dreg, dmin, dmax, range_ps,
+                       weight_c1, bias_c1, weight_d1, bias_d1, hd};
+    hipStream_t st = effi_s(stream);
+    switch (cout / 16) {
+        case 1: return launch_bf16x3_encgen_pair<1>(a0, a1, g, st);
+        case 2: return launch_bf16x3_encgen_pair<2>(a0, a1, g, st);
+        case 3: return launch_bf16x3_encgen_pair<3>(a0, a1, g, st);
+        default: return EFFI_ERR_UNSUPPORTED;
+    }
+}
+
 extern "C" int EFFI_FN(effi_conv2d_k3_k1_bf16x3_sr)(const void* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16,
                                                     const float* bias, int cout1, int relu1, const float* extra, int c_extra,
                                                     const void* w2pack_bf16, const float* bias2, int cout2, int relu, int h, int w,

@@ -55,6 +55,22 @@ struct Conv2dArgs {
     unsigned short* out_sr;
 };
 
+// GENERATED inputs of the encoder's convc2 / convd2 (models/update.py:86-91): instead of reading relu(convc1(GetCost(inv_depth))) /
+// relu(convd1(inv_depth)) as maps that another launch wrote, the convolution's workgroup evaluates them for its own tile (+ halo)
+// straight into the LDS image -- from the inverse-depth map and the stage's two cached volumes (a few values per pixel).  The
+// arithmetic is that of getcost_conv1x1_block (volume_ops.hip) / effi_c1k7_relu_tile_x3 (common.hpp), operation for operation, so
+// the result is bitwise the one of encoder_inputs + pair launch; what disappears is one launch and 2 x hd channels written and read
+// back per GRU iteration.
+struct EncGenArgs {
+    const float* inv_depth; const float* disp_range; int n_range; const float* interval;
+    const float* cur_vol; long cds, cps; int Dcur;
+    const float* reg_vol; long rds, rps; int Dreg;
+    const float* dmin; const float* dmax; long range_ps;
+    const float* w_c1; const float* b_c1;          // convc1: [6][hd], [hd]
+    const float* w_d1; const float* b_d1;          // convd1 (7x7): [49][hd], [hd]
+    int hd;
+};
+
 __device__ __forceinline__ float apply_act(float v, int act) {
     switch (act) {
         case EFFI_ACT_RELU: return fmaxf(v, 0.0f);
@@ -222,9 +238,13 @@ __device__ __forceinline__ void split_octet(const f32x4 (&pa)[8], int px, bf16x8
 // are congruent mod 16 slots), filled by unit u = tid + 256 j; units beyond the image (the last pass) land in its padding.
 // NW: waves per workgroup (4, or 8 for SR kernels: twice the rows behind ONE copy of the weight fragments -- at the same LDS budget
 // per CU six waves per SIMD instead of four, and half the L2 -> LDS weight traffic).
-template <int NT, int MR, int EPI, bool ZB, bool WIDE, bool SR = false, int NW = 4>
-__device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int tiles_x, int ntiles, int bid, int nbid, int bidy) {
+// GEN (with SR): the A image is generated (EncGenArgs); gmode (workgroup-uniform) 0 = relu(convc1(GetCost(inv_depth))), 1 =
+// relu(convd1(inv_depth)) (7x7) -- ONE instantiation for both so that the two halves of the pair kernel share their LDS.
+template <int NT, int MR, int EPI, bool ZB, bool WIDE, bool SR = false, int NW = 4, bool GEN = false>
+__device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int tiles_x, int ntiles, int bid, int nbid, int bidy,
+                                                      const EncGenArgs* gp = nullptr, int gmode = 0) {
     constexpr int NTHR = NW * 64;
+    static_assert(!GEN || SR, "generated inputs use the split-resident LDS image");
     static_assert(NW == 4 || (SR && NW == 8), "eight waves: split-resident kernels only");
     constexpr int TR = WIDE ? NW : NW * MR, TW = WIDE ? 16 * MR : 16;
     constexpr int AR = TR + 2, AW = SR ? TW + 2 : TW + 8, AQ = AW / 4, XOFF = SR ? 0 : 3, XLEFT = 4, CCH = 16, NKS = 5;
@@ -243,6 +263,9 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
     __shared__ __attribute__((aligned(16))) unsigned short lds_al[SR ? 8 : APIX * CCH];
     __shared__ __attribute__((aligned(16))) unsigned short lds_b[NB4 * NTHR * 8];
     const unsigned short* const lds_al_rd = SR ? lds_ah + 2 * APIXP * 8 : lds_al;      // SR: part 1 of the one image
+    // gmode 1: the inverse-depth tile of the staged region grown by the 7x7 kernel's reach (+ one zero-weighted row; 8 columns read)
+    constexpr int IW7 = (AW + 7 + 1) & ~1, IH7 = AR + 7;
+    __shared__ float lds_inv[GEN ? IH7 * IW7 : 1];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -271,7 +294,7 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
     const unsigned short* wbf = reinterpret_cast<const unsigned short*>(a.wpack);
     // SR: where unit tid + 256 j of a chunk's image lies in the chunk's four planes of the map (16-byte units; constant per tile)
     int goff[NUA];
-    if (SR) {
+    if (SR && !GEN) {
 #pragma unroll
         for (int j = 0; j < NUA; ++j) {
             const int u = tid + j * NTHR;
@@ -283,7 +306,9 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
         }
     }
     auto prefetch = [&](int ch) {
-        if constexpr (SR) {
+        if constexpr (GEN) {
+            (void)ch;
+        } else if constexpr (SR) {
             // every source has a multiple of 16 channels (host): the chunk lies in one source, at its local chunk index
             const int cb = ch * CCH;
             const int c1 = cb - a.ch[0], c2 = c1 - a.ch[1];
@@ -328,6 +353,109 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
         }
         }
     };
+    // ---- generated A image (GEN): per-pixel set-up once per tile, one 16-channel chunk per call ----
+    constexpr int PPT = GEN ? (APIX + NTHR - 1) / NTHR : 1;          // gmode 0: staged pixels per thread
+    float gcost[PPT][6];
+    bool gin[PPT];
+    if (GEN && gmode == 0) {
+        const EncGenArgs& g = *gp;
+        const float itv = g.interval[0];
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int p = tid + i * NTHR;
+            const int row = p / AW, col = p - row * AW;
+            const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+            gin[i] = (p < APIX) & (gy >= 0) & (gy < h) & (gx >= 0) & (gx < w);
+            const long pix = gin[i] ? (long)gy * w + gx : 0;
+            effi_getcost_pixel<3>(g.inv_depth[pix], 0, g.disp_range, g.n_range, itv, g.cur_vol + pix * g.cps, g.cds, g.Dcur,
+                                  g.reg_vol + pix * g.rps, g.rds, g.Dreg, g.dmin[pix * g.range_ps], g.dmax[pix * g.range_ps], gcost[i]);
+        }
+    }
+    if (GEN && gmode != 0) {
+        const EncGenArgs& g = *gp;
+        for (int e = tid; e < IH7 * IW7; e += NTHR) {
+            const int yy = e / IW7, xx = e - yy * IW7;
+            const int gy = y0 - 1 - 3 + yy, gx = x0 - 1 - 3 + xx;
+            lds_inv[e] = (yy < IH7 - 1 && gy >= 0 && gy < h && gx >= 0 && gx < w) ? g.inv_depth[(long)gy * w + gx] : 0.0f;
+        }
+        __syncthreads();
+    }
+    auto generate = [&](int ch) {
+        if (GEN && gmode == 0) {
+            const EncGenArgs& g = *gp;
+            const int hd = g.hd;
+#pragma unroll
+            for (int i = 0; i < PPT; ++i) {
+                const int p = tid + i * NTHR;
+                if (p >= APIX) continue;
+#pragma unroll
+                for (int oct = 0; oct < 2; ++oct) {
+                    const int c0 = ch * CCH + oct * 8;
+                    float acc[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = g.b_c1[c0 + j];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc[j] = fmaf(gcost[i][k], g.w_c1[k * hd + c0 + j], acc[j]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = gin[i] ? fmaxf(acc[j], 0.0f) : 0.0f;        // outside the map: the 3x3's zero padding
+                    effi_bf16x8_t hi, lo;
+                    effi_split8(acc, hi, lo);
+                    *reinterpret_cast<effi_bf16x8_t*>(&lds_ah[((0 * 2 + oct) * APIXP + p) * 8]) = hi;
+                    if (!kHiOnly) *reinterpret_cast<effi_bf16x8_t*>(&lds_ah[((1 * 2 + oct) * APIXP + p) * 8]) = lo;
+                }
+            }
+        }
+        if (GEN && gmode != 0) {
+            const EncGenArgs& g = *gp;
+            const int hd = g.hd;
+            // weight fragments of this chunk's 16 channels: lane (cout j = li, quarter lk) holds W[16 ch + j][ky = 4 s + lk][kx = 0..7]
+            effi_bf16x8_t wh[2], wl[2];
+#pragma unroll
+            for (int s_ = 0; s_ < 2; ++s_) {
+                const int ky = 4 * s_ + lk;
+                float wv8[8];
+#pragma unroll
+                for (int kx = 0; kx < 8; ++kx) wv8[kx] = (ky < 7 && kx < 7) ? g.w_d1[(ky * 7 + kx) * hd + CCH * ch + li] : 0.0f;
+                effi_split8(wv8, wh[s_], wl[s_]);
+            }
+            float b4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b4[r] = g.b_d1[CCH * ch + 4 * lk + r];
+            constexpr int NSEG = (APIX + 15) / 16;                    // groups of 16 consecutive staged pixels (a group may wrap a row)
+            for (int seg = wv; seg < NSEG; seg += NW) {
+                const int pr = seg * 16 + li, p = min(pr, APIX - 1);
+                const int row = p / AW, col = p - row * AW;
+                const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+                const bool inside = (gy >= 0) & (gy < h) & (gx >= 0) & (gx < w);
+                f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int s_ = 0; s_ < 2; ++s_) {
+                    const float* rowp = lds_inv + (row + 4 * s_ + lk) * IW7 + col;
+                    float x8[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) x8[i] = rowp[i];
+                    effi_bf16x8_t ah, al;
+                    effi_split8(x8, ah, al);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s_], ah, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s_], ah, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s_], al, acc, 0, 0, 0);
+                }
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = inside ? fmaxf(acc[r] + b4[r], 0.0f) : 0.0f;
+                const bf16x4 h4 = __builtin_convertvector(v, bf16x4);
+                const bf16x4 l4 = __builtin_convertvector(v - __builtin_convertvector(h4, f32x4), bf16x4);
+                if (pr < APIX) {
+                    const int e = ((lk >> 1) * APIXP + p) * 8 + (lk & 1) * 4;      // octet lk >> 1 of the chunk, half lk & 1
+                    *reinterpret_cast<bf16x4*>(&lds_ah[e]) = h4;
+                    if (!kHiOnly) *reinterpret_cast<bf16x4*>(&lds_ah[2 * APIXP * 8 + e]) = l4;
+                }
+            }
+        }
+    };
+
     // A: split + transpose out of the prefetch registers.  B (pre-split by the host, L2-resident, identical for every
     // workgroup) is copied global -> LDS (all its loads are issued before the first use; the LDS image is padded to whole
     // 256-thread passes so the copy needs no predicate).
@@ -338,7 +466,9 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
             const int u = min(tid + j * NTHR, NBF - 1);
             tb[j] = *reinterpret_cast<const f32x4*>(wbf + ((long)ch * NBF + u) * 8);
         }
-        if constexpr (SR) {
+        if constexpr (GEN) {
+            generate(ch);
+        } else if constexpr (SR) {
 #pragma unroll
             for (int j = 0; j < NUA; ++j) *reinterpret_cast<f32x4*>(&lds_ah[(tid + j * NTHR) * 8]) = pa[j];
         } else if (stager) {
@@ -596,6 +726,17 @@ __global__ __launch_bounds__(NW * 64) void conv2d_k3_bf16x3_pair_kernel(const Co
     else conv2d_k3_bf16x3_tile<NT, MR, EFFI_EPI_PLAIN, false, WIDE, SR, NW>(a1, tiles_x, ntiles, blockIdx.x, gridDim.x, 0);
 }
 
+// convc2 | convd2 with GENERATED inputs (EncGenArgs): blockIdx.y = 0 -> relu(convc2(relu(convc1(GetCost(inv_depth))))),
+// 1 -> relu(convd2(relu(convd1(inv_depth)))); split-resident outputs.  Replaces encoder_inputs + the pair launch.
+template <int NT, int MR, bool WIDE>
+__global__ __launch_bounds__(256) void conv2d_k3_bf16x3_encgen_pair_kernel(const Conv2dArgs a0, const Conv2dArgs a1, const EncGenArgs g,
+                                                                           int tiles_x, int ntiles) {
+    // (the two halves stacked along blockIdx.y: interleaving lookup-bound and matrix-bound workgroups along x measured 24 % SLOWER
+    // at 592x800)
+    conv2d_k3_bf16x3_tile<NT, MR, EFFI_EPI_PLAIN, false, WIDE, true, 4, true>(blockIdx.y == 0 ? a0 : a1, tiles_x, ntiles, blockIdx.x, gridDim.x, 0, &g,
+                                                                             (int)blockIdx.y);
+}
+
 // ---- split-bf16 3x3 convolution entry --------------------------------------------------------------------------
 // Thresholds of the rows-per-wave choice below (workgroup counts); the environment overrides are for A/B runs of the rule
 // (with several views in flight the chip is filled by other views' kernels, which favours the larger tiles earlier).
@@ -692,6 +833,28 @@ static int launch_bf16x3_pair(const Conv2dArgs& a0, const Conv2dArgs& a1, hipStr
     if (mr == 4) hipLaunchKernelGGL((conv2d_k3_bf16x3_pair_kernel<NT, 4, false, SR>), grid, dim3(256), 0, st, a0, a1, tiles_x, ntiles);
     else if (mr == 2) hipLaunchKernelGGL((conv2d_k3_bf16x3_pair_kernel<NT, 2, false, SR>), grid, dim3(256), 0, st, a0, a1, tiles_x, ntiles);
     else hipLaunchKernelGGL((conv2d_k3_bf16x3_pair_kernel<NT, 1, false, SR>), grid, dim3(256), 0, st, a0, a1, tiles_x, ntiles);
+    return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+}
+
+// Generated-input pair (conv2d_k3_bf16x3_encgen_pair_kernel): the MR rule of launch_bf16x3_pair, 4 waves.
+template <int NT>
+static int launch_bf16x3_encgen_pair(const Conv2dArgs& a0, const Conv2dArgs& a1, const EncGenArgs& g, hipStream_t st) {
+    const long cols = effi_cdiv(a0.w, 16);
+    const long t4 = cols * effi_cdiv(a0.h, 16) * 2, t2 = cols * effi_cdiv(a0.h, 8) * 2;
+    int mr;
+    if (t4 >= effi_mr4_min() && !(NT == 2 && t4 >= effi_mr4_nt2_max())) mr = 4;
+    else if (t2 >= effi_mr2_min()) mr = 2;
+    else mr = 1;
+    const long force = effi_opt_or(EFFI_OPT_FORCE_MR, 0);
+    if (force) mr = (int)force;
+    // always 16-column tiles: the generated image pays per STAGED pixel (24 volume taps each), and a 4 x 64 tile stages 1.55 x its
+    // pixels against 1.27 x for 16 x 16 (592x800, hd 16: 55 us per launch with wide tiles, 47 us without; the loaded form gains 5 %
+    // from wide tiles)
+    const int tiles_x = (int)cols, ntiles = tiles_x * effi_cdiv(a0.h, 4 * mr);
+    const dim3 grid(ntiles, 2);
+    if (mr == 4) hipLaunchKernelGGL((conv2d_k3_bf16x3_encgen_pair_kernel<NT, 4, false>), grid, dim3(256), 0, st, a0, a1, g, tiles_x, ntiles);
+    else if (mr == 2) hipLaunchKernelGGL((conv2d_k3_bf16x3_encgen_pair_kernel<NT, 2, false>), grid, dim3(256), 0, st, a0, a1, g, tiles_x, ntiles);
+    else hipLaunchKernelGGL((conv2d_k3_bf16x3_encgen_pair_kernel<NT, 1, false>), grid, dim3(256), 0, st, a0, a1, g, tiles_x, ntiles);
     return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
 

@@ -296,27 +296,7 @@ __global__ __launch_bounds__(64) void softmax_regress_conf_reg_kernel(const floa
 // ------------------------------------------------------------------------------------------------
 // K8: 1-D lookup in a per-pixel vector (pro_bilinear_sampler, models/Effi_MVS_plus.py:102-134)
 // ------------------------------------------------------------------------------------------------
-// the sampling position of a query in a Dp-long vector: first tap x0 and the two weights (the arithmetic depends on Dp, not on the volume)
-__device__ __forceinline__ void lookup1d_index(int Dp, float q_depth, float dmin, float dmax, int& x0, float& w0, float& w1) {
-    const float scaled = 1.0f / q_depth;                               // depth_to_disp, :156-164
-    const float min_disp = 1.0f / dmax, max_disp = 1.0f / dmin;
-    const float disp = (scaled - min_disp) / ((max_disp - min_disp) + 1e-10f);
-    const float dm1 = (float)(Dp - 1);
-    const float t = disp * dm1;                                        // :123
-    const float g = 2.0f * t / dm1 - 1.0f;                             // :107
-    float ix = ((g + 1.0f) / 2.0f) * dm1;                              // grid_sample, align_corners=True
-    ix = fminf(fmaxf(ix, -2.0f), dm1 + 2.0f);                          // neutral: both taps stay out of range
-    const float x0f = floorf(ix);
-    x0 = (int)x0f;
-    w1 = ix - x0f;
-    w0 = (x0f + 1.0f) - ix;
-}
-__device__ __forceinline__ float lookup1d_fetch(const float* __restrict__ vol, long dstride, int Dp, int x0, float w0, float w1) {
-    float r = 0.0f;
-    if (x0 >= 0 && x0 <= Dp - 1) r = vol[x0 * dstride] * w0;
-    if (x0 + 1 >= 0 && x0 + 1 <= Dp - 1) r = r + vol[(x0 + 1) * dstride] * w1;
-    return r;
-}
+// (lookup1d_index / lookup1d_fetch / effi_getcost_pixel: common.hpp -- shared with the generated-input convolution of conv2d_sr.hip)
 __device__ __forceinline__ float lookup1d(const float* __restrict__ vol, long dstride, int Dp,
                                           float q_depth, float dmin, float dmax) {
     int x0;
@@ -417,28 +397,9 @@ __device__ __forceinline__ void getcost_conv1x1_block(const GetcostConvArgs& g, 
     const long cds = g.cds, cps = g.cps, rds = g.rds, rps_ = g.rps, range_ps = g.range_ps;
     const int p = bx * TPB + threadIdx.x;
     if (p >= hw) return;
-    const float itv = interval[0];
-    float depth = inv_depth[p];
-    if (!input_is_depth) depth = effi_inv_to_depth(depth, disp_range[0], disp_range[n_range - 1]);
-    const float dv = 1.0f / depth;
-    const float half = (float)(NQ / 2) * itv;
-    const float smin = fmaxf(dv - half, 1e-4f);
-    const float smax = fminf(fmaxf(dv + half, 1e-4f), 1e4f);
-    const float step = (smax - smin) / (float)(NQ - 1);
-    const float rlo = dmin[p * range_ps], rhi = dmax[p * range_ps];
     float cost[2 * NQ];
-#pragma unroll
-    for (int k = 0; k < NQ; ++k) {
-        const float s = fmaxf(smin + (float)k * step, 1e-5f);
-        const float qd = 1.0f / s;
-        // both volumes of a stage are equally long on the path: one position per query serves both (bitwise the same values)
-        int x0;
-        float w0, w1;
-        lookup1d_index(Dcur, qd, rlo, rhi, x0, w0, w1);
-        cost[k] = lookup1d_fetch(cur_vol + p * cps, cds, Dcur, x0, w0, w1);
-        if (Dreg != Dcur) lookup1d_index(Dreg, qd, rlo, rhi, x0, w0, w1);
-        cost[NQ + k] = lookup1d_fetch(reg_vol + p * rps_, rds, Dreg, x0, w0, w1);
-    }
+    effi_getcost_pixel<NQ>(inv_depth[p], input_is_depth, disp_range, n_range, interval[0], cur_vol + p * cps, cds, Dcur, reg_vol + p * rps_, rds,
+                           Dreg, dmin[p * range_ps], dmax[p * range_ps], cost);
     for (int c0 = 0; c0 < cout; c0 += 8) {                 // cout % 8 == 0 (checked by the caller)
         float acc[8];
 #pragma unroll

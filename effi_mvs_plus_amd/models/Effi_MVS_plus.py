@@ -228,7 +228,15 @@ class GetCost(nn.Module):
 
         lookup.conv1x1 = lookup_conv1x1 if CostNum in (2, 3, 4) else None
         lookup.encoder_inputs = lookup_encoder_inputs if CostNum == 3 else None
+        def lookup_encoder_pair_sr(inv_depth, wc1, bc1, wd1, bd1, hd, wc2, bc2, out_c2, wd2, bd2, out_d2):
+            """lookup_encoder_inputs_sr + the convc2 | convd2 pair in one launch (ops.encoder_pair_gen_sr)."""
+            h, w = inv_depth.shape[-2:]
+            n = h * w
+            return ops.encoder_pair_gen_sr(inv_depth, disp_range[b], interval, cur[b * n:(b + 1) * n], reg[b * n:(b + 1) * n],
+                                           lo, hi, CostNum, h, w, wc1, bc1, wd1, bd1, hd, wc2, bc2, out_c2, wd2, bd2, out_d2, hd)
+
         lookup.encoder_inputs_sr = lookup_encoder_inputs_sr if CostNum == 3 else None
+        lookup.encoder_pair_sr = lookup_encoder_pair_sr if CostNum == 3 else None
         return lookup
 
     @ops.on_tensor_device
@@ -433,7 +441,13 @@ class Effi_MVS_plus(nn.Module):
 
             lookup.conv1x1 = lookup_conv1x1 if self.CostNum in (2, 3, 4) else None
             lookup.encoder_inputs = lookup_encoder_inputs if self.CostNum == 3 else None
+            def lookup_encoder_pair_sr(inv_depth, wc1, bc1, wd1, bd1, hd, wc2, bc2, out_c2, wd2, bd2, out_d2, cur_c=cur_c, reg_c=reg_c,
+                                       lo_c=lo_c, hi_c=hi_c, itv=itv, h=h, w=w):
+                return ops.encoder_pair_gen_sr(inv_depth, disp_range, itv, cur_c, reg_c, lo_c, hi_c, self.CostNum, h, w,
+                                               wc1, bc1, wd1, bd1, hd, wc2, bc2, out_c2, wd2, bd2, out_d2, hd)
+
             lookup.encoder_inputs_sr = lookup_encoder_inputs_sr if self.CostNum == 3 else None
+            lookup.encoder_pair_sr = lookup_encoder_pair_sr if self.CostNum == 3 else None
             _, masks, invs, depths = self.update_block[s].run_fused(hidden, lookup, inv_cur, inp, self.seq_len[s],
                                                                      disp_range, fuse_upsample=not want_intermediates,
                                                                      sr_maps=None if sr_maps is None else sr_maps[s],

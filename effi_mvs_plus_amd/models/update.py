@@ -314,9 +314,13 @@ class BasicUpdateBlock(nn.Module):
         wh1, bh1 = _pack(dh._c1, dh.conv1)
         wh2, bh2 = dh._c2t.get([dh.conv2.weight], lambda: packing.pack_head_taps(dh.conv2.weight, hd))
         inv_list, mask_list, depth_list = [], [], []
+        gen_pair = ops.option("enc_gen") != 0 and getattr(lookup, "encoder_pair_sr", None) is not None
         for i in range(seq_len):
-            lookup.encoder_inputs_sr(inv_depth, wc1, bc1, w7, b7, hd, A, B)                        # cor1 -> A, dfm1 -> B
-            ops.conv2d_k3_pair_sr([A], wc2.wx, bc2, Cm, [B], wd2.wx, bd2, Dm, hd, act=ops.ACT_RELU)  # cor -> C, dfm -> D
+            if gen_pair:                       # cor1 / dfm1 generated inside the pair kernel: cor -> C, dfm -> D in one launch
+                lookup.encoder_pair_sr(inv_depth, wc1, bc1, w7, b7, hd, wc2.wx, bc2, Cm, wd2.wx, bd2, Dm)
+            else:
+                lookup.encoder_inputs_sr(inv_depth, wc1, bc1, w7, b7, hd, A, B)                        # cor1 -> A, dfm1 -> B
+                ops.conv2d_k3_pair_sr([A], wc2.wx, bc2, Cm, [B], wd2.wx, bd2, Dm, hd, act=ops.ACT_RELU)  # cor -> C, dfm -> D
             ops.conv2d_k3_k1_sr([Cm, Dm], wd.wx, bd, cmix, context, wca, bca, hd, relu=True, out_sr=A)   # x -> A (cor1 is dead)
             z, _ = ops.conv2d_k3_sr([Hm, A], wzr.wx, bzr, 2 * hd, epilogue=ops.EPI_GRU_ZR, aux0=net, out0=z_buf, out_sr=B)   # r*h -> B
             # the new state overwrites H in place (no launch reads H between the z / r convolution and here), and so does its fp32

@@ -96,7 +96,7 @@ def _x3(name):
 # forms) in the library's own table (include/effi_mvs_hip.h: effi_set_option).  Both are initialised ONCE from the environment
 # (EFFI_<NAME>) and changed afterwards through ``set_option`` -- nothing on a per-call path reads the environment.
 _PY_OPTION_DEFAULTS = {"c1k7_mfma": 1, "k5s2_split": 1, "roll": 1, "conv3d_unaligned_split": 1, "conv3d_s2_split": 1, "fpn_conv0_fused": 1,
-                       "fpn_split_head": 1, "csp_pair": 1, "head_taps": 1, "enc_tail": 0}
+                       "fpn_split_head": 1, "csp_pair": 1, "head_taps": 1, "enc_tail": 0, "enc_gen": 1}
 _PY_OPTS = {k: int(os.environ.get("EFFI_" + k.upper(), v)) for k, v in _PY_OPTION_DEFAULTS.items()}
 LIB_OPTIONS = ("warp_lds_kb", "dyn_form", "dyn_setup_exact", "dyn_xchg", "pixnet_mfma", "force_mr", "mr4_min", "mr4_nt2_max", "mr2_min",
                "wide_tiles", "roll_mr", "roll_zt", "roll_rp", "deconv_mr", "sr_waves")
@@ -1145,6 +1145,30 @@ def encoder_inputs_sr(x, disp_range, interval, cur_vol, reg_vol, dmin, dmax, nq,
                 _p(weight_c1), _p(bias_c1), _p(weight_d1), _p(bias_d1), cout, _p(out_c1.t), _p(out_d1.t), out_c1.hp, out_c1.wp,
                 _stream()), "effi_encoder_inputs_bf16x3_sr")
     return out_c1, out_d1
+
+
+def encoder_pair_gen_sr(x, disp_range, interval, cur_vol, reg_vol, dmin, dmax, nq, h, w, weight_c1, bias_c1, weight_d1, bias_d1, hd,
+                        wpack_c2, bias_c2, out_c2, wpack_d2, bias_d2, out_d2, cout, act=ACT_RELU):
+    """``encoder_inputs_sr`` + ``conv2d_k3_pair_sr`` in one launch (models/update.py:86-91): the 1x1 / 7x7 results are generated tile by
+    tile inside the 3x3 kernel.  -> (act(convc2(cor1)), act(convd2(dfm1))) as SR maps; bitwise equal to the two launches."""
+    _t(x, "inv_depth"), _t(interval, "interval"), _t(disp_range, "disp_range")
+    for t_ in (weight_c1, bias_c1, weight_d1, bias_d1):
+        _t(t_, "encoder weights")
+    g = _sr_srcs([out_c2, out_d2])
+    cur_vol, cds, cps, Dc = _vol_strides(cur_vol, h, w)
+    reg_vol, rds, rps, Dr = _vol_strides(reg_vol, h, w)
+    dmin_t, gps = _range_ptr(dmin, h, w)
+    dmax_t, gps2 = _range_ptr(dmax, h, w)
+    if gps != gps2:
+        raise ValueError("depth_min / depth_max must both be global or both per-pixel")
+    if (g.channels, g.h, g.w) != (cout, h, w) or tuple(x.shape[-2:]) != (h, w):
+        raise ValueError("encoder_pair_gen_sr: output maps must be [cout,h,w]")
+    work = lambda: {"flops": 2.0 * h * w * ((2 * nq + 49) * hd + 2 * 9 * hd * cout), "bytes": 4.0 * h * w * (2 * cout + 1 + Dc + Dr)}
+    check(_call(f"conv2d_k3x3_encgen_nt{(cout + 15) // 16}", work, _x3("effi_encoder_pair_gen_bf16x3_sr"), _p(x), _p(disp_range),
+                disp_range.numel(), _p(interval), _p(cur_vol), cds, cps, Dc, _p(reg_vol), rds, rps, Dr, _p(dmin_t), _p(dmax_t), gps, nq,
+                h, w, _p(weight_c1), _p(bias_c1), _p(weight_d1), _p(bias_d1), hd, _p(wpack_c2), _p(bias_c2), _p(out_c2.t), _p(wpack_d2),
+                _p(bias_d2), _p(out_d2.t), cout, g.hp, g.wp, act, _stream()), "effi_encoder_pair_gen_bf16x3_sr")
+    return out_c2, out_d2
 
 
 def _sr_srcs(srcs):

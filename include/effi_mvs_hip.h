@@ -628,6 +628,16 @@ int effi_encoder_inputs_bf16x3_sr(const float* inv_depth, const float* disp_rang
                                   int Dreg, const float* dmin, const float* dmax, long range_ps, int nq, int h, int w,
                                   const float* weight_c1, const float* bias_c1, const float* weight_d1, const float* bias_d1,
                                   int cout, void* sr_c1, void* sr_d1, int hp, int wp, effi_stream_t stream);
+/* effi_encoder_inputs_bf16x3_sr + effi_conv2d_k3_bf16x3_pair_sr in ONE launch (models/update.py:86-91): out_sr_c2 =
+ * act(convc2(relu(convc1(GetCost(inv_depth))))), out_sr_d2 = act(convd2(relu(convd1(inv_depth)))).  The 1x1 / 7x7 results are generated
+ * tile by tile inside the 3x3 kernel and never reach memory; bitwise equal to the two launches.  nq == 3, hd in {16, 32, 48},
+ * cout in {16, 32, 48}; weight_* as for effi_encoder_inputs_bf16x3_sr, wpack_* / bias_* as for the pair. */
+int effi_encoder_pair_gen_bf16x3_sr(const float* inv_depth, const float* disp_range, int n_range, const float* interval,
+                                    const float* cur_vol, long cds, long cps, int Dcur, const float* reg_vol, long rds, long rps,
+                                    int Dreg, const float* dmin, const float* dmax, long range_ps, int nq, int h, int w,
+                                    const float* weight_c1, const float* bias_c1, const float* weight_d1, const float* bias_d1, int hd,
+                                    const void* wpack_c2, const float* bias_c2, void* out_sr_c2, const void* wpack_d2,
+                                    const float* bias_d2, void* out_sr_d2, int cout, int hp, int wp, int act, effi_stream_t stream);
 /* effi_conv2d_k3_bf16x3_f32 on SR maps (models/update.py:36-38,43-48,75,77): srcs = SR maps of src_channels[i] channels each
  * (multiples of 16), cout % 16 == 0.  EFFI_EPI_PLAIN: out_sr = act(conv) (out0, if given, the same values as fp32 [cout][h][w]);
  * EFFI_EPI_GRU_ZR: out0 = z (fp32 [cout/2][h][w]), out_sr = r * h, aux0 = h (fp32); EFFI_EPI_GRU_Q: out0 AND out_sr =
@@ -651,7 +661,7 @@ int effi_conv2d_k3_k1_up2x_bf16x3_sr(const void* const* srcs, const int* src_cha
                                      const float* bias, int cout1, const void* w2pack_bf16, const float* bias2, const float* inv_depth,
                                      const float* disp_range, int n_range, int h, int w, int hp, int wp, float* out_depth,
                                      float* out_depth_inv, effi_stream_t stream);
-/* the four convolution entries above with plain bf16 operands (hi only; precision "bf16"): the lo planes are neither read nor written */
+/* the convolution entries above with plain bf16 operands (hi only; precision "bf16"): the lo planes are neither read nor written */
 int effi_conv2d_k3_bf16x3_sr_bf16(const void* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16, const float* bias,
                                   int cout, int h, int w, int hp, int wp, int epilogue, int act, const float* aux0, const float* aux1,
                                   float* out0, void* out_sr, effi_stream_t stream);
@@ -667,6 +677,12 @@ int effi_conv2d_k3_k1_up2x_bf16x3_sr_bf16(const void* const* srcs, const int* sr
                                           const float* bias, int cout1, const void* w2pack_bf16, const float* bias2,
                                           const float* inv_depth, const float* disp_range, int n_range, int h, int w, int hp, int wp,
                                           float* out_depth, float* out_depth_inv, effi_stream_t stream);
+int effi_encoder_pair_gen_bf16x3_sr_bf16(const float* inv_depth, const float* disp_range, int n_range, const float* interval,
+                                         const float* cur_vol, long cds, long cps, int Dcur, const float* reg_vol, long rds, long rps,
+                                         int Dreg, const float* dmin, const float* dmax, long range_ps, int nq, int h, int w,
+                                         const float* weight_c1, const float* bias_c1, const float* weight_d1, const float* bias_d1,
+                                         int hd, const void* wpack_c2, const float* bias_c2, void* out_sr_c2, const void* wpack_d2,
+                                         const float* bias_d2, void* out_sr_d2, int cout, int hp, int wp, int act, effi_stream_t stream);
 
 #ifdef __cplusplus
 }

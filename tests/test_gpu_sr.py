@@ -156,6 +156,49 @@ def test_initial_states_and_encoder_inputs_in_sr_form(model, split_precision, h,
         assert_sr_equals(b_, d1, f"relu(convd1(inv)) stage {s + 1}")
 
 
+@pytest.mark.parametrize("precision", ["split", "bf16"])
+@pytest.mark.parametrize("h,w,force_mr", [(20, 28, None), (37, 52, 2), (37, 52, 4), (74, 100, 1), (148, 200, None), (100, 528, None)])
+def test_generated_encoder_pair_is_bitwise_the_two_launches(model, precision, h, w, force_mr):
+    """``encoder_pair_gen_sr`` (cor1 / dfm1 generated inside the convc2 | convd2 kernel) against ``encoder_inputs_sr`` +
+    ``conv2d_k3_pair_sr``: every bit of both output maps, for the three stages' channel counts, every tile shape (100x528: the
+    4 x 64 tiles of the 592x800 stage), map edges that cut tiles, queries that leave the volume."""
+    from effi_mvs_plus_amd import ops
+    from effi_mvs_plus_amd.models.update import _pack
+    net, _ = model
+    g = torch.Generator().manual_seed(7 * h + w)
+    D = 8
+    before = ops.get_precision()
+    try:
+        ops.set_precision(precision)
+        for s, hd in enumerate(net.hdim_stage):
+            e = net.update_block[s].encoder
+            wc1, bc1 = e.convc1_raw()
+            w7, b7 = e.conv7_packed()
+            wd2, bd2 = _pack(e._caches["d2"], e.convd2)
+            wc2, bc2 = _pack(e._caches["c2"], e.convc2)
+            inv = (torch.rand(1, h, w, generator=g) * 1.2 - 0.1).to(DEV)          # some estimates outside [0, 1]: taps off the volume
+            cur, reg = torch.randn(D, h, w, generator=g).to(DEV), torch.randn(D, h, w, generator=g).to(DEV)
+            dr = torch.linspace(1 / 935.0, 1 / 425.0, 384).to(DEV)
+            itv = torch.tensor([(dr[-1] - dr[0]).item() / 384], device=DEV)
+            lo, hi = torch.full((1,), 425.0, device=DEV), torch.full((1,), 935.0, device=DEV)
+            maps = ops.sr_alloc(6, hd, h, w, DEV, clear=False)
+            for m in maps:
+                m.t.fill_(5.0)
+            ops.sr_clear_border([maps])
+            A, B, C1, D1, C2, D2 = maps
+            with ops.options(force_mr=force_mr):
+                ops.encoder_inputs_sr(inv, dr, itv, cur, reg, lo, hi, 3, h, w, wc1, bc1, w7, b7, hd, A, B)
+                ops.conv2d_k3_pair_sr([A], wc2.wx, bc2, C1, [B], wd2.wx, bd2, D1, hd, act=ops.ACT_RELU)
+                ops.encoder_pair_gen_sr(inv, dr, itv, cur, reg, lo, hi, 3, h, w, wc1, bc1, w7, b7, hd, wc2.wx, bc2, C2, wd2.wx, bd2, D2, hd,
+                                        act=ops.ACT_RELU)
+            torch.cuda.synchronize()
+            assert float(C1.t.float().abs().max()) > 0 and float(D1.t.float().abs().max()) > 0
+            assert torch.equal(C1.t, C2.t), f"stage {s + 1} (hd {hd}): relu(convc2(cor1)) differs"
+            assert torch.equal(D1.t, D2.t), f"stage {s + 1} (hd {hd}): relu(convd2(dfm1)) differs"
+    finally:
+        ops.set_precision(before)
+
+
 @pytest.mark.parametrize("H,W,N,nd", [(128, 160, 4, "8,8,8"), (192, 256, 5, "48,8,8"), (320, 416, 3, "48,32,8")])
 @pytest.mark.parametrize("precision", ["split", "bf16"])
 def test_cascade_is_bitwise_unchanged_by_split_resident_maps(H, W, N, nd, precision):
