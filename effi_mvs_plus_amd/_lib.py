@@ -94,6 +94,9 @@ SIGNATURES = {
     "effi_channel_sum_f32": [_vp, _i, _i, _l, _vp, _vp, _i, _vp],
     "effi_conv2d_k5s2_dgrad_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "effi_bn_moment_f32": [_vp, _i, _i, _l, _vp, _i, _vp, _vp, _i, _vp],
+    "effi_bn_train_fwd_f32": [_vp, _i, _i, _l, _vp, _vp, _f, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp],
+    "effi_pack_conv2d_mfma_f32": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "effi_pack_conv2d_k5s2_dgrad_f32": [_vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "effi_bn_apply_f32": [_vp, _i, _i, _l, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "effi_bn_bwd_f32": [_vp, _vp, _vp, _i, _i, _l, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "effi_pointwise_f32": [_i, _vp, _vp, _vp, _vp, _f, _f, _l, _l, _i, _vp, _vp, _vp, _vp],

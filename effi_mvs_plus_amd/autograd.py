@@ -19,11 +19,39 @@ import torch
 
 from . import ops, packing
 
-_stack = torch.stack
+def _stack(ts):
+    """Per-sample results -> [B, ...]: a view for B = 1 (DTU training runs one sample per GPU, train.py:37), a copy otherwise."""
+    return ts[0].unsqueeze(0) if len(ts) == 1 else torch.stack(ts)
 
 
 def _c(t_):
     return t_.contiguous()
+
+
+class _GradArena:
+    """Zero-initialised storage for the weight gradients of one backward pass: the weight-gradient kernels ACCUMULATE (one atomic
+    per weight and workgroup), so every gradient starts from zeros -- ~300 ``zeros_like`` launches per step as separate tensors.
+    Here they are slices of large blocks that one fill each clears: a slice is handed out once, the rest of a block is still zero
+    for the next step's gradients, and an exhausted block lives as long as a gradient references it."""
+    BLOCK = 1 << 21          # floats per block (8 MB)
+
+    def __init__(self):
+        self.blocks = {}     # device -> [tensor, used]
+
+    def zeros_like(self, w):
+        n = w.numel()
+        if w.dtype != torch.float32 or n > self.BLOCK // 4:
+            return torch.zeros_like(w)
+        blk = self.blocks.get(w.device)
+        if blk is None or blk[1] + n > blk[0].numel():
+            blk = [torch.zeros(self.BLOCK, device=w.device, dtype=torch.float32), 0]
+            self.blocks[w.device] = blk
+        out = blk[0][blk[1]:blk[1] + n].view(w.shape)
+        blk[1] += (n + 63) & ~63
+        return out
+
+
+grad_arena = _GradArena()
 
 
 # =============================================================================================
@@ -47,7 +75,7 @@ class _Conv2d(torch.autograd.Function):
                 w7, b7 = packing.pack_conv2d_c1k7(weight, bias)
                 y = _stack([ops.conv2d_c1k7_relu(xs[0][b], w7, b7, cout, exact=True) for b in range(B)])
             else:
-                wp, bp = packing.pack_conv2d_mfma(weight, bias)       # exact fp32 products in training, whatever ops.get_precision() says
+                wp, bp = ops.pack_conv2d_mfma_dev(weight, bias)       # exact fp32 products in training, whatever ops.get_precision() says
                 y = _stack([ops.conv2d([x[b] for x in xs], wp, bp, cout, ks, act=act) for b in range(B)])
         ctx.save_for_backward(weight, y, *xs)
         ctx.act, ctx.has_bias = act, bias is not None
@@ -62,7 +90,7 @@ class _Conv2d(torch.autograd.Function):
         if ctx.act != ops.ACT_NONE:
             g = ops.pointwise(ops.PW_ACT_BWD[ctx.act], g, y)
         gb = ops.channel_sum(g) if ctx.has_bias else None
-        gw = torch.zeros_like(weight) if ctx.needs_input_grad[0] else None
+        gw = grad_arena.zeros_like(weight) if ctx.needs_input_grad[0] else None
         if gw is not None:
             dw = gw.view(cout, cin, ks * ks)
             for b in range(B):
@@ -74,7 +102,7 @@ class _Conv2d(torch.autograd.Function):
         if any(ctx.needs_input_grad[3:]):
             if ks == 7:
                 raise NotImplementedError("7x7 convolution: no input gradient (its input is the detached inverse depth, update.py:121)")
-            wp, bp = packing.pack_conv2d_mfma(_c(weight.flip(2, 3).transpose(0, 1)), None)
+            wp, bp = ops.pack_conv2d_mfma_dev(weight, None, dgrad=True)
             gcat = _stack([ops.conv2d([g[b]], wp, bp, cin, ks) for b in range(B)])
             off = 0
             for i, x in enumerate(xs):
@@ -97,7 +125,7 @@ class _Conv2dK5S2(torch.autograd.Function):
         x = _c(x)
         cout = weight.shape[0]
         with torch.no_grad():
-            wp, bp = packing.pack_conv2d_mfma(weight, None)
+            wp, bp = ops.pack_conv2d_mfma_dev(weight, None)
             y = _stack([ops.conv2d_k5s2(x[b], wp, bp, cout, act=ops.ACT_NONE) for b in range(x.shape[0])])
         ctx.save_for_backward(weight, x)
         return y
@@ -109,13 +137,13 @@ class _Conv2dK5S2(torch.autograd.Function):
         B, cin, hin, win = x.shape
         gw = gx = None
         if ctx.needs_input_grad[0]:
-            gw = torch.zeros_like(weight)
+            gw = grad_arena.zeros_like(weight)
             dw = gw.view(weight.shape[0], cin, 25)
             for b in range(B):
                 ops.conv_wgrad(g[b], x[b], dw, 0, 1, 5, stride=(1, 2))
         if ctx.needs_input_grad[1]:
             wc = _c(weight)
-            gx = _stack([ops.conv2d_k5s2_dgrad(g[b], wc, hin, win) for b in range(B)])
+            gx = _stack([ops.conv2d_k5s2_dgrad_mfma(g[b], wc, hin, win) for b in range(B)])
         return gw, gx
 
 
@@ -155,7 +183,7 @@ class _Conv3d(torch.autograd.Function):
         B = g.shape[0]
         gw = None
         if ctx.needs_input_grad[0]:
-            gw = torch.zeros_like(weight)
+            gw = grad_arena.zeros_like(weight)
             dw = gw.view(cout, cin, 27)
             for b in range(B):
                 off = 0
@@ -211,7 +239,7 @@ class _Deconv3d(torch.autograd.Function):
         B = g.shape[0]
         gw = gx = None
         if ctx.needs_input_grad[0]:
-            gw = torch.zeros_like(weight)
+            gw = grad_arena.zeros_like(weight)
             dw = gw.view(cin, cout, 27)
             for b in range(B):
                 ops.conv_wgrad(x[b], g[b], dw, 0, 3, 3, stride=(s[0], s[1]))
@@ -233,16 +261,10 @@ class _BatchNormTrain(torch.autograd.Function):
     updated in place with ``momentum`` (unbiased variance), optional fused ReLU."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, relu, n_tracked=None):
         x = _c(x)
         with torch.no_grad():
-            mean, var = ops.bn_moments(x)
-            invstd = torch.rsqrt(var + eps)
-            y = ops.bn_apply(x, mean, invstd, _c(gamma), _c(beta), relu)
-            n = x.numel() // x.shape[1]
-            if running_mean is not None:
-                running_mean.mul_(1 - momentum).add_(mean, alpha=momentum)
-                running_var.mul_(1 - momentum).add_(var * (n / max(n - 1, 1)), alpha=momentum)
+            y, mean, invstd = ops.bn_train_fwd(x, _c(gamma), _c(beta), eps, momentum, running_mean, running_var, n_tracked, relu)
         ctx.save_for_backward(x, y, mean, invstd, gamma)
         ctx.relu = relu
         return y
@@ -251,20 +273,23 @@ class _BatchNormTrain(torch.autograd.Function):
     def backward(ctx, gy):
         x, y, mean, invstd, gamma = ctx.saved_tensors
         gx, s1, s2 = ops.bn_bwd(_c(gy), y, x, mean, invstd, _c(gamma), ctx.relu)
-        return gx, s2, s1, None, None, None, None, None
+        return gx, s2, s1, None, None, None, None, None, None
 
 
 def batch_norm_train(x, bn, relu):
     """``bn``: nn.BatchNorm2d / 3d module (its running statistics and counter are updated like nn.BatchNorm does)."""
-    if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    n_tracked = bn.num_batches_tracked            # incremented by the forward kernel (nn.BatchNorm counts before it uses the value)
     if bn.momentum is None:                 # nn.BatchNorm: cumulative moving average, factor 1 / num_batches_tracked
-        if bn.num_batches_tracked is None:
+        if n_tracked is None:
             raise NotImplementedError("batch_norm_train: momentum=None needs track_running_stats (the counter)")
-        momentum = 1.0 / float(bn.num_batches_tracked.item())
+        n_tracked.add_(1)
+        momentum, n_tracked = 1.0 / float(n_tracked.item()), None
     else:
         momentum = bn.momentum
-    return _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, relu)
+    if n_tracked is not None and (n_tracked.device != x.device or bn.running_mean is None):
+        n_tracked.add_(1)
+        n_tracked = None
+    return _BatchNormTrain.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum, bn.eps, relu, n_tracked)
 
 
 # =============================================================================================

@@ -156,6 +156,91 @@ __global__ __launch_bounds__(TPB) void bn_moment_kernel(const float* __restrict_
     }
 }
 
+// Last step of the two moment passes (replaces reduce_partials_kernel + six one-line torch launches per BatchNorm call): adds the
+// nsplit partial sums of a channel in ascending order and
+//   stage 1: mean[c] = sum / N
+//   stage 2: var = sum / N;  invstd[c] = 1 / sqrt(var + eps);  running_mean = running_mean (1 - m) + m mean;
+//            running_var = running_var (1 - m) + m var N / (N - 1)   (nn.BatchNorm's update with the unbiased variance);
+//            thread 0 adds 1 to num_batches_tracked.
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int C, int nsplit, int stage, float n_total, float eps, float momentum,
+                                   float unbias, float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ var_out,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ n_tracked) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (stage == 2 && c == 0 && n_tracked) n_tracked[0] += 1;
+    if (c >= C) return;
+    float s = 0.0f;
+    for (int j = 0; j < nsplit; ++j) s += partial[(long)c * nsplit + j];
+    if (stage == 1) {
+        mean[c] = s / n_total;
+        return;
+    }
+    const float var = s / n_total;
+    if (var_out) var_out[c] = var;
+    invstd[c] = rsqrtf(var + eps);
+    if (running_mean) {
+        const float keep = 1.0f - momentum;
+        running_mean[c] = running_mean[c] * keep + momentum * mean[c];
+        running_var[c] = running_var[c] * keep + momentum * (var * unbias);
+    }
+}
+
+// Weights of a 2-D convolution [cout][cin][taps] -> the B-operand order of the fp32 matrix-core kernels [kg][tap][nt][k][j]
+// (packing.pack_conv2d_mfma: lane k * 16 + j holds W[16 n + j][4 g + k]; rows / columns past the end are zero) + the bias padded to
+// 16 nt.  dgrad != 0: the weights of the INPUT-GRADIENT convolution instead (in / out swapped, taps flipped):
+// W'[co][ci][t] = W[ci][co][taps - 1 - t] with co < cin, ci < cout.  One launch instead of the seven torch launches of the host
+// form, per layer and step (the weights change every step).
+__global__ __launch_bounds__(TPB) void pack_conv2d_mfma_kernel(const float* __restrict__ w, const float* __restrict__ bias, int cout, int cin,
+                                                               int taps, int dgrad, int nt, int kg, float* __restrict__ wp,
+                                                               float* __restrict__ bp) {
+    const long total = (long)kg * taps * nt * 64;
+    const long e = (long)blockIdx.x * TPB + threadIdx.x;
+    if (e < 16 * nt) {
+        const int co_n = dgrad ? cin : cout;
+        bp[e] = (bias && e < co_n) ? bias[e] : 0.0f;
+    }
+    if (e >= total) return;
+    const int j = (int)(e & 15), k = (int)((e >> 4) & 3);
+    long r = e >> 6;
+    const int n = (int)(r % nt);
+    r /= nt;
+    const int t = (int)(r % taps), g = (int)(r / taps);
+    const int co = 16 * n + j, ci = 4 * g + k;
+    float v = 0.0f;
+    if (!dgrad) {
+        if (co < cout && ci < cin) v = w[((long)co * cin + ci) * taps + t];
+    } else {
+        if (co < cin && ci < cout) v = w[((long)ci * cin + co) * taps + (taps - 1 - t)];
+    }
+    wp[e] = v;
+}
+
+// Input gradient of a 5x5 / stride-2 / padding-2 convolution as ONE 3x3 stride-1 convolution over the output gradient g followed by a
+// pixel shuffle: the input pixels of parity class (py, px) receive g through the taps ky = py (mod 2), kx = px (mod 2) only, and
+//   dx[ci][2 yy + py][2 xx + px] = sum_co sum_{dy,dx in -1..1} g[co][yy + dy][xx + dx] K[(ci,py,px)][co][dy + 1][dx + 1],
+//   K[(ci,py,px)][co][dy + 1][dx + 1] = W[co][ci][py + 2 - 2 dy][px + 2 - 2 dx]   (zero where that tap does not exist).
+// This kernel writes K in the matrix-core operand order (pack_conv2d_mfma_kernel) for the output channels (ci, py, px) = 4 ci + 2 py + px,
+// ci in [ci_off, ci_off + ci_n): the 3x3 kernel then does the work at matrix-core rate (the direct vector form took 226 us per call).
+__global__ __launch_bounds__(TPB) void pack_k5s2_dgrad_kernel(const float* __restrict__ w, int cout, int cin, int ci_off, int ci_n, int nt, int kg,
+                                                              float* __restrict__ wp, float* __restrict__ bp) {
+    const long total = (long)kg * 9 * nt * 64;
+    const long e = (long)blockIdx.x * TPB + threadIdx.x;
+    if (e < 16 * nt) bp[e] = 0.0f;
+    if (e >= total) return;
+    const int j = (int)(e & 15), k = (int)((e >> 4) & 3);
+    long r = e >> 6;
+    const int n = (int)(r % nt);
+    r /= nt;
+    const int t = (int)(r % 9), g = (int)(r / 9);
+    const int cq = 16 * n + j, co = 4 * g + k;                 // output channel (ci, py, px) of the 3x3 kernel; its input channel = co
+    float v = 0.0f;
+    if (cq < 4 * ci_n && co < cout) {
+        const int ci = ci_off + (cq >> 2), py = (cq >> 1) & 1, px = cq & 1;
+        const int ky = py + 2 - 2 * (t / 3 - 1), kx = px + 2 - 2 * (t % 3 - 1);
+        if (ky >= 0 && ky < 5 && kx >= 0 && kx < 5) v = w[(((long)co * cin + ci) * 5 + ky) * 5 + kx];
+    }
+    wp[e] = v;
+}
+
 // y = (x - mean) * invstd * gamma + beta, then ReLU if asked
 __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__ x, int Bn, int C, long n, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -458,6 +543,55 @@ extern "C" int effi_bn_moment_f32(const float* x, int B, int C, long n, const fl
     if (power == 1) hipLaunchKernelGGL(bn_moment_kernel<1>, grid, dim3(TPB), 0, s, x, B, C, n, shift, out, part);
     else hipLaunchKernelGGL(bn_moment_kernel<2>, grid, dim3(TPB), 0, s, x, B, C, n, shift, out, part);
     if (ns > 1) hipLaunchKernelGGL(reduce_partials_kernel<1>, dim3((C + 63) / 64), dim3(64), 0, s, scratch, C, ns, out, out);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+// nn.BatchNorm in training mode, forward, as ONE entry (five launches: sum, mean, centred squares, variance + running statistics,
+// apply): what ops.bn_moments + torch arithmetic + ops.bn_apply did in ~17 launches.  running_mean / running_var / n_tracked may be
+// NULL (no tracking); scratch: [C][nsplit] floats (always used: nsplit >= 1).
+extern "C" int effi_bn_train_fwd_f32(const float* x, int B, int C, long n, const float* gamma, const float* beta, float eps, float momentum,
+                                     float* running_mean, float* running_var, long long* n_tracked, int relu, float* y, float* mean,
+                                     float* invstd, float* scratch, int nsplit, effi_stream_t stream) {
+    if (!x || !gamma || !beta || !y || !mean || !invstd || !scratch || B < 1 || C < 1 || n < 1 || nsplit < 1) return EFFI_ERR_BADARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return EFFI_ERR_BADARG;
+    const int ns = nsplit > 1024 ? 1024 : nsplit;
+    hipStream_t s = effi_s(stream);
+    const dim3 grid(C, ns), fgrid((C + 63) / 64);
+    const long N = (long)B * n;
+    const float nf = (float)N, unbias = (float)((double)N / (double)(N > 1 ? N - 1 : 1));
+    hipLaunchKernelGGL(bn_moment_kernel<1>, grid, dim3(TPB), 0, s, x, B, C, n, (const float*)nullptr, mean, scratch);
+    hipLaunchKernelGGL(bn_finalize_kernel, fgrid, dim3(64), 0, s, scratch, C, ns, 1, nf, eps, momentum, unbias, mean, invstd, (float*)nullptr,
+                       (float*)nullptr, (float*)nullptr, (long long*)nullptr);
+    hipLaunchKernelGGL(bn_moment_kernel<2>, grid, dim3(TPB), 0, s, x, B, C, n, (const float*)mean, invstd, scratch);
+    hipLaunchKernelGGL(bn_finalize_kernel, fgrid, dim3(64), 0, s, scratch, C, ns, 2, nf, eps, momentum, unbias, mean, invstd, (float*)nullptr,
+                       running_mean, running_var, n_tracked);
+    const long total = (long)B * C * n;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)min((total + TPB - 1) / TPB, 16384L)), dim3(TPB), 0, s, x, B, C, n, mean, invstd, gamma,
+                       beta, relu, y);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_pack_conv2d_mfma_f32(const float* weight, const float* bias, int cout, int cin, int ks, int dgrad, float* wpack,
+                                         float* bias_pack, effi_stream_t stream) {
+    if (!weight || !wpack || !bias_pack || cout < 1 || cin < 1 || ks < 1 || ks > 7) return EFFI_ERR_BADARG;
+    const int co = dgrad ? cin : cout, ci = dgrad ? cout : cin;
+    const int nt = (co + 15) / 16, kg = (ci + 3) / 4, taps = ks * ks;
+    const long total = (long)kg * taps * nt * 64;
+    hipLaunchKernelGGL(pack_conv2d_mfma_kernel, dim3((unsigned)((total + TPB - 1) / TPB)), dim3(TPB), 0, effi_s(stream), weight, bias, cout, cin,
+                       taps, dgrad, nt, kg, wpack, bias_pack);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_pack_conv2d_k5s2_dgrad_f32(const float* weight, int cout, int cin, int ci_off, int ci_n, float* wpack, float* bias_pack,
+                                               effi_stream_t stream) {
+    if (!weight || !wpack || !bias_pack || cout < 1 || cin < 1 || ci_off < 0 || ci_n < 1 || ci_off + ci_n > cin) return EFFI_ERR_BADARG;
+    const int nt = (4 * ci_n + 15) / 16, kg = (cout + 3) / 4;
+    const long total = (long)kg * 9 * nt * 64;
+    hipLaunchKernelGGL(pack_k5s2_dgrad_kernel, dim3((unsigned)((total + TPB - 1) / TPB)), dim3(TPB), 0, effi_s(stream), weight, cout, cin, ci_off,
+                       ci_n, nt, kg, wpack, bias_pack);
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
 }

@@ -1490,6 +1490,30 @@ def conv2d_k5s2_dgrad(grad_out, weight, hin, win):
     return gx
 
 
+def conv2d_k5s2_dgrad_mfma(grad_out, weight, hin, win):
+    """``conv2d_k5s2_dgrad`` on the matrix cores: one 3x3 convolution over ``grad_out`` whose 4 cin output channels are the four pixel
+    parities of the input gradient (weights re-arranged on the device, effi_pack_conv2d_k5s2_dgrad_f32), then a pixel shuffle."""
+    _t(grad_out, "grad_out"), _t(weight, "weight")
+    cout, cin = weight.shape[0], weight.shape[1]
+    ho, wo = (hin - 1) // 2 + 1, (win - 1) // 2 + 1
+    if tuple(grad_out.shape) != (cout, ho, wo):
+        raise ValueError("conv2d_k5s2_dgrad: grad_out shape does not match the input size")
+    planes = torch.empty(4 * cin, ho, wo, device=grad_out.device, dtype=torch.float32)
+    kg = (cout + 3) // 4
+    for c0 in range(0, cin, 16):                       # at most 64 output channels per launch
+        cn = min(16, cin - c0)
+        nt = (4 * cn + 15) // 16
+        if nt == 5:
+            raise NotImplementedError("conv2d_k5s2_dgrad_mfma: input channels must come in groups of 4 / 8 / 12 / 16")
+        buf = torch.empty(kg * 9 * nt * 64 + 16 * nt, device=grad_out.device, dtype=torch.float32)
+        wp, bp = buf[:kg * 9 * nt * 64], buf[kg * 9 * nt * 64:]
+        check(_lib.lib().effi_pack_conv2d_k5s2_dgrad_f32(_p(weight), cout, cin, c0, cn, _p(wp), _p(bp), _stream()),
+              "effi_pack_conv2d_k5s2_dgrad_f32")
+        conv2d([grad_out], wp, bp, 4 * cn, 3, out0=planes[4 * c0:4 * (c0 + cn)])
+    gx = torch.nn.functional.pixel_shuffle(planes.unsqueeze(0), 2)[0]                # [cin, 2 ho, 2 wo]
+    return gx if (2 * ho, 2 * wo) == (hin, win) else gx[:, :hin, :win].contiguous()
+
+
 def _reduce_split(total, channels, k=1, device=None):
     """Workgroups per channel of the split per-channel reductions and their scratch ([C][nsplit][k] floats): ~8 K elements per
     workgroup, at most 256 per channel, none when the tensor is small.  The partial sums are added in a fixed order (second launch)."""
@@ -1522,6 +1546,46 @@ def bn_moments(x):
     var = torch.empty(Cc, device=x.device, dtype=torch.float32)
     check(_lib.lib().effi_bn_moment_f32(_p(x), B, Cc, n, _p(mean), 2, _p(var), _p(scratch), nsplit, _stream()), "effi_bn_moment_f32")
     return mean, var / float(B * n)
+
+
+def bn_train_fwd(x, gamma, beta, eps, momentum, running_mean=None, running_var=None, n_tracked=None, relu=False):
+    """nn.BatchNorm (training mode) forward in one entry: -> (y, mean [C], invstd [C]); the running statistics (and the int64 counter
+    ``n_tracked``) are updated in place when given."""
+    _t(x, "bn input"), _t(gamma, "bn weight"), _t(beta, "bn bias")
+    B, Cc = x.shape[0], x.shape[1]
+    n = x.numel() // (B * Cc)
+    nsplit = int(min(256, max(1, (B * n) // 8192)))
+    buf = torch.empty(Cc * (nsplit + 2), device=x.device, dtype=torch.float32)        # scratch | mean | invstd in one allocation
+    mean, invstd = buf[Cc * nsplit:Cc * (nsplit + 1)], buf[Cc * (nsplit + 1):]
+    y = torch.empty_like(x)
+    if running_mean is not None:
+        _t(running_mean, "running_mean"), _t(running_var, "running_var")
+    if n_tracked is not None and (n_tracked.dtype != torch.int64 or n_tracked.device != x.device):
+        raise ValueError("bn_train_fwd: num_batches_tracked must be an int64 tensor on the input's device")
+    check(_lib.lib().effi_bn_train_fwd_f32(_p(x), B, Cc, n, _p(gamma), _p(beta), float(eps), float(momentum), _p(running_mean),
+                                           _p(running_var), _p(n_tracked), int(relu), _p(y), _p(mean), _p(invstd), _p(buf), nsplit,
+                                           _stream()), "effi_bn_train_fwd_f32")
+    return y, mean, invstd
+
+
+def pack_conv2d_mfma_dev(weight, bias=None, dgrad=False):
+    """``packing.pack_conv2d_mfma`` on the device in one launch (training: every layer, every step); ``dgrad``: the weights of the
+    input-gradient convolution (``weight.flip(2, 3).transpose(0, 1)`` packed).  -> (wpack, bias_pack)."""
+    _t(weight, "weight")
+    cout, cin, ks, _ = weight.shape
+    co, ci = (cin, cout) if dgrad else (cout, cin)
+    if co == 1 and ks == 3:       # single-output-channel layers carry a second (vector) weight block: host form
+        from . import packing
+        w = weight.flip(2, 3).transpose(0, 1).contiguous() if dgrad else weight
+        return packing.pack_conv2d_mfma(w, bias)
+    nt, kg = (co + 15) // 16, (ci + 3) // 4
+    buf = torch.empty(kg * ks * ks * nt * 64 + 16 * nt, device=weight.device, dtype=torch.float32)
+    wp, bp = buf[:kg * ks * ks * nt * 64].view(kg, ks * ks, nt, 64), buf[kg * ks * ks * nt * 64:]
+    if bias is not None:
+        _t(bias, "bias")
+    check(_lib.lib().effi_pack_conv2d_mfma_f32(_p(weight), _p(bias), cout, cin, ks, int(dgrad), _p(wp), _p(bp), _stream()),
+          "effi_pack_conv2d_mfma_f32")
+    return wp, bp
 
 
 def bn_apply(x, mean, invstd, gamma, beta, relu):

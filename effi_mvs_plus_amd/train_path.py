@@ -150,7 +150,7 @@ def depthnet(pixelwise_seq, cost_reg, feats, pairs, hyp):
     for b in range(B):
         s, e = A.warp_correlate(feats[0][b], [f[b] for f in feats[1:]], pairs[b], hyp[b], with_entropy=True)
         sims.append(s), ents.append(e)
-    sim_views, entropy = torch.stack(sims), torch.stack(ents)                       # [B,S,D,h,w], [B,S,h,w] (detached, :43)
+    sim_views, entropy = A._stack(sims), A._stack(ents)                       # [B,S,D,h,w], [B,S,h,w] (detached, :43)
     S, h, w = entropy.shape[1:]
     # one call per source view, as in the reference's loop (:32-46): each call has its own batch statistics
     weights = torch.cat([pixelwise_net(pixelwise_seq, entropy[:, v:v + 1]) for v in range(S)], dim=1)
@@ -172,7 +172,7 @@ def hot_path(model, features, cnet_depth, proj_matrices, depth_values):
     d_nums = model.depth_stage_nums
     base_itv = (hi - lo) / n_range                                                  # :424
     hyp1, _ = zip(*[ops.stage1_hypotheses(depth_values[b].contiguous(), d_nums[0]) for b in range(B)])
-    hyp1 = torch.stack(hyp1)                                                        # [B,D1] depths
+    hyp1 = A._stack(list(hyp1))                                                        # [B,D1] depths
     depth_min_, depth_max_ = 1.0 / hi.view(B, 1, 1, 1), 1.0 / lo.view(B, 1, 1, 1)
     keys = ["stage{}".format(s + 1) for s in range(model.num_stage)]
 
@@ -191,7 +191,7 @@ def hot_path(model, features, cnet_depth, proj_matrices, depth_values):
         h, w = feats[0].shape[-2:]
         if s == 0:
             out = depthnet(model.PixelwiseNet, model.cost_regularization, feats, pairs, hyp1)
-            conf = torch.stack([ops.upsample_nearest(out["photometric_confidence"][b:b + 1].contiguous(), 4)[0] for b in range(B)])   # :478-480
+            conf = A._stack([ops.upsample_nearest(out["photometric_confidence"][b:b + 1].contiguous(), 4)[0] for b in range(B)])   # :478-480
             weights, reg_vol, cur_vol = out["view_weights"], out["reg_volume"], out["volume"].squeeze(1)
             preds.append(out["depth"])
             cur_depth = out["depth"].unsqueeze(1)
@@ -204,7 +204,7 @@ def hot_path(model, features, cnet_depth, proj_matrices, depth_values):
             for b in range(B):
                 sm, sp = A.warp_correlate_dyn(feats[0][b], [f[b] for f in feats[1:]], weights[b], pairs[b], cur_depth[b, 0], itv[b], D)
                 sims.append(sm), smps.append(sp)
-            sim, samples = torch.stack(sims), torch.stack(smps)                     # [B,D,h,w]
+            sim, samples = A._stack(sims), A._stack(smps)                     # [B,D,h,w]
             dmax_cur, dmin_cur = samples[:, 0:1], samples[:, -1:]                   # :508-509
             x5 = sim.unsqueeze(1)
             prior = A.vol_lookup(reg_vol, samples, dmin_prev, dmax_prev)            # queries read nearest-downsampled (:510)
@@ -212,7 +212,7 @@ def hot_path(model, features, cnet_depth, proj_matrices, depth_values):
             prior = A.vol_lookup(cur_vol, samples, dmin_prev, dmax_prev)
             cur_vol = cost_up_small(model.CSP_C[s - 1], x5, prior.unsqueeze(1))[0].squeeze(1)
         # depth_to_disp (:538); the update block detaches it first thing (update.py:121), so no gradient leaves through it
-        inv_cur = torch.stack([ops.depth_to_inv(cur_depth[b].detach().contiguous(), depth_values[b].contiguous()) for b in range(B)])
+        inv_cur = A._stack([ops.depth_to_inv(cur_depth[b].detach().contiguous(), depth_values[b].contiguous()) for b in range(B)])
         itv_s = base_itv * model.depth_interals_ratio[s]
 
         def cost_fn(inv, i, cur_vol=cur_vol, reg_vol=reg_vol, itv_s=itv_s, dmin_cur=dmin_cur, dmax_cur=dmax_cur):

@@ -477,6 +477,26 @@ int effi_bn_moment_f32(const float* x, int B, int C, long n, const float* shift,
                        effi_stream_t stream);
 int effi_bn_apply_f32(const float* x, int B, int C, long n, const float* mean, const float* invstd, const float* gamma,
                       const float* beta, int relu, float* y, effi_stream_t stream);
+/* The forward of nn.BatchNorm2d / 3d in training mode as one entry (models/module.py:148-157,191-200,217-220 under model.train()):
+ * mean / invstd [C] (outputs, kept for the backward) from the two moment passes, y = BN(x) (+ ReLU), and -- when running_mean /
+ * running_var are given -- nn.BatchNorm's running-statistic update with ``momentum`` (unbiased variance) and num_batches_tracked += 1
+ * (n_tracked: the module's int64 counter, or NULL).  scratch: [C][nsplit] floats, nsplit >= 1 workgroups per channel (partials are
+ * added in ascending order: bitwise repeatable). */
+int effi_bn_train_fwd_f32(const float* x, int B, int C, long n, const float* gamma, const float* beta, float eps, float momentum,
+                          float* running_mean, float* running_var, long long* n_tracked, int relu, float* y, float* mean,
+                          float* invstd, float* scratch, int nsplit, effi_stream_t stream);
+/* nn.Conv2d weights [cout][cin][ks][ks] (+ bias or NULL) -> the operand order effi_conv2d_f32 reads (wpack [ceil(ci/4)][ks*ks]
+ * [ceil(co/16)][64] floats, bias_pack [16 ceil(co/16)]); dgrad != 0: the weights of the input-gradient convolution (in / out swapped,
+ * taps flipped; co = cin, ci = cout; bias_pack zero unless bias given).  Training re-packs every layer every step
+ * (train.py:229-263: the optimizer changed the weights): one launch here. */
+int effi_pack_conv2d_mfma_f32(const float* weight, const float* bias, int cout, int cin, int ks, int dgrad, float* wpack,
+                              float* bias_pack, effi_stream_t stream);
+/* The input gradient of a 5x5 / stride-2 / padding-2 convolution (models/module.py:376-388 under loss.backward()) as a 3x3 convolution
+ * over the output gradient + pixel shuffle: packs, for input channels [ci_off, ci_off + ci_n) of weight [cout][cin][5][5], the
+ * 3x3 weights with 4 ci_n output channels (4 ci + 2 py + px = input channel ci, pixel parity (py, px)) and cout input channels in
+ * effi_conv2d_f32's operand order (wpack [ceil(cout/4)][9][ceil(4 ci_n/16)][64], bias_pack zeros). */
+int effi_pack_conv2d_k5s2_dgrad_f32(const float* weight, int cout, int cin, int ci_off, int ci_n, float* wpack, float* bias_pack,
+                                    effi_stream_t stream);
 int effi_bn_bwd_f32(const float* gy, const float* y, const float* x, int B, int C, long n, const float* mean, const float* invstd,
                     const float* gamma, int relu, float* s1, float* s2, float* gx, float* scratch, int nsplit,
                     effi_stream_t stream);
