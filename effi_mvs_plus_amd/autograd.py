@@ -43,8 +43,10 @@ class _GradArena:
         if w.dtype != torch.float32 or n > self.BLOCK // 4:
             return torch.zeros_like(w)
         blk = self.blocks.get(w.device)
-        if blk is None or blk[1] + n > blk[0].numel():
-            blk = [torch.zeros(self.BLOCK, device=w.device, dtype=torch.float32), 0]
+        cap = torch.cuda.is_current_stream_capturing()
+        # inside a graph capture the block's fill must be part of the graph (a replay accumulates into the same addresses again)
+        if blk is None or blk[1] + n > blk[0].numel() or blk[2] != cap:
+            blk = [torch.zeros(self.BLOCK, device=w.device, dtype=torch.float32), 0, cap]
             self.blocks[w.device] = blk
         out = blk[0][blk[1]:blk[1] + n].view(w.shape)
         blk[1] += (n + 63) & ~63
@@ -325,6 +327,30 @@ class _Mul(torch.autograd.Function):
         x, y = ctx.saved_tensors
         gx, gy = ops.pointwise(ops.PW_MUL_BWD, _c(g), x, y, n_out=2)
         return gx, gy
+
+
+class _SplitChannels(torch.autograd.Function):
+    """[B,C,...] -> ([B,:k,...], [B,k:,...]) as views; the backward writes the two gradients side by side (one launch; autograd's own
+    slice backward would zero-fill and copy a full-size tensor per half and add the two)."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        ctx.k, ctx.C = k, x.shape[1]
+        return x[:, :k], x[:, k:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None or gb is None:
+            ref = ga if ga is not None else gb
+            shape = list(ref.shape)
+            shape[1] = ctx.k if ga is None else ctx.C - ctx.k
+            z = torch.zeros(shape, device=ref.device, dtype=ref.dtype)
+            ga, gb = (z, gb) if ga is None else (ga, z)
+        return torch.cat([ga, gb], dim=1), None
+
+
+def split_channels(x, k):
+    return _SplitChannels.apply(x, k)
 
 
 class _GruCombine(torch.autograd.Function):

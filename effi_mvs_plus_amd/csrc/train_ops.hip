@@ -23,6 +23,12 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Positions [i0, i1) of the flattened (sample b, position r < n) range of ONE channel, TPB threads striding: the sample index is
+// advanced by comparison instead of a 64-bit division per element (the division was most of these kernels' instructions).
+#define EFFI_FOR_BATCH_RANGE(i0, i1, n, b, r)                                                                      \
+    for (long i_ = (i0) + threadIdx.x, b = i_ / (n), r = i_ - b * (n); i_ < (i1);                                 \
+         i_ += TPB, r += TPB, (r >= (n)) ? (b += r / (n), r %= (n)) : 0L)
+
 // ------------------------------------------------------------------------------------------------
 // weight gradient, generic: A on the small grid (Da,ha,wa), B on the large one (Db,hb,wb), position o of A meets
 // B at o*stride + tap - pad.  grid = (ceil(ca / CAB), cb, strips); every workgroup reduces its strip and adds atomically.
@@ -67,16 +73,30 @@ __global__ __launch_bounds__(TPB) void wgrad_nd_kernel(const float* __restrict__
             }
         }
     }
-    __shared__ float red[TPB / 64][CAB * TAPS];
+    // Reduction over the workgroup's 256 threads of CAB * TAPS values each.  A butterfly (wave_sum) per value costs 12 instructions
+    // per value and lane -- as much as 16 positions of the loop above; instead each wave transposes its values through LDS, 32 at a
+    // time ([value][lane], rows padded to 65 words), and lane v adds row v: 1 write + 2 reads + 2 adds per value.
+    constexpr int NV = CAB * TAPS, CH = 32;
+    __shared__ float red[TPB / 64][NV];
+    __shared__ float tr[TPB / 64][CH][65];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < CAB; ++i)
+    for (int c0 = 0; c0 < NV; c0 += CH) {
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-            const float v = wave_sum(acc[i][t]);
-            if (lane == 0) red[wv][i * TAPS + t] = v;
+        for (int v = 0; v < CH; ++v)
+            if (c0 + v < NV) tr[wv][v][lane] = acc[(c0 + v) / TAPS][(c0 + v) % TAPS];
+        __syncthreads();
+        {
+            // lanes 0..31: first half of row (lane & 31), lanes 32..63: second half; the two halves meet through one shuffle
+            const int row = lane & 31, j0 = (lane >> 5) * 32;
+            float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) sum += tr[wv][row][j0 + j];
+            sum += __shfl_xor(sum, 32);
+            if (lane < 32 && c0 + row < NV) red[wv][c0 + row] = sum;
         }
-    __syncthreads();
+        __syncthreads();
+    }
     for (int e = threadIdx.x; e < CAB * TAPS; e += TPB) {
         const int i = e / TAPS, t = e - i * TAPS;
         if (ca0 + i >= ca) continue;
@@ -95,10 +115,7 @@ __global__ __launch_bounds__(TPB) void channel_sum_kernel(const float* __restric
     const long per = (total + gridDim.y - 1) / gridDim.y;
     const long i0 = blockIdx.y * per, i1 = min(total, i0 + per);
     float s = 0.0f;
-    for (long i = i0 + threadIdx.x; i < i1; i += TPB) {
-        const long b = i / n, r = i - b * n;
-        s += g[((long)b * C + c) * n + r];
-    }
+    EFFI_FOR_BATCH_RANGE(i0, i1, n, b, r) s += g[((long)b * C + c) * n + r];
     __shared__ float red[TPB / 64];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -131,17 +148,27 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partial, int C,
 // BatchNorm, training mode (nn.BatchNorm2d / 3d on batch statistics; models/module.py:148-157,191-200,217-220)
 // ------------------------------------------------------------------------------------------------
 // out[c] = sum (x - shift[c])^P over batch and positions (P = 1 with shift = nullptr: the sum; P = 2 with shift = mean)
+// shift_partial (with P = 2): the first pass' partial sums [C][ns_in] instead of a finished mean -- every workgroup adds them (in
+// ascending order: all get the same bits) and divides by N itself, which saves the launch that used to do it; workgroup (c, 0) also
+// publishes the mean to mean_out.
 template <int P>
 __global__ __launch_bounds__(TPB) void bn_moment_kernel(const float* __restrict__ x, int Bn, int C, long n, const float* __restrict__ shift,
-                                                        float* __restrict__ out, float* __restrict__ partial) {
+                                                        float* __restrict__ out, float* __restrict__ partial,
+                                                        const float* __restrict__ shift_partial = nullptr, int ns_in = 0,
+                                                        float* __restrict__ mean_out = nullptr) {
     const int c = blockIdx.x;
     const long total = (long)Bn * n;
     const long per = (total + gridDim.y - 1) / gridDim.y;
     const long i0 = blockIdx.y * per, i1 = min(total, i0 + per);
-    const float sh = shift ? shift[c] : 0.0f;
+    float sh = shift ? shift[c] : 0.0f;
+    if (shift_partial) {
+        float m = 0.0f;
+        for (int j = 0; j < ns_in; ++j) m += shift_partial[(long)c * ns_in + j];
+        sh = m / (float)total;
+        if (blockIdx.y == 0 && threadIdx.x == 0) mean_out[c] = sh;
+    }
     float s = 0.0f;
-    for (long i = i0 + threadIdx.x; i < i1; i += TPB) {
-        const long b = i / n, r = i - b * n;
+    EFFI_FOR_BATCH_RANGE(i0, i1, n, b, r) {
         const float v = x[((long)b * C + c) * n + r] - sh;
         s += (P == 1) ? v : v * v;
     }
@@ -153,34 +180,6 @@ __global__ __launch_bounds__(TPB) void bn_moment_kernel(const float* __restrict_
         const float t = red[0] + red[1] + red[2] + red[3];
         if (partial) partial[(long)c * gridDim.y + blockIdx.y] = t;
         else out[c] = t;
-    }
-}
-
-// Last step of the two moment passes (replaces reduce_partials_kernel + six one-line torch launches per BatchNorm call): adds the
-// nsplit partial sums of a channel in ascending order and
-//   stage 1: mean[c] = sum / N
-//   stage 2: var = sum / N;  invstd[c] = 1 / sqrt(var + eps);  running_mean = running_mean (1 - m) + m mean;
-//            running_var = running_var (1 - m) + m var N / (N - 1)   (nn.BatchNorm's update with the unbiased variance);
-//            thread 0 adds 1 to num_batches_tracked.
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int C, int nsplit, int stage, float n_total, float eps, float momentum,
-                                   float unbias, float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ var_out,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ n_tracked) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (stage == 2 && c == 0 && n_tracked) n_tracked[0] += 1;
-    if (c >= C) return;
-    float s = 0.0f;
-    for (int j = 0; j < nsplit; ++j) s += partial[(long)c * nsplit + j];
-    if (stage == 1) {
-        mean[c] = s / n_total;
-        return;
-    }
-    const float var = s / n_total;
-    if (var_out) var_out[c] = var;
-    invstd[c] = rsqrtf(var + eps);
-    if (running_mean) {
-        const float keep = 1.0f - momentum;
-        running_mean[c] = running_mean[c] * keep + momentum * mean[c];
-        running_var[c] = running_var[c] * keep + momentum * (var * unbias);
     }
 }
 
@@ -242,15 +241,41 @@ __global__ __launch_bounds__(TPB) void pack_k5s2_dgrad_kernel(const float* __res
 }
 
 // y = (x - mean) * invstd * gamma + beta, then ReLU if asked
+struct BnFinish {                // second half of the statistics, done by the apply kernel (see effi_bn_train_fwd_f32); var_partial == NULL: off
+    const float* var_partial; int ns; float n_total, eps, momentum, unbias;
+    float* invstd_out; float* running_mean; float* running_var; long long* n_tracked;
+};
 __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__ x, int Bn, int C, long n, const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, int relu, float* __restrict__ y) {
-    const long total = (long)Bn * C * n;
-    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
-        const int c = (int)((i / n) % C);
-        float v = (x[i] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+                                                       const float* __restrict__ beta, int relu, float* __restrict__ y, const BnFinish f) {
+    // grid (chunks of a plane, planes = Bn * C): the channel is a workgroup constant (no division per element)
+    const int c = (int)(blockIdx.y % C);
+    float is;
+    if (f.var_partial) {
+        // variance from the second pass' partial sums (every workgroup of the channel, same order, same bits); the first workgroup
+        // of the channel publishes invstd and updates the running statistics (nn.BatchNorm: unbiased variance, momentum)
+        float sq = 0.0f;
+        for (int j = 0; j < f.ns; ++j) sq += f.var_partial[(long)c * f.ns + j];
+        const float var = sq / f.n_total;
+        is = rsqrtf(var + f.eps);
+        if (blockIdx.x == 0 && blockIdx.y == (unsigned)c && threadIdx.x == 0) {
+            f.invstd_out[c] = is;
+            if (f.running_mean) {
+                const float keep = 1.0f - f.momentum;
+                f.running_mean[c] = f.running_mean[c] * keep + f.momentum * mean[c];
+                f.running_var[c] = f.running_var[c] * keep + f.momentum * (var * f.unbias);
+            }
+            if (c == 0 && f.n_tracked) f.n_tracked[0] += 1;
+        }
+    } else {
+        is = invstd[c];
+    }
+    const float mu = mean[c], ga = gamma[c], be = beta[c];
+    const long base = (long)blockIdx.y * n;
+    for (long r = (long)blockIdx.x * TPB + threadIdx.x; r < n; r += (long)gridDim.x * TPB) {
+        float v = (x[base + r] - mu) * is * ga + be;
         if (relu) v = fmaxf(v, 0.0f);
-        y[i] = v;
+        y[base + r] = v;
     }
 }
 
@@ -265,8 +290,7 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const float* __restr
     const long i0 = blockIdx.y * per, i1 = min(total, i0 + per);
     const float mu = mean[c], is = invstd[c];
     float a = 0.0f, b2 = 0.0f;
-    for (long i = i0 + threadIdx.x; i < i1; i += TPB) {
-        const long b = i / n, r = i - b * n;
+    EFFI_FOR_BATCH_RANGE(i0, i1, n, b, r) {
         const long e = ((long)b * C + c) * n + r;
         float g = gy[e];
         if (relu && !(y[e] > 0.0f)) g = 0.0f;
@@ -294,16 +318,31 @@ __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                            const float* __restrict__ x, int Bn, int C, long n,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           const float* __restrict__ gamma, const float* __restrict__ s1,
-                                                           const float* __restrict__ s2, int relu, float* __restrict__ gx) {
-    const long total = (long)Bn * C * n;
+                                                           const float* __restrict__ gamma, float* __restrict__ s1,
+                                                           float* __restrict__ s2, int relu, float* __restrict__ gx,
+                                                           const float* __restrict__ partial, int ns) {
     const float invN = 1.0f / (float)((long)Bn * n);
-    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long)gridDim.x * TPB) {
-        const int c = (int)((i / n) % C);
+    const int c = (int)(blockIdx.y % C);                       // grid (chunks of a plane, planes = Bn * C)
+    float t1, t2;
+    if (partial) {        // the reduce kernel's partial sums [C][ns][2]: added here (ascending order), published by the channel's first workgroup
+        t1 = t2 = 0.0f;
+        for (int j = 0; j < ns; ++j) {
+            t1 += partial[((long)c * ns + j) * 2 + 0];
+            t2 += partial[((long)c * ns + j) * 2 + 1];
+        }
+        if (blockIdx.x == 0 && blockIdx.y == (unsigned)c && threadIdx.x == 0) { s1[c] = t1; s2[c] = t2; }
+    } else {
+        t1 = s1[c];
+        t2 = s2[c];
+    }
+    const float mu = mean[c], is = invstd[c], ga = gamma[c], a1 = t1 * invN, a2 = t2 * invN;
+    const long base = (long)blockIdx.y * n;
+    for (long r = (long)blockIdx.x * TPB + threadIdx.x; r < n; r += (long)gridDim.x * TPB) {
+        const long i = base + r;
         float g = gy[i];
         if (relu && !(y[i] > 0.0f)) g = 0.0f;
-        const float xh = (x[i] - mean[c]) * invstd[c];
-        gx[i] = gamma[c] * invstd[c] * (g - s1[c] * invN - xh * (s2[c] * invN));
+        const float xh = (x[i] - mu) * is;
+        gx[i] = ga * is * (g - a1 - xh * a2);
     }
 }
 
@@ -503,9 +542,16 @@ extern "C" int effi_conv_wgrad_f32(const float* a, const float* b, int ca, int c
     if (Da < 1 || ha < 1 || wa < 1 || Db < 1 || hb < 1 || wb < 1 || sz < 1 || sz > 2 || sxy < 1 || sxy > 2) return EFFI_ERR_BADARG;
     hipStream_t s = effi_s(stream);
     const long na = (long)Da * ha * wa;
-    const int strips = (int)max(1L, min(32L, na / 4096));
+    // positions per thread: ~32 (the end-of-workgroup reduction is amortised over them), fewer when that leaves the chip short of
+    // workgroups (small maps / few channel blocks)
+    auto strips_for = [&](int cab) {
+        const long blocks = (long)((ca + cab - 1) / cab) * cb;
+        long st = max(1L, min(64L, na / 8192));
+        while (blocks * st < 768 && na / st > 2048 && st < 64) st *= 2;
+        return (int)st;
+    };
 #define EFFI_WG(KD_, KS_, CAB_)                                                                                            \
-    hipLaunchKernelGGL((wgrad_nd_kernel<KD_, KS_, CAB_>), dim3((ca + CAB_ - 1) / CAB_, cb, strips), dim3(TPB), 0, s, a, b, ca, \
+    hipLaunchKernelGGL((wgrad_nd_kernel<KD_, KS_, CAB_>), dim3((ca + CAB_ - 1) / CAB_, cb, strips_for(CAB_)), dim3(TPB), 0, s, a, b, ca, \
                        cb_total, cb_off, Da, ha, wa, Db, hb, wb, sz, sxy, dw)
     if (kd == 1 && ks == 1) EFFI_WG(1, 1, 16);
     else if (kd == 1 && ks == 3) EFFI_WG(1, 3, 8);
@@ -521,6 +567,14 @@ extern "C" int effi_conv_wgrad_f32(const float* a, const float* b, int ca, int c
 // Split reductions: nsplit workgroups per channel write partial sums to ``scratch`` ([C][nsplit][K] floats, caller-owned) and a second
 // tiny launch adds them in a fixed order; scratch == NULL or nsplit <= 1: one workgroup per channel.  Either way the order of the
 // additions is fixed: a training step's BatchNorm statistics are bitwise repeatable.
+// grid of the per-plane element-wise kernels: (chunks of a plane, planes); ~4 elements per thread, at most ~16 K workgroups in all
+static dim3 effi_plane_grid(long n, int planes) {
+    long gx = (n + 4 * TPB - 1) / (4 * TPB);
+    const long cap = max(1L, 16384L / planes);
+    if (gx > cap) gx = cap;
+    return dim3((unsigned)gx, (unsigned)planes);
+}
+
 static int effi_nsplit(const float* scratch, int nsplit) { return (scratch && nsplit > 1) ? (nsplit > 1024 ? 1024 : nsplit) : 1; }
 
 extern "C" int effi_channel_sum_f32(const float* g, int B, int C, long n, float* out, float* scratch, int nsplit, effi_stream_t stream) {
@@ -549,26 +603,28 @@ extern "C" int effi_bn_moment_f32(const float* x, int B, int C, long n, const fl
 
 // nn.BatchNorm in training mode, forward, as ONE entry (five launches: sum, mean, centred squares, variance + running statistics,
 // apply): what ops.bn_moments + torch arithmetic + ops.bn_apply did in ~17 launches.  running_mean / running_var / n_tracked may be
-// NULL (no tracking); scratch: [C][nsplit] floats (always used: nsplit >= 1).
+// NULL (no tracking); scratch: 2 x [C][nsplit] floats (always used: nsplit >= 1).
 extern "C" int effi_bn_train_fwd_f32(const float* x, int B, int C, long n, const float* gamma, const float* beta, float eps, float momentum,
                                      float* running_mean, float* running_var, long long* n_tracked, int relu, float* y, float* mean,
                                      float* invstd, float* scratch, int nsplit, effi_stream_t stream) {
     if (!x || !gamma || !beta || !y || !mean || !invstd || !scratch || B < 1 || C < 1 || n < 1 || nsplit < 1) return EFFI_ERR_BADARG;
     if ((running_mean == nullptr) != (running_var == nullptr)) return EFFI_ERR_BADARG;
+    if ((long)B * C > 65535) return EFFI_ERR_UNSUPPORTED;
     const int ns = nsplit > 1024 ? 1024 : nsplit;
     hipStream_t s = effi_s(stream);
-    const dim3 grid(C, ns), fgrid((C + 63) / 64);
+    const dim3 grid(C, ns);
     const long N = (long)B * n;
     const float nf = (float)N, unbias = (float)((double)N / (double)(N > 1 ? N - 1 : 1));
-    hipLaunchKernelGGL(bn_moment_kernel<1>, grid, dim3(TPB), 0, s, x, B, C, n, (const float*)nullptr, mean, scratch);
-    hipLaunchKernelGGL(bn_finalize_kernel, fgrid, dim3(64), 0, s, scratch, C, ns, 1, nf, eps, momentum, unbias, mean, invstd, (float*)nullptr,
-                       (float*)nullptr, (float*)nullptr, (long long*)nullptr);
-    hipLaunchKernelGGL(bn_moment_kernel<2>, grid, dim3(TPB), 0, s, x, B, C, n, (const float*)mean, invstd, scratch);
-    hipLaunchKernelGGL(bn_finalize_kernel, fgrid, dim3(64), 0, s, scratch, C, ns, 2, nf, eps, momentum, unbias, mean, invstd, (float*)nullptr,
-                       running_mean, running_var, n_tracked);
-    const long total = (long)B * C * n;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)min((total + TPB - 1) / TPB, 16384L)), dim3(TPB), 0, s, x, B, C, n, mean, invstd, gamma,
-                       beta, relu, y);
+    // three launches: sums -> centred squares (each workgroup finishes the mean from the partial sums itself) -> apply (each
+    // workgroup finishes the variance itself; the first one of a channel writes invstd and the running statistics)
+    float* part1 = scratch;
+    float* part2 = scratch + (long)C * ns;
+    hipLaunchKernelGGL(bn_moment_kernel<1>, grid, dim3(TPB), 0, s, x, B, C, n, (const float*)nullptr, mean, part1, (const float*)nullptr, 0,
+                       (float*)nullptr);
+    hipLaunchKernelGGL(bn_moment_kernel<2>, grid, dim3(TPB), 0, s, x, B, C, n, (const float*)nullptr, invstd, part2, (const float*)part1, ns,
+                       mean);
+    const BnFinish fin{part2, ns, nf, eps, momentum, unbias, invstd, running_mean, running_var, n_tracked};
+    hipLaunchKernelGGL(bn_apply_kernel, effi_plane_grid(n, B * C), dim3(TPB), 0, s, x, B, C, n, mean, invstd, gamma, beta, relu, y, fin);
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
 }
@@ -599,9 +655,9 @@ extern "C" int effi_pack_conv2d_k5s2_dgrad_f32(const float* weight, int cout, in
 extern "C" int effi_bn_apply_f32(const float* x, int B, int C, long n, const float* mean, const float* invstd, const float* gamma,
                                  const float* beta, int relu, float* y, effi_stream_t stream) {
     if (!x || !mean || !invstd || !gamma || !beta || !y || B < 1 || C < 1 || n < 1) return EFFI_ERR_BADARG;
-    const long total = (long)B * C * n;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)min((total + TPB - 1) / TPB, 16384L)), dim3(TPB), 0, effi_s(stream), x, B, C, n,
-                       mean, invstd, gamma, beta, relu, y);
+    if ((long)B * C > 65535) return EFFI_ERR_UNSUPPORTED;
+    const BnFinish off{nullptr, 0, 0.0f, 0.0f, 0.0f, 0.0f, nullptr, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(bn_apply_kernel, effi_plane_grid(n, B * C), dim3(TPB), 0, effi_s(stream), x, B, C, n, mean, invstd, gamma, beta, relu, y, off);
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
 }
@@ -610,14 +666,13 @@ extern "C" int effi_bn_bwd_f32(const float* gy, const float* y, const float* x, 
                                const float* invstd, const float* gamma, int relu, float* s1, float* s2, float* gx,
                                float* scratch, int nsplit, effi_stream_t stream) {
     if (!gy || !y || !x || !mean || !invstd || !gamma || !s1 || !s2 || !gx || B < 1 || C < 1 || n < 1) return EFFI_ERR_BADARG;
+    if ((long)B * C > 65535) return EFFI_ERR_UNSUPPORTED;
     hipStream_t s = effi_s(stream);
     const int ns = effi_nsplit(scratch, nsplit);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, ns), dim3(TPB), 0, s, gy, y, x, B, C, n, mean, invstd, relu, s1, s2,
                        ns > 1 ? scratch : nullptr);
-    if (ns > 1) hipLaunchKernelGGL(reduce_partials_kernel<2>, dim3((C + 63) / 64), dim3(64), 0, s, scratch, C, ns, s1, s2);
-    const long total = (long)B * C * n;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)min((total + TPB - 1) / TPB, 16384L)), dim3(TPB), 0, s, gy, y, x, B, C, n, mean,
-                       invstd, gamma, s1, s2, relu, gx);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, effi_plane_grid(n, B * C), dim3(TPB), 0, s, gy, y, x, B, C, n, mean, invstd, gamma, s1, s2, relu, gx,
+                       (const float*)(ns > 1 ? scratch : nullptr), ns);
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
 }

@@ -534,6 +534,21 @@ def get_depth_range_samples(cur_depth, ndepth, depth_inteval_pixel, device, dtyp
     return get_cur_depth_range_samples(cur_depth, ndepth, depth_inteval_pixel, shape, max_depth, min_depth)
 
 
+def mvs_loss_static(inputs, depth_gt_ms, mask_ms, dloss, depth_values=[425, 935], loss_rate=0.9):
+    """``mvs_loss`` without data-dependent shapes: the mean over the valid pixels as sum(loss * valid) / count instead of boolean
+    indexing (which synchronises with the host and cannot be captured into a graph).  Same value up to the order of the additions."""
+    total = torch.zeros((), dtype=torch.float32, device=mask_ms["stage1"].device)
+    per_output = {}
+    n = len(inputs)
+    for i, est in enumerate(inputs):
+        key = "stage{}".format(dloss[i])
+        valid = (mask_ms[key] > 0.5).to(est.dtype)
+        li = (F.smooth_l1_loss(est, depth_gt_ms[key], reduction="none") * valid).sum() / valid.sum()
+        per_output["l{}".format(i)] = li
+        total = total + (1.0 if i == 0 else loss_rate ** (n - i - 1)) * li
+    return total, per_output
+
+
 def mvs_loss(inputs, depth_gt_ms, mask_ms, dloss, depth_values=[425, 935], loss_rate=0.9):
     """Smooth-L1 over the cascade's outputs with geometric weights (reference: models/module.py:526-552).
     Training-side consumer of the path's outputs; plain tensor algebra."""

@@ -10,6 +10,8 @@ import functools
 import os
 import threading
 
+import weakref
+
 import torch
 
 from . import _lib
@@ -1555,8 +1557,8 @@ def bn_train_fwd(x, gamma, beta, eps, momentum, running_mean=None, running_var=N
     B, Cc = x.shape[0], x.shape[1]
     n = x.numel() // (B * Cc)
     nsplit = int(min(256, max(1, (B * n) // 8192)))
-    buf = torch.empty(Cc * (nsplit + 2), device=x.device, dtype=torch.float32)        # scratch | mean | invstd in one allocation
-    mean, invstd = buf[Cc * nsplit:Cc * (nsplit + 1)], buf[Cc * (nsplit + 1):]
+    buf = torch.empty(Cc * (2 * nsplit + 2), device=x.device, dtype=torch.float32)    # scratch (two passes) | mean | invstd in one allocation
+    mean, invstd = buf[2 * Cc * nsplit:Cc * (2 * nsplit + 1)], buf[Cc * (2 * nsplit + 1):]
     y = torch.empty_like(x)
     if running_mean is not None:
         _t(running_mean, "running_mean"), _t(running_var, "running_var")
@@ -1566,6 +1568,9 @@ def bn_train_fwd(x, gamma, beta, eps, momentum, running_mean=None, running_var=N
                                            _p(running_var), _p(n_tracked), int(relu), _p(y), _p(mean), _p(invstd), _p(buf), nsplit,
                                            _stream()), "effi_bn_train_fwd_f32")
     return y, mean, invstd
+
+
+_PACK_CACHE = {}
 
 
 def pack_conv2d_mfma_dev(weight, bias=None, dgrad=False):
@@ -1578,6 +1583,13 @@ def pack_conv2d_mfma_dev(weight, bias=None, dgrad=False):
         from . import packing
         w = weight.flip(2, 3).transpose(0, 1).contiguous() if dgrad else weight
         return packing.pack_conv2d_mfma(w, bias)
+    # a layer is applied several times per step (five images through the feature pyramid, three GRU iterations per stage): its
+    # packed weights are reused until the tensor changes (``_version`` counts in-place updates: the optimizer's) or dies
+    # (entries made outside a graph capture are not valid inside one -- the replay must re-pack -- and vice versa)
+    key = (id(weight), bool(dgrad), torch.cuda.is_current_stream_capturing())
+    hit = _PACK_CACHE.get(key)
+    if hit is not None and hit[0]() is weight and hit[1] == weight._version and hit[2] is bias and (bias is None or hit[3] == bias._version):
+        return hit[4], hit[5]
     nt, kg = (co + 15) // 16, (ci + 3) // 4
     buf = torch.empty(kg * ks * ks * nt * 64 + 16 * nt, device=weight.device, dtype=torch.float32)
     wp, bp = buf[:kg * ks * ks * nt * 64].view(kg, ks * ks, nt, 64), buf[kg * ks * ks * nt * 64:]
@@ -1585,6 +1597,9 @@ def pack_conv2d_mfma_dev(weight, bias=None, dgrad=False):
         _t(bias, "bias")
     check(_lib.lib().effi_pack_conv2d_mfma_f32(_p(weight), _p(bias), cout, cin, ks, int(dgrad), _p(wp), _p(bp), _stream()),
           "effi_pack_conv2d_mfma_f32")
+    if len(_PACK_CACHE) > 4096:
+        _PACK_CACHE.clear()
+    _PACK_CACHE[key] = (weakref.ref(weight), weight._version, bias, None if bias is None else bias._version, wp, bp)
     return wp, bp
 
 

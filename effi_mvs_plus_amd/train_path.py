@@ -108,10 +108,17 @@ def projection_input(enc, disp, cost, context):
     return A.dropout2d(x, enc.dropout.p) if enc.dropout is not None else x          # update.py:97-98 (training)
 
 
-def conv_gru(gru, h, *xs):
+def gru_gate_weights(gru):
+    """convz | convr as ONE convolution (they read the same input, update.py:43-46): weights and biases concatenated along the output
+    channels -- once per update block, so the three iterations share the packed operands and the gradient comes back through one
+    slice.  Forward, input gradient and both weight gradients then run once instead of twice."""
+    return torch.cat([gru.convz.weight, gru.convr.weight]), torch.cat([gru.convz.bias, gru.convr.bias])
+
+
+def conv_gru(gru, h, *xs, gates=None):
     xs = list(xs)
-    z = A.conv2d([h] + xs, gru.convz.weight, gru.convz.bias, SIGMOID)
-    r = A.conv2d([h] + xs, gru.convr.weight, gru.convr.bias, SIGMOID)
+    wzr, bzr = gates if gates is not None else gru_gate_weights(gru)
+    z, r = A.split_channels(A.conv2d([h] + xs, wzr, bzr, SIGMOID), gru.convz.out_channels)
     q = A.conv2d([A._Mul.apply(r, h)] + xs, gru.convq.weight, gru.convq.bias, TANH)
     return A._GruCombine.apply(z, h, q)
 
@@ -131,10 +138,11 @@ def mask_head(block, net):
 def update_block(block, net, cost_fn, inv_depth, context, seq_len):
     """BasicUpdateBlock.forward (models/update.py:114-141): ``cost_fn(inv_depth, i)`` -> [B,2*nq,h,w]."""
     inv_list, mask_list = [], []
+    gates = gru_gate_weights(block.depth_gru)
     for i in range(seq_len):
         inv_depth = inv_depth.detach()                                              # update.py:121
         x = projection_input(block.encoder, inv_depth, cost_fn(inv_depth, i), context)
-        net = conv_gru(block.depth_gru, net, x)
+        net = conv_gru(block.depth_gru, net, x, gates=gates)
         inv_depth = inv_depth + depth_head(block.depth_head, net)
         inv_list.append(inv_depth)
         mask_list.append(mask_head(block, net) if (block.UpMask and i == seq_len - 1) else inv_depth)
@@ -166,9 +174,14 @@ def hot_path(model, features, cnet_depth, proj_matrices, depth_values):
     """Training-mode ``forward_hot``: same interface and outputs."""
     B, n_range = depth_values.shape
     lo, hi = depth_values[:, 0], depth_values[:, -1]
-    if B > 1 and (not torch.equal(lo, lo[:1].expand_as(lo)) or not torch.equal(hi, hi[:1].expand_as(hi))):
+    if B > 1 and getattr(model, "static_depth_range", None) is None and (not torch.equal(lo, lo[:1].expand_as(lo))
+                                                                         or not torch.equal(hi, hi[:1].expand_as(hi))):
         raise NotImplementedError("training path: the samples of a batch must share their depth range (DTU training does)")
-    lo_f, hi_f = float(lo[0]), float(hi[0])
+    static_range = getattr(model, "static_depth_range", None)
+    if static_range is not None:        # graph capture (train_graph.GraphedTrainStep): the range is a constant of the captured step
+        lo_f, hi_f = static_range
+    else:
+        lo_f, hi_f = float(lo[0]), float(hi[0])
     d_nums = model.depth_stage_nums
     base_itv = (hi - lo) / n_range                                                  # :424
     hyp1, _ = zip(*[ops.stage1_hypotheses(depth_values[b].contiguous(), d_nums[0]) for b in range(B)])

@@ -480,8 +480,8 @@ int effi_bn_apply_f32(const float* x, int B, int C, long n, const float* mean, c
 /* The forward of nn.BatchNorm2d / 3d in training mode as one entry (models/module.py:148-157,191-200,217-220 under model.train()):
  * mean / invstd [C] (outputs, kept for the backward) from the two moment passes, y = BN(x) (+ ReLU), and -- when running_mean /
  * running_var are given -- nn.BatchNorm's running-statistic update with ``momentum`` (unbiased variance) and num_batches_tracked += 1
- * (n_tracked: the module's int64 counter, or NULL).  scratch: [C][nsplit] floats, nsplit >= 1 workgroups per channel (partials are
- * added in ascending order: bitwise repeatable). */
+ * (n_tracked: the module's int64 counter, or NULL).  scratch: 2 x [C][nsplit] floats, nsplit >= 1 workgroups per channel (partials
+ * are added in ascending order: bitwise repeatable). */
 int effi_bn_train_fwd_f32(const float* x, int B, int C, long n, const float* gamma, const float* beta, float eps, float momentum,
                           float* running_mean, float* running_var, long long* n_tracked, int relu, float* y, float* mean,
                           float* invstd, float* scratch, int nsplit, effi_stream_t stream);

@@ -452,3 +452,70 @@ def test_optimizer_step_reduces_the_loss():
     with torch.no_grad():
         after = net(imgs, pm, dv)["depth"][-1]
     assert torch.isfinite(after).all() and not torch.equal(after, target)
+
+
+def test_graphed_training_step_replays_the_eager_step():
+    """train_graph.GraphedTrainStep: forward -> mvs_loss_static -> backward -> AdamW captured into one HIP graph.  Three replays on
+    three different samples against three eager steps of an identical model: the losses (steps 2 and 3 see the weights the graph's
+    optimizer wrote) and the parameters agree to what the atomics of the weight-gradient kernels allow; BatchNorm's counters advance
+    once per replay; the static loss equals the reference's boolean-indexing loss."""
+    import copy
+    from effi_mvs_plus_amd import train_graph
+    from effi_mvs_plus_amd.models import mvs_loss
+    from effi_mvs_plus_amd.models.module import mvs_loss_static
+    H, W, N = 128, 160, 3
+    net, _ = build_model("8,8,8", seed=4, device=DEV)
+    net.train()
+    drops = [m for m in net.modules() if isinstance(m, torch.nn.Dropout2d)]
+    p_drop = [m.p for m in drops]
+    for m in drops:
+        m.p = 0.0                                  # deterministic comparison first; dropout inside the graph is checked at the end
+    ref = copy.deepcopy(net)
+    DL = list(train_graph.DLOSS)
+
+    def sample(seed):
+        imgs, pm, dv = synth.synth_sample(H, W, N, seed=seed)
+        g = torch.Generator().manual_seed(seed)
+        gt, mask = {}, {}
+        for k, f in (("stage1", 8), ("stage2", 4), ("stage3", 2), ("stage4", 1)):
+            gt[k] = (synth.DEPTH_MIN_MM + (synth.DEPTH_MAX_MM - synth.DEPTH_MIN_MM) * torch.rand(1, H // f, W // f, generator=g)).to(DEV)
+            mask[k] = (torch.rand(1, H // f, W // f, generator=g) > 0.3).float().to(DEV)
+        return imgs.to(DEV), {k: v.to(DEV) for k, v in pm.items()}, dv.to(DEV), gt, mask
+
+    samples = [sample(s) for s in (31, 32, 33)]
+    lr = 1e-4
+    opt_e = torch.optim.AdamW(ref.parameters(), lr=lr, capturable=True)
+    eager = []
+    for imgs, pm, dv, gt, mask in samples:
+        opt_e.zero_grad(set_to_none=True)
+        out = ref(imgs, pm, dv)["depth"]
+        loss, _ = mvs_loss_static(out, gt, mask, DL)
+        with torch.no_grad():
+            want, _ = mvs_loss([o.detach() for o in out], gt, mask, DL)
+        assert abs(float(loss) - float(want)) <= 1e-5 * abs(float(want))          # the static loss IS the reference's loss
+        loss.backward()
+        opt_e.step()
+        eager.append(float(loss))
+    opt_g = torch.optim.AdamW(net.parameters(), lr=lr, capturable=True)
+    step = train_graph.GraphedTrainStep(net, opt_g, *samples[0])
+    nbt0 = int(net.feature.conv0[0].bn.num_batches_tracked)
+    got = [float(step(*smp)) for smp in samples]
+    for a, b in zip(got, eager):
+        assert abs(a - b) <= 2e-4 * abs(b), (got, eager)
+    assert int(net.feature.conv0[0].bn.num_batches_tracked) == nbt0 + 3 * N
+    worst = max(float((p - q).abs().max()) for p, q in zip(net.parameters(), ref.parameters()))
+    assert worst <= 3 * 3 * lr                                      # AdamW moves a weight by at most ~lr per step
+    close = sum(int(((p - q).abs() <= 0.05 * lr).sum()) for p, q in zip(net.parameters(), ref.parameters()))
+    total = sum(p.numel() for p in net.parameters())
+    assert close >= 0.97 * total, (close, total)                    # (ill-conditioned gradients near zero flip Adam's sign for a few)
+    for (k, a), (_, b) in zip(net.named_buffers(), ref.named_buffers()):
+        if a.dtype.is_floating_point:
+            assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max())), k
+    # dropout inside a captured step: every replay draws new masks (the generator's offset advances per replay)
+    if any(p > 0 for p in p_drop):
+        for m, p in zip(drops, p_drop):
+            m.p = p
+        opt_d = torch.optim.AdamW(net.parameters(), lr=0.0, weight_decay=0.0, capturable=True)
+        step_d = train_graph.GraphedTrainStep(net, opt_d, *samples[0])
+        a, b = float(step_d()), float(step_d())
+        assert a != b and abs(a - b) < 0.9 * max(a, b)

@@ -61,6 +61,15 @@ def main():
     hip_ms = timed(hip_step, 5)
     print(f"HIP training step {W}x{H} N={N} B={B}: {hip_ms:.1f} ms  ({B * 1e3 / hip_ms:.1f} samples/s)")
 
+    if not os.environ.get("BENCH_TRAIN_NO_GRAPH"):
+        # the same step (static loss, capturable AdamW) captured into one HIP graph and replayed: no per-launch host work
+        from effi_mvs_plus_amd import train_graph
+        opt_g = torch.optim.AdamW(net.parameters(), lr=1e-5, capturable=True)
+        step = train_graph.GraphedTrainStep(net, opt_g, imgs, pm, dv, gt, mask)
+        graph_ms = timed(lambda: step(), 10)
+        print(f"HIP training step, graph replay (train_graph.GraphedTrainStep): {graph_ms:.1f} ms  ({B * 1e3 / graph_ms:.1f} samples/s)")
+        del step
+
     if os.environ.get("BENCH_TRAIN_HIP_ONLY"):
         return
     # stock PyTorch-ROCm: autograd through the oracle's training-mode op sequence, leaves = one tensor per parameter

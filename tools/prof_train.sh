@@ -3,7 +3,7 @@
 tag=${1:-t}
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
-cd /tmp && export TMPDIR=/tmp && export BENCH_TRAIN_HIP_ONLY=1
+cd /tmp && export TMPDIR=/tmp && export BENCH_TRAIN_HIP_ONLY=1 && export BENCH_TRAIN_NO_GRAPH=1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_train_$tag -o p -- python3 $R/tools/bench_train.py > $R/gpurun_out/prof_train_$tag.log 2>&1 || { tail -20 $R/gpurun_out/prof_train_$tag.log; exit 1; }
 cd $R
 grep "HIP training step" gpurun_out/prof_train_$tag.log
