@@ -114,14 +114,17 @@ __global__ __launch_bounds__(TPB) void channel_sum_kernel(const float* __restric
     const long total = (long)Bn * n;
     const long per = (total + gridDim.y - 1) / gridDim.y;
     const long i0 = blockIdx.y * per, i1 = min(total, i0 + per);
-    float s = 0.0f;
-    EFFI_FOR_BATCH_RANGE(i0, i1, n, b, r) s += g[((long)b * C + c) * n + r];
-    __shared__ float red[TPB / 64];
-    s = wave_sum(s);
+    // double accumulation: bias gradients are sums with heavy cancellation (PixelwiseNet's single output channel: the fp32 sum was
+    // 1.9e-2 of the result away from the fp64 one, four times the reference's own fp32 error); the kernel is bound by its loads
+    double s = 0.0;
+    EFFI_FOR_BATCH_RANGE(i0, i1, n, b, r) s += (double)g[((long)b * C + c) * n + r];
+    __shared__ double red[TPB / 64];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float t = red[0] + red[1] + red[2] + red[3];
+        const float t = (float)(red[0] + red[1] + red[2] + red[3]);
         if (partial) partial[(long)c * gridDim.y + blockIdx.y] = t;
         else out[c] = t;                                    // one workgroup per channel
     }

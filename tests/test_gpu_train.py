@@ -401,6 +401,12 @@ def test_training_step_matches_autograd_through_the_oracle(B, N):
         assert p_.grad is not None, f"{k}: no gradient"
         e_hip = rel(p_.grad, leaves64[k].grad)
         e_ref = rel(leaves32[k].grad, leaves64[k].grad)
+        # 5e-2 of the gradient's peak, or twice what the reference's own fp32 pass is away from fp64.  Tightening this to 1e-2 was
+        # tried in round 3 and is NOT met: the distance of individual gradients moves between runs of the SAME arithmetic with
+        # ulp-level differences in the BatchNorm means -- old three-kernel BatchNorm: worst 6.5e-3, all-gradient L2 3.9e-4; the same
+        # with every mean moved by one ulp: 4.6e-3 / 7.7e-6; the one-entry BatchNorm of round 3 (outputs equal to the old ones to
+        # 1e-6 in every one of the 74 calls, no ReLU decision differs): CSP_C1.conv1.conv.weight 3.6e-2, PixelwiseNet.3.bias 1.3-2.1e-2.
+        # Something downstream amplifies 1e-6 to 1e-2 for a few parameters; not located (training section).
         bound = max(5e-2, 2 * e_ref)
         n += 1
         n_plain += e_hip <= 1e-3
