@@ -906,13 +906,15 @@ __device__ __forceinline__ void conv3d_roll_rp_bf16x3_body(const Conv2dArgs a, i
     constexpr int CSH = (NOCT == 2) ? 2 : 0;                           // columns dropped on the left of the fetched 24
     constexpr int APIX = AR * AW, NQ = AR * AQ, NITEMS = NQ * NOCT;
     constexpr int NIT = 36 * NOCT, NKS = NIT / 4;
-    constexpr int NBF = NKS * 2 * 64;                                  // 16-byte units of B (one N-tile)
     constexpr int SLOT = NOCT * APIX * 8;                              // bf16 elements per plane slot
     constexpr int MP = MR / 2;
     static_assert(NITEMS <= 256, "one staging item per thread");
+    // The weight fragments live in REGISTERS (9 NOCT K-steps x (hi, lo) x 4 VGPRs = 72 NOCT): a wave re-read all of them from LDS for
+    // every output plane -- half of the kernel's LDS traffic, and LDS bandwidth is what bounds it (per workgroup and plane 295 KB
+    // of fragment reads = 2,300 clocks at 128 B/clk against 860 clocks of MFMA; measured 2,100).  Without the 37 KB weight image a
+    // workgroup needs 38 KB of LDS and occupancy is set by registers.
     __shared__ __attribute__((aligned(16))) unsigned short lds_ah[3 * SLOT];
     __shared__ __attribute__((aligned(16))) unsigned short lds_al[3 * SLOT];
-    __shared__ __attribute__((aligned(16))) unsigned short lds_b[NBF * 8];
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -934,7 +936,10 @@ __device__ __forceinline__ void conv3d_roll_rp_bf16x3_body(const Conv2dArgs a, i
     const float* s_src = (soct * 8 < a.ch[0]) ? a.src[0] + (long)(soct * 8) * a.cstride
                                               : a.src[1] + (long)(soct * 8 - a.ch[0]) * a.cstride;
 
-    f32x4 pa[2][8];
+    // planes in flight in registers: ONE (fetched one output plane ahead).  With a second buffer (two planes ahead, the form of the
+    // kernel below) the 16-channel instantiation passes 256 registers (one workgroup per CU) and the 8-channel one drops from 3 to 2
+    constexpr int NBUF = 1;
+    f32x4 pa[NBUF][8];
     auto prefetch = [&](auto buf_t, int z) {
         constexpr int bf = decltype(buf_t)::value;
         const bool ok = (s_off >= 0) & (z >= 0) & (z < D);
@@ -957,11 +962,14 @@ __device__ __forceinline__ void conv3d_roll_rp_bf16x3_body(const Conv2dArgs a, i
         }
     };
     using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
+    bf16x8 breg_h[NKS], breg_l[NKS];
     {
         const unsigned short* wbf = reinterpret_cast<const unsigned short*>(a.wpack);
-        for (int u = tid; u < NBF; u += 256)
-            *reinterpret_cast<float4*>(&lds_b[u * 8]) = *reinterpret_cast<const float4*>(wbf + (long)u * 8);
+#pragma unroll
+        for (int s_ = 0; s_ < NKS; ++s_) {
+            breg_h[s_] = *reinterpret_cast<const bf16x8*>(wbf + ((long)(s_ * 2 + 0) * 64 + lane) * 8);
+            if (!kHiOnly) breg_l[s_] = *reinterpret_cast<const bf16x8*>(wbf + ((long)(s_ * 2 + 1) * 64 + lane) * 8);
+        }
     }
     // item 4 s + lk = (dz, dy, dx, oct): element offset inside a slot, dz in the low bits
     int kconst[NKS];
@@ -975,19 +983,20 @@ __device__ __forceinline__ void conv3d_roll_rp_bf16x3_body(const Conv2dArgs a, i
     const int lane_base = ((wv * MR) * AW + li + XOFF) * 8;
 
     f32x4 acc[MP];
+    using BL = std::integral_constant<int, NBUF - 1>;                  // the second buffer, or the only one
     prefetch(B0{}, z0 - 1);
-    prefetch(B1{}, z0);
+    if (NBUF == 2) prefetch(BL{}, z0);
     stash(B0{}, 0);
-    prefetch(B0{}, z0 + 1);
-    stash(B1{}, 1);
-    prefetch(B1{}, z0 + 2);
+    prefetch(B0{}, NBUF == 2 ? z0 + 1 : z0);
+    stash(BL{}, 1);
+    prefetch(BL{}, NBUF == 2 ? z0 + 2 : z0 + 1);
     int rot = 0;
     auto plane = [&](auto bt, int z) {
         int s2 = rot + 2;
         s2 -= (s2 >= 3) ? 3 : 0;
         stash(bt, s2);
         __syncthreads();
-        if (z + 2 < z1) prefetch(bt, z + 3);
+        if (z + NBUF < z1) prefetch(bt, z + NBUF + 1);
         int s1 = rot + 1;
         s1 -= (s1 >= 3) ? 3 : 0;
         const int rb0 = rot * SLOT, rb1 = s1 * SLOT, rb2 = s2 * SLOT;
@@ -997,9 +1006,8 @@ __device__ __forceinline__ void conv3d_roll_rp_bf16x3_body(const Conv2dArgs a, i
         for (int s_ = 0; s_ < NKS; ++s_) {
             const int dz = kconst[s_] & 3;
             const int off = lane_base + (kconst[s_] >> 2) + (dz == 0 ? rb0 : (dz == 1 ? rb1 : rb2));
-            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&lds_b[((s_ * 2 + 0) * 64 + lane) * 8]);
-            bf16x8 bl = bh;
-            if (!kHiOnly) bl = *reinterpret_cast<const bf16x8*>(&lds_b[((s_ * 2 + 1) * 64 + lane) * 8]);
+            const bf16x8 bh = breg_h[s_];
+            const bf16x8 bl = kHiOnly ? bh : breg_l[s_];
 #pragma unroll
             for (int m = 0; m < MP; ++m) {
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&lds_ah[off + m * 2 * AW * 8]);
@@ -1024,7 +1032,7 @@ __device__ __forceinline__ void conv3d_roll_rp_bf16x3_body(const Conv2dArgs a, i
     };
     for (int z = z0; z < z1; z += 2) {
         plane(B0{}, z);
-        if (z + 1 < z1) plane(B1{}, z + 1);
+        if (z + 1 < z1) plane(BL{}, z + 1);
     }
 }
 
@@ -2417,10 +2425,12 @@ static int launch_roll(const Conv2dArgs& a, hipStream_t st, const Conv2dArgs* pa
     // the window), 1.3x as much with 4 rows per wave as with 2.  E.g. 8->8 at 48x148x200: MR 4 / ZT 6 (1040 workgroups, 3
     // rounds) 74 us, MR 2 / ZT 16 (741 workgroups, 1 round) 55 us.
     const int cols = effi_cdiv(a.w, 16), D = a.zcount;
+    const bool rp = NT == 1 && a.cout <= 8 && effi_option(EFFI_OPT_ROLL_RP) != 0;      // row-pair operand (see conv3d_roll_rp_bf16x3_body)
     int mr = 2, zt = D;
     double best = 1e30;
     for (int m = 2; m <= 4; m += 2) {
-        const int occ = (NOCT == 1 && NT == 1) ? (m == 2 ? 3 : 2) : (NOCT == 1 ? 2 : (NT == 1 && m == 2 ? 2 : 1));
+        // (row-pair kernels, weights in registers: 3 workgroups per CU with 8 input channels, 2 with 16, whatever MR)
+        const int occ = rp ? (NOCT == 1 ? 3 : 2) : (NOCT == 1 && NT == 1) ? (m == 2 ? 3 : 2) : (NOCT == 1 ? 2 : (NT == 1 && m == 2 ? 2 : 1));
         const long tiles_m = (long)cols * effi_cdiv(a.h, 4 * m), slots = 256L * occ;
         for (int nz = 1; nz <= D; ++nz) {
             const int z = effi_cdiv(D, nz);
@@ -2435,7 +2445,7 @@ static int launch_roll(const Conv2dArgs& a, hipStream_t st, const Conv2dArgs* pa
     const long tiles = (long)cols * effi_cdiv(a.h, 4 * mr);
     const dim3 grid((unsigned)tiles, (unsigned)effi_cdiv(D, zt), pair ? 2 : 1);
     // (option roll_rp = 0, with packing.py: the one-row-per-tile operand, A/B runs)
-    if (NT == 1 && a.cout <= 8 && effi_option(EFFI_OPT_ROLL_RP) != 0) {     // row-pair operand (see conv3d_roll_rp_bf16x3_body)
+    if (rp) {
         if (pair) {
             if (mr == 4) hipLaunchKernelGGL((conv3d_roll_rp_bf16x3_pair_kernel<NOCT, 4>), grid, dim3(256), 0, st, a, *pair, cols, (int)tiles, zt);
             else hipLaunchKernelGGL((conv3d_roll_rp_bf16x3_pair_kernel<NOCT, 2>), grid, dim3(256), 0, st, a, *pair, cols, (int)tiles, zt);
