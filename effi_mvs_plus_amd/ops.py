@@ -98,7 +98,7 @@ def _x3(name):
 # forms) in the library's own table (include/effi_mvs_hip.h: effi_set_option).  Both are initialised ONCE from the environment
 # (EFFI_<NAME>) and changed afterwards through ``set_option`` -- nothing on a per-call path reads the environment.
 _PY_OPTION_DEFAULTS = {"c1k7_mfma": 1, "k5s2_split": 1, "roll": 1, "conv3d_unaligned_split": 1, "conv3d_s2_split": 1, "fpn_conv0_fused": 1,
-                       "fpn_split_head": 1, "csp_pair": 1, "head_taps": 1, "enc_tail": 0, "enc_gen": 1}
+                       "fpn_split_head": 1, "csp_pair": 1, "head_taps": 1, "enc_tail": 0, "enc_gen": 1, "reduce_chunk": 2048}
 _PY_OPTS = {k: int(os.environ.get("EFFI_" + k.upper(), v)) for k, v in _PY_OPTION_DEFAULTS.items()}
 LIB_OPTIONS = ("warp_lds_kb", "dyn_form", "dyn_setup_exact", "dyn_xchg", "pixnet_mfma", "force_mr", "mr4_min", "mr4_nt2_max", "mr2_min",
                "wide_tiles", "roll_mr", "roll_zt", "roll_rp", "deconv_mr", "sr_waves")
@@ -1516,10 +1516,14 @@ def conv2d_k5s2_dgrad_mfma(grad_out, weight, hin, win):
     return gx if (2 * ho, 2 * wo) == (hin, win) else gx[:, :hin, :win].contiguous()
 
 
+# elements per workgroup of the split per-channel reductions.  8192 left the chip short of workgroups (8 channels x 40 workgroups at
+# 512x640: 1.25 per CU, 27 us for a 31-MB pass); 2048 = 8 elements per thread
+# (option reduce_chunk; graph-replayed training step 28.6 -> 26.3 ms)
+
 def _reduce_split(total, channels, k=1, device=None):
-    """Workgroups per channel of the split per-channel reductions and their scratch ([C][nsplit][k] floats): ~8 K elements per
+    """Workgroups per channel of the split per-channel reductions and their scratch ([C][nsplit][k] floats): ~2 K elements per
     workgroup, at most 256 per channel, none when the tensor is small.  The partial sums are added in a fixed order (second launch)."""
-    nsplit = int(min(256, max(1, total // 8192)))
+    nsplit = int(min(256, max(1, total // _PY_OPTS["reduce_chunk"])))
     if nsplit <= 1:
         return None, 1
     return torch.empty(channels * nsplit * k, device=device, dtype=torch.float32), nsplit
@@ -1556,7 +1560,7 @@ def bn_train_fwd(x, gamma, beta, eps, momentum, running_mean=None, running_var=N
     _t(x, "bn input"), _t(gamma, "bn weight"), _t(beta, "bn bias")
     B, Cc = x.shape[0], x.shape[1]
     n = x.numel() // (B * Cc)
-    nsplit = int(min(256, max(1, (B * n) // 8192)))
+    nsplit = int(min(256, max(1, (B * n) // _PY_OPTS["reduce_chunk"])))
     buf = torch.empty(Cc * (2 * nsplit + 2), device=x.device, dtype=torch.float32)    # scratch (two passes) | mean | invstd in one allocation
     mean, invstd = buf[2 * Cc * nsplit:Cc * (2 * nsplit + 1)], buf[Cc * (2 * nsplit + 1):]
     y = torch.empty_like(x)

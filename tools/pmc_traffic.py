@@ -42,6 +42,11 @@ def key_of(name):
     if m:
         wide, sr = m.group(3) == "true", m.group(4) == "true"
         return f"conv2d_k3x3_pair_nt{m.group(1)}", ((2.0 if wide else 1.5) if sr else ({1: 1.0, 2: 1.25, 4: 1.5}.get(int(m.group(2)), 1.0) if wide else 1.0))
+    m = re.match(r"conv2d_k3_bf16x3_encgen_pair_kernel<(\d+)", n)
+    if m:
+        # reads: 4-byte lanes along the rows of the cost volumes / the inverse-depth map (x2, as encoder_inputs); its writes are
+        # the 16-byte split-resident stores
+        return f"conv2d_k3x3_encgen_nt{m.group(1)}", 2.0
     if n.startswith("encoder_inputs_kernel"):
         return "encoder_inputs", 2.0                                                   # 4 B per lane, 256-byte runs of the cost volumes
     m = re.match(r"conv3d_roll(?:_rp)?_bf16x3_pair_kernel<(\d+)", n)
