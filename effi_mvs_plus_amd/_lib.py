@@ -85,6 +85,7 @@ SIGNATURES = {
                                       _i, _vp, _vp, _i, _i, _vp],
     "effi_encoder_pair_gen_bf16x3_sr": [_vp, _vp, _i, _vp, _vp, _l, _l, _i, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp, _vp,
                                         _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "effi_gru_zr_q_fused_bf16x3_sr": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "effi_conv2d_k3_bf16x3_sr": [_vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "effi_conv2d_k3_bf16x3_pair_sr": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "effi_conv2d_k3_k1_bf16x3_sr": [_vp, _vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
@@ -114,7 +115,7 @@ BF16X3_ENTRIES = ("effi_conv2d_k3_bf16x3_pair_f32", "effi_conv2d_k3_bf16x3_f32",
                   "effi_conv3d_k3s1_roll_bf16x3_pair_f32", "effi_deconv3d_k3s2_bf16x3_f32", "effi_encoder_tail_bf16x3_f32", "effi_conv2d_k3_twice_bf16x3_f32",
                   "effi_conv2d_k5s2_bf16x3_f32", "effi_conv3d_k3s2_bf16x3_f32",
                   "effi_conv2d_k3_bf16x3_sr", "effi_conv2d_k3_bf16x3_pair_sr", "effi_conv2d_k3_k1_bf16x3_sr", "effi_conv2d_k3_k1_up2x_bf16x3_sr",
-                  "effi_encoder_pair_gen_bf16x3_sr")
+                  "effi_encoder_pair_gen_bf16x3_sr", "effi_gru_zr_q_fused_bf16x3_sr")
 for _n in BF16X3_ENTRIES:
     SIGNATURES[_n + "_bf16"] = SIGNATURES[_n]
 

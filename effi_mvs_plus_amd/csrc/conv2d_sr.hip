@@ -208,3 +208,5 @@ extern "C" int EFFI_FN(effi_conv2d_k3_k1_up2x_bf16x3_sr)(const void* const* srcs
         default: return EFFI_ERR_UNSUPPORTED;
     }
 }
+
+#include "gru_fused.hpp"

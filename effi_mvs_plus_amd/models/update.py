@@ -296,8 +296,9 @@ class BasicUpdateBlock(nn.Module):
         A, B, Cm, Dm, Hm = maps
         if not net_sr_ready:
             ops.sr_from_planar(net, out=Hm)
-        zh_buf = torch.empty(max(hd, 9), h, w, device=dev, dtype=torch.float32)       # z, then (z is dead) the head's 9 tap planes
-        z_buf, head_buf = zh_buf[:hd], zh_buf[:9]
+        gru_fused = hd <= 16 * ops.option("gru_fused")          # option gru_fused: 0 off, 1 = hd 16, 2 = hd 16 and 32
+        zh_buf = torch.empty(9 if gru_fused else max(hd, 9), h, w, device=dev, dtype=torch.float32)   # z, then (z is dead) the head's 9 tap planes
+        z_buf, head_buf = (None if gru_fused else zh_buf[:hd]), zh_buf[:9]
         h_own = net if net_owned else None       # fp32 state we may write: each lane reads h[p] and writes h'[p] of its own pixel
         e = self.encoder
         wc1, bc1 = e.convc1_raw()
@@ -315,6 +316,9 @@ class BasicUpdateBlock(nn.Module):
         wh2, bh2 = dh._c2t.get([dh.conv2.weight], lambda: packing.pack_head_taps(dh.conv2.weight, hd))
         inv_list, mask_list, depth_list = [], [], []
         gen_pair = ops.option("enc_gen") != 0 and getattr(lookup, "encoder_pair_sr", None) is not None
+        H_first = Hm
+        h_pp = [None, net if net_owned else None]               # fp32 state buffers of the fused form: iteration i writes h_pp[i % 2]
+                                                                # (iteration 0 reads the caller's ``net``; it is reused from iteration 1 on if ours)
         for i in range(seq_len):
             if gen_pair:                       # cor1 / dfm1 generated inside the pair kernel: cor -> C, dfm -> D in one launch
                 lookup.encoder_pair_sr(inv_depth, wc1, bc1, w7, b7, hd, wc2.wx, bc2, Cm, wd2.wx, bd2, Dm)
@@ -322,12 +326,22 @@ class BasicUpdateBlock(nn.Module):
                 lookup.encoder_inputs_sr(inv_depth, wc1, bc1, w7, b7, hd, A, B)                        # cor1 -> A, dfm1 -> B
                 ops.conv2d_k3_pair_sr([A], wc2.wx, bc2, Cm, [B], wd2.wx, bd2, Dm, hd, act=ops.ACT_RELU)  # cor -> C, dfm -> D
             ops.conv2d_k3_k1_sr([Cm, Dm], wd.wx, bd, cmix, context, wca, bca, hd, relu=True, out_sr=A)   # x -> A (cor1 is dead)
-            z, _ = ops.conv2d_k3_sr([Hm, A], wzr.wx, bzr, 2 * hd, epilogue=ops.EPI_GRU_ZR, aux0=net, out0=z_buf, out_sr=B)   # r*h -> B
-            # the new state overwrites H in place (no launch reads H between the z / r convolution and here), and so does its fp32
-            # copy once it lives in a buffer of ours
-            if h_own is None:
-                h_own = torch.empty(hd, h, w, device=dev, dtype=torch.float32)
-            net, _ = ops.conv2d_k3_sr([B, A], wq.wx, bq, hd, epilogue=ops.EPI_GRU_Q, aux0=net, aux1=z, out0=h_own, out_sr=Hm)
+            if gru_fused:
+                # ConvGRU as one launch (csrc/gru_fused.hpp): r * h and z stay on chip.  A workgroup reads its neighbours' pixels of
+                # the state, so the state ping-pongs between two buffers in both forms (H <-> B as SR maps; two fp32 maps)
+                h_next = h_pp[i % 2]
+                if h_next is None or h_next.data_ptr() == net.data_ptr():
+                    h_next = h_pp[i % 2] = torch.empty(hd, h, w, device=dev, dtype=torch.float32)
+                H_next = B if Hm is not B else H_first
+                net, _ = ops.gru_zr_q_fused_sr(Hm, A, net, wzr.wx, bzr, wq.wx, bq, h_next, H_next)
+                Hm = H_next
+            else:
+                z, _ = ops.conv2d_k3_sr([Hm, A], wzr.wx, bzr, 2 * hd, epilogue=ops.EPI_GRU_ZR, aux0=net, out0=z_buf, out_sr=B)   # r*h -> B
+                # the new state overwrites H in place (no launch reads H between the z / r convolution and here), and so does its fp32
+                # copy once it lives in a buffer of ours
+                if h_own is None:
+                    h_own = torch.empty(hd, h, w, device=dev, dtype=torch.float32)
+                net, _ = ops.conv2d_k3_sr([B, A], wq.wx, bq, hd, epilogue=ops.EPI_GRU_Q, aux0=net, aux1=z, out0=h_own, out_sr=Hm)
             want_mask = self.UpMask and i == seq_len - 1
             fused_up = want_mask and fuse_upsample
             if want_mask and not fused_up:

@@ -98,7 +98,7 @@ def _x3(name):
 # forms) in the library's own table (include/effi_mvs_hip.h: effi_set_option).  Both are initialised ONCE from the environment
 # (EFFI_<NAME>) and changed afterwards through ``set_option`` -- nothing on a per-call path reads the environment.
 _PY_OPTION_DEFAULTS = {"c1k7_mfma": 1, "k5s2_split": 1, "roll": 1, "conv3d_unaligned_split": 1, "conv3d_s2_split": 1, "fpn_conv0_fused": 1,
-                       "fpn_split_head": 1, "csp_pair": 1, "head_taps": 1, "enc_tail": 0, "enc_gen": 1, "reduce_chunk": 2048}
+                       "fpn_split_head": 1, "csp_pair": 1, "head_taps": 1, "enc_tail": 0, "enc_gen": 1, "reduce_chunk": 2048, "gru_fused": 0}
 _PY_OPTS = {k: int(os.environ.get("EFFI_" + k.upper(), v)) for k, v in _PY_OPTION_DEFAULTS.items()}
 LIB_OPTIONS = ("warp_lds_kb", "dyn_form", "dyn_setup_exact", "dyn_xchg", "pixnet_mfma", "force_mr", "mr4_min", "mr4_nt2_max", "mr2_min",
                "wide_tiles", "roll_mr", "roll_zt", "roll_rp", "deconv_mr", "sr_waves")
@@ -1207,6 +1207,23 @@ def conv2d_k3_sr(srcs, wpack, bias, cout, epilogue=EPI_PLAIN, act=ACT_NONE, aux0
                 _int_array([m.channels for m in srcs]), len(srcs), _p(wpack), _p(bias), cout, h, w, g.hp, g.wp, epilogue, act,
                 _p(aux0), _p(aux1), _p(out0), _p(out_sr.t), _stream()), "effi_conv2d_k3_bf16x3_sr")
     return (out0, out_sr) if out0 is not None else out_sr
+
+
+def gru_zr_q_fused_sr(H_in, X, h_in, wzr_pack, bias_zr, wq_pack, bias_q, h_out, H_out):
+    """ConvGRU in one launch (csrc/gru_fused.hpp): SR maps ``H_in`` (state) and ``X`` (encoder output), fp32 state ``h_in`` ->
+    (``h_out`` fp32, ``H_out`` SR); outputs must be other buffers than the inputs.  Bitwise equal to ``conv2d_k3_sr(GRU_ZR)`` +
+    ``conv2d_k3_sr(GRU_Q)``."""
+    g = _sr_srcs([H_in, X, H_out])
+    hd, h, w = g.channels, g.h, g.w
+    _t(h_in, "h"), _t(h_out, "h_out")
+    if tuple(h_in.shape) != (hd, h, w) or tuple(h_out.shape) != (hd, h, w) or X.channels != hd or H_out.channels != hd:
+        raise ValueError("gru_zr_q_fused_sr: state / input maps must hold hd channels of one size")
+    if h_out.data_ptr() == h_in.data_ptr() or H_out.t.data_ptr() in (H_in.t.data_ptr(), X.t.data_ptr()):
+        raise ValueError("gru_zr_q_fused_sr: outputs must not alias inputs")
+    work = lambda: {"flops": 2.0 * h * w * 9 * (2 * hd * 2 * hd + 2 * hd * hd), "bytes": 4.0 * h * w * 5 * hd}
+    check(_call(f"gru_fused_nt{hd // 16}", work, _x3("effi_gru_zr_q_fused_bf16x3_sr"), _p(H_in.t), _p(X.t), _p(h_in), _p(wzr_pack), _p(bias_zr),
+                _p(wq_pack), _p(bias_q), hd, h, w, g.hp, g.wp, _p(h_out), _p(H_out.t), _stream()), "effi_gru_zr_q_fused_bf16x3_sr")
+    return h_out, H_out
 
 
 def conv2d_k3_pair_sr(srcs_a, wpack_a, bias_a, out_a, srcs_b, wpack_b, bias_b, out_b, cout, act=ACT_NONE):

@@ -681,6 +681,14 @@ int effi_conv2d_k3_k1_up2x_bf16x3_sr(const void* const* srcs, const int* src_cha
                                      const float* bias, int cout1, const void* w2pack_bf16, const float* bias2, const float* inv_depth,
                                      const float* disp_range, int n_range, int h, int w, int hp, int wp, float* out_depth,
                                      float* out_depth_inv, effi_stream_t stream);
+/* ConvGRU (models/update.py:33-49) as ONE launch on split-resident maps: z | r = sigmoid(convzr([h, x])), q = tanh(convq([r * h, x])),
+ * h' = (1 - z) h + z q; r * h and z never reach memory (csrc/gru_fused.hpp).  H_in / X: SR maps of hd channels; h_in fp32 [hd][h][w];
+ * wzr_pack / bias_zr: convz | convr as one layer (cout 2 hd), wq_pack / bias_q: convq, both in effi_conv2d_k3_bf16x3_f32's operand
+ * order; outputs h_out (fp32) and H_out (SR) must NOT alias the inputs (a workgroup reads its neighbours' pixels).  hd in {16, 32}.
+ * Bitwise equal to effi_conv2d_k3_bf16x3_sr(GRU_ZR) + (GRU_Q). */
+int effi_gru_zr_q_fused_bf16x3_sr(const void* H_in, const void* X, const float* h_in, const void* wzr_pack, const float* bias_zr,
+                                  const void* wq_pack, const float* bias_q, int hd, int h, int w, int hp, int wp, float* h_out,
+                                  void* H_out, effi_stream_t stream);
 /* the convolution entries above with plain bf16 operands (hi only; precision "bf16"): the lo planes are neither read nor written */
 int effi_conv2d_k3_bf16x3_sr_bf16(const void* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16, const float* bias,
                                   int cout, int h, int w, int hp, int wp, int epilogue, int act, const float* aux0, const float* aux1,
@@ -697,6 +705,9 @@ int effi_conv2d_k3_k1_up2x_bf16x3_sr_bf16(const void* const* srcs, const int* sr
                                           const float* bias, int cout1, const void* w2pack_bf16, const float* bias2,
                                           const float* inv_depth, const float* disp_range, int n_range, int h, int w, int hp, int wp,
                                           float* out_depth, float* out_depth_inv, effi_stream_t stream);
+int effi_gru_zr_q_fused_bf16x3_sr_bf16(const void* H_in, const void* X, const float* h_in, const void* wzr_pack, const float* bias_zr,
+                                       const void* wq_pack, const float* bias_q, int hd, int h, int w, int hp, int wp, float* h_out,
+                                       void* H_out, effi_stream_t stream);
 int effi_encoder_pair_gen_bf16x3_sr_bf16(const float* inv_depth, const float* disp_range, int n_range, const float* interval,
                                          const float* cur_vol, long cds, long cps, int Dcur, const float* reg_vol, long rds, long rps,
                                          int Dreg, const float* dmin, const float* dmax, long range_ps, int nq, int h, int w,

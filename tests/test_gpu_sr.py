@@ -199,6 +199,46 @@ def test_generated_encoder_pair_is_bitwise_the_two_launches(model, precision, h,
         ops.set_precision(before)
 
 
+@pytest.mark.parametrize("precision", ["split", "bf16"])
+@pytest.mark.parametrize("h,w", [(20, 28), (37, 52), (74, 100), (148, 200), (29, 15)])
+def test_fused_conv_gru_is_bitwise_the_two_launches(model, precision, h, w):
+    """``gru_zr_q_fused_sr`` (z | r convolution, r * h, q convolution and the state update in one kernel, r * h and z on chip) against
+    ``conv2d_k3_sr(GRU_ZR)`` + ``conv2d_k3_sr(GRU_Q)``: every bit of the new state in both forms (fp32 map, split-resident map incl.
+    its untouched zero border), for hd = 32 and 16, map sizes that cut the 14 x 14 output tiles everywhere."""
+    from effi_mvs_plus_amd import ops
+    from effi_mvs_plus_amd.models.update import _pack
+    net, _ = model
+    g = torch.Generator().manual_seed(3 * h + w)
+    before = ops.get_precision()
+    try:
+        ops.set_precision(precision)
+        for s in (1, 2):
+            hd = net.hdim_stage[s]
+            gru = net.update_block[s].depth_gru
+            wzr, bzr = gru._packed_zr()
+            wq, bq = _pack(gru._cq, gru.convq)
+            hcur = torch.tanh(torch.randn(hd, h, w, generator=g)).to(DEV)
+            x = torch.relu(torch.randn(hd, h, w, generator=g)).to(DEV)
+            maps = ops.sr_alloc(5, hd, h, w, DEV, clear=False)
+            for m in maps:
+                m.t.fill_(9.0)
+            ops.sr_clear_border([maps])
+            Hm, Xm, RH, H1, H2 = maps
+            ops.sr_from_planar(hcur, out=Hm)
+            ops.sr_from_planar(x, out=Xm)
+            z, _ = ops.conv2d_k3_sr([Hm, Xm], wzr.wx, bzr, 2 * hd, epilogue=ops.EPI_GRU_ZR, aux0=hcur, out_sr=RH)
+            want, _ = ops.conv2d_k3_sr([RH, Xm], wq.wx, bq, hd, epilogue=ops.EPI_GRU_Q, aux0=hcur, aux1=z, out_sr=H1)
+            got = torch.full_like(hcur, 7.0)
+            ops.gru_zr_q_fused_sr(Hm, Xm, hcur, wzr.wx, bzr, wq.wx, bq, got, H2)
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), f"hd {hd}: fp32 state differs ({int((got != want).sum())} values)"
+            assert torch.equal(H1.t, H2.t), f"hd {hd}: split-resident state differs"
+            with pytest.raises(ValueError):
+                ops.gru_zr_q_fused_sr(Hm, Xm, hcur, wzr.wx, bzr, wq.wx, bq, hcur, H2)          # in place: refused
+    finally:
+        ops.set_precision(before)
+
+
 @pytest.mark.parametrize("H,W,N,nd", [(128, 160, 4, "8,8,8"), (192, 256, 5, "48,8,8"), (320, 416, 3, "48,32,8")])
 @pytest.mark.parametrize("precision", ["split", "bf16"])
 def test_cascade_is_bitwise_unchanged_by_split_resident_maps(H, W, N, nd, precision):
@@ -222,11 +262,17 @@ def test_cascade_is_bitwise_unchanged_by_split_resident_maps(H, W, N, nd, precis
             assert ops.uses_sr()
             got = net.forward_hot(feats, ctx, pm, dv)
             inter = net.forward_hot(feats, ctx, pm, dv, want_intermediates=True)       # unfused mask head on the fp32 state
+            with ops.options(gru_fused=2):                                              # ConvGRU as one launch at hd 16 and 32 (option; default off)
+                got_f = net.forward_hot(feats, ctx, pm, dv)
+            with ops.options(enc_gen=0):                                                # encoder inputs as maps instead of generated in the pair kernel
+                got_e = net.forward_hot(feats, ctx, pm, dv)
     finally:
         ops.set_precision(before)
         ops.set_sr(True)
     for i, (a, b) in enumerate(zip(got["depth"], want["depth"])):
         assert torch.equal(a, b), f"depth map {i} differs"
+        assert torch.equal(got_f["depth"][i], b), f"depth map {i} differs with the one-launch ConvGRU"
+        assert torch.equal(got_e["depth"][i], b), f"depth map {i} differs with encoder-input maps"
     assert torch.equal(got["photometric_confidence"], want["photometric_confidence"])
     for a, b in zip(inter["depth"], want_inter["depth"]):     # (the unfused mask head evaluates its softmax with expf: its own pair)
         assert torch.equal(a, b)
