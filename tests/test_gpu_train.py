@@ -525,3 +525,41 @@ def test_graphed_training_step_replays_the_eager_step():
         step_d = train_graph.GraphedTrainStep(net, opt_d, *samples[0])
         a, b = float(step_d()), float(step_d())
         assert a != b and abs(a - b) < 0.9 * max(a, b)
+
+
+@pytest.mark.parametrize("cout,cin,ks", [(16, 8, 3), (12, 20, 3), (64, 32, 1), (8, 3, 5), (48, 33, 3)])
+def test_device_weight_packing_equals_the_host_form(cout, cin, ks):
+    """effi_pack_conv2d_mfma_f32 (one launch per layer and step in training) against packing.pack_conv2d_mfma: forward order with and
+    without bias, input-gradient order (in / out swapped, taps flipped) -- every element, padding included; cached until the weight changes."""
+    from effi_mvs_plus_amd import ops, packing
+    g = torch.Generator().manual_seed(cout + cin)
+    W = torch.randn(cout, cin, ks, ks, generator=g).to(DEV)
+    b = torch.randn(cout, generator=g).to(DEV)
+    for bias in (b, None):
+        wp, bp = ops.pack_conv2d_mfma_dev(W, bias)
+        w0, b0 = packing.pack_conv2d_mfma(W, bias)
+        assert torch.equal(wp.reshape(-1), w0.reshape(-1)) and torch.equal(bp, b0)
+    wp, bp = ops.pack_conv2d_mfma_dev(W, None, dgrad=True)
+    w0, b0 = packing.pack_conv2d_mfma(W.flip(2, 3).transpose(0, 1).contiguous(), None)
+    assert torch.equal(wp.reshape(-1), w0.reshape(-1)) and torch.equal(bp, b0)
+    again, _ = ops.pack_conv2d_mfma_dev(W, None, dgrad=True)
+    assert again.data_ptr() == wp.data_ptr()                       # cache hit: same tensor, same version
+    W.mul_(2.0)                                                     # an in-place update (the optimizer's) invalidates it
+    fresh, _ = ops.pack_conv2d_mfma_dev(W, None, dgrad=True)
+    assert torch.equal(fresh.reshape(-1), (2.0 * w0).reshape(-1))
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(8, 16, 32, 40), (3, 8, 31, 45), (32, 64, 16, 20), (12, 16, 10, 14)])
+def test_k5s2_input_gradient_on_the_matrix_cores(cin, cout, h, w):
+    """conv2d_k5s2_dgrad_mfma (3x3 convolution over the output gradient with the four pixel parities as output channels + pixel
+    shuffle) against the direct vector kernel and torch's conv_transpose formulation, odd sizes included."""
+    from effi_mvs_plus_amd import ops
+    g = torch.Generator().manual_seed(cin * 7 + h)
+    W = (torch.randn(cout, cin, 5, 5, generator=g) / math.sqrt(cin * 25)).to(DEV)
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    gy = torch.randn(cout, ho, wo, generator=g).to(DEV)
+    got = ops.conv2d_k5s2_dgrad_mfma(gy, W, h, w)
+    direct = ops.conv2d_k5s2_dgrad(gy, W, h, w)
+    want = torch.nn.grad.conv2d_input((1, cin, h, w), W.cpu().double(), gy.cpu().double()[None], stride=2, padding=2)[0]
+    assert tuple(got.shape) == (cin, h, w)
+    assert rel(got, want.float()) <= 2e-6 and rel(direct, want.float()) <= 2e-6
