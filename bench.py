@@ -46,6 +46,8 @@ def family_of(key):
     of one template are one family -- the roofline brackets the family with the largest share of a view, not its largest key."""
     if key.startswith(("conv2d_k3x3", "conv2d_k3k1")):        # conv2d_k3_bf16x3_kernel / _pair_kernel, every NT / MR / epilogue
         return "conv2d_k3_bf16x3"
+    if key.startswith("encgen_pair"):                         # conv2d_k3_bf16x3_encgen_pair_kernel: its own template (lookup + 1x1 / 7x7 + 3x3)
+        return "encgen_pair"
     return key
 
 

@@ -1166,7 +1166,7 @@ def encoder_pair_gen_sr(x, disp_range, interval, cur_vol, reg_vol, dmin, dmax, n
     if (g.channels, g.h, g.w) != (cout, h, w) or tuple(x.shape[-2:]) != (h, w):
         raise ValueError("encoder_pair_gen_sr: output maps must be [cout,h,w]")
     work = lambda: {"flops": 2.0 * h * w * ((2 * nq + 49) * hd + 2 * 9 * hd * cout), "bytes": 4.0 * h * w * (2 * cout + 1 + Dc + Dr)}
-    check(_call(f"conv2d_k3x3_encgen_nt{(cout + 15) // 16}", work, _x3("effi_encoder_pair_gen_bf16x3_sr"), _p(x), _p(disp_range),
+    check(_call(f"encgen_pair_nt{(cout + 15) // 16}", work, _x3("effi_encoder_pair_gen_bf16x3_sr"), _p(x), _p(disp_range),
                 disp_range.numel(), _p(interval), _p(cur_vol), cds, cps, Dc, _p(reg_vol), rds, rps, Dr, _p(dmin_t), _p(dmax_t), gps, nq,
                 h, w, _p(weight_c1), _p(bias_c1), _p(weight_d1), _p(bias_d1), hd, _p(wpack_c2), _p(bias_c2), _p(out_c2.t), _p(wpack_d2),
                 _p(bias_d2), _p(out_d2.t), cout, g.hp, g.wp, act, _stream()), "effi_encoder_pair_gen_bf16x3_sr")

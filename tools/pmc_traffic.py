@@ -46,7 +46,7 @@ def key_of(name):
     if m:
         # reads: 4-byte lanes along the rows of the cost volumes / the inverse-depth map (x2, as encoder_inputs); its writes are
         # the 16-byte split-resident stores
-        return f"conv2d_k3x3_encgen_nt{m.group(1)}", 2.0
+        return f"encgen_pair_nt{m.group(1)}", 2.0
     if n.startswith("encoder_inputs_kernel"):
         return "encoder_inputs", 2.0                                                   # 4 B per lane, 256-byte runs of the cost volumes
     m = re.match(r"conv3d_roll(?:_rp)?_bf16x3_pair_kernel<(\d+)", n)
@@ -96,7 +96,7 @@ def key_of(name):
 
 # families whose dominant read shape is one of the calibrated ones (see the module docstring)
 CALIBRATED = {"encoder_inputs", "deconv3d_x3", "getcost_conv1x1", "warpcorr_views_c32", "warpcorr_dyn_c8", "warpcorr_dyn_c16", "head_update"}
-CALIBRATED_PREFIXES = ("conv2d_k3x3", "conv3d_x3", "conv3d_roll", "conv2d_k3k1")
+CALIBRATED_PREFIXES = ("conv2d_k3x3", "conv3d_x3", "conv3d_roll", "conv2d_k3k1", "encgen_pair")
 
 
 def collect(path):
