@@ -29,6 +29,7 @@ enum EffiOption {
     EFFI_OPT_ROLL_MR, EFFI_OPT_ROLL_ZT, EFFI_OPT_ROLL_RP,         // rolling 3-D convolution: rows per wave, planes per workgroup, row-pair operand
     EFFI_OPT_DECONV_MR,          // transposed 3-D convolution: rows per wave
     EFFI_OPT_SR_WAVES,           // split-resident 3x3 convolutions: 8 = 512-thread workgroups where the rule picks 1 or 2 rows per wave
+    EFFI_OPT_ENC_GEN_MR3,        // generated-input pair kernel: 0 = 4 rows per wave where the rule says so (default: 3)
     EFFI_OPT_COUNT
 };
 constexpr long EFFI_OPT_UNSET = -0x7fffffffL;

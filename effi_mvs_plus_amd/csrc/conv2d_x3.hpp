@@ -850,9 +850,13 @@ static int launch_bf16x3_encgen_pair(const Conv2dArgs& a0, const Conv2dArgs& a1,
     // always 16-column tiles: the generated image pays per STAGED pixel (24 volume taps each), and a 4 x 64 tile stages 1.55 x its
     // pixels against 1.27 x for 16 x 16 (592x800, hd 16: 55 us per launch with wide tiles, 47 us without; the loaded form gains 5 %
     // from wide tiles)
+    // "4 rows per wave" is 3 here: 14 x 18 = 252 staged pixels are ONE lookup per thread; 18 x 18 = 324 make 68 threads do a second
+    // one while 188 wait (option enc_gen_mr3 = 0: 4 rows)
+    if (mr == 4 && effi_opt_or(EFFI_OPT_ENC_GEN_MR3, 1) != 0) mr = 3;
     const int tiles_x = (int)cols, ntiles = tiles_x * effi_cdiv(a0.h, 4 * mr);
     const dim3 grid(ntiles, 2);
     if (mr == 4) hipLaunchKernelGGL((conv2d_k3_bf16x3_encgen_pair_kernel<NT, 4, false>), grid, dim3(256), 0, st, a0, a1, g, tiles_x, ntiles);
+    else if (mr == 3) hipLaunchKernelGGL((conv2d_k3_bf16x3_encgen_pair_kernel<NT, 3, false>), grid, dim3(256), 0, st, a0, a1, g, tiles_x, ntiles);
     else if (mr == 2) hipLaunchKernelGGL((conv2d_k3_bf16x3_encgen_pair_kernel<NT, 2, false>), grid, dim3(256), 0, st, a0, a1, g, tiles_x, ntiles);
     else hipLaunchKernelGGL((conv2d_k3_bf16x3_encgen_pair_kernel<NT, 1, false>), grid, dim3(256), 0, st, a0, a1, g, tiles_x, ntiles);
     return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
