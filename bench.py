@@ -77,18 +77,21 @@ def path_work(H, W, N, nd):
 
 def run_cfg5(args, torch, dist, rank, world, dev):
     """BASELINE.json cfg5: every (scan, reference view) of an evaluation set, sharded contiguously over the ranks.
-    Inside the timed region, per item: feature pyramid of each image the rank has not seen in this scan (effi_mvs_plus_amd.scan_eval.
-    ScanFeatureCache: an image is the source of ~4 other views), context pyramid of the reference image, one hipGraph replay of the hot
-    path, copy of the two output maps into the gather's staging batch; every ``--gather-batch`` views one asynchronous gather to
-    rank 0.  Strong scaling: the set is fixed, N ranks split it."""
+    Inside the timed region, per item (effi_mvs_plus_amd.scan_eval.ScanRunner): the synthetic image and feature pyramid of each image
+    the rank has not seen in this scan (an image is the source of ~4 other views) on a producer stream; on one of ``--cfg5-slots``
+    lanes the reference image written into the slot, one small launch that points the slot's view table at the cached maps, one
+    hipGraph replay of context pyramid + hot path, copies of the two output maps into the gather's staging batch; every
+    ``--gather-batch`` views one asynchronous gather to rank 0.  Strong scaling: the set is fixed, N ranks split it.  After the timed
+    region a sample of the gathered views is recomputed one at a time, eagerly, and must equal the gathered maps bitwise."""
     from common import build_model
     from effi_mvs_plus_amd import _lib, ops, scan_eval, synth
-    from effi_mvs_plus_amd.graph import HotPathGraph
     _lib.lib()
     if args.precision:
         ops.set_precision(args.precision)
     precision = ops.get_precision()
     H, W, N, nd = WORKLOADS["cfg5"]
+    if args.cfg5_size:
+        W, H = (int(v) for v in args.cfg5_size.lower().split("x"))
     net, _ = build_model(nd, seed=1, device=dev)
     items = scan_eval.build_items(args.cfg5_scans, args.cfg5_images, N - 1)
     _, pm, dv = synth.synth_sample(H, W, N, seed=0)          # one rig for every item: view 0 = the reference, 1.. = its sources
@@ -96,40 +99,50 @@ def run_cfg5(args, torch, dist, rank, world, dev):
     dv = dv.to(dev)
     distributed = world > 1
 
-    def image(scan, img):                                      # a synthetic "decoded image", generated on the device
+    def image(scan, img, out=None):                            # a synthetic "decoded image", generated on the device
         g = torch.Generator(device=dev).manual_seed(100003 * scan + img)
-        return torch.rand(1, 3, H, W, device=dev, generator=g)
+        if out is None:
+            return torch.rand(1, 3, H, W, device=dev, generator=g)
+        return out.uniform_(0.0, 1.0, generator=g)
 
     with torch.no_grad():
-        feats = scan_eval.ScanFeatureCache(lambda s_, i_: net.feature(image(s_, i_)))
-        f0 = [net.feature(image(0, v)) for v in range(N)]
-        c0 = net.cnet_depth(image(0, 0))
-        graph = HotPathGraph(net, f0, c0, pm, dv, slots=1)
-        del f0, c0
+        runner = scan_eval.ScanRunner(net, image, (10 ** 6, 0, tuple(range(1, N))), pm, dv, slots=args.cfg5_slots)
         torch.cuda.synchronize()
-
-        def forward(item):
-            scan, ref, srcs = item
-            f = [feats.get(scan, ref)] + [feats.get(scan, v) for v in srcs]
-            ctx = net.cnet_depth(image(scan, ref))
-            out = graph(f, ctx, pm, dv)                        # device-to-device copy into the static slot + one graph launch
-            return out["depth"][-1][0], out["photometric_confidence"][0]
-
         # untimed warm-up on a scan of its own (same shapes; its cache entries are dropped by the first timed item)
-        for it in scan_eval.build_items(1, min(args.cfg5_images, max(args.warmup, N + 1)), N - 1)[:max(1, args.warmup)]:
-            forward((10 ** 6, it[1], it[2]))
-        feats.hits = feats.misses = feats.max_entries = 0
+        warm = [(10 ** 6, it[1], it[2]) for it in scan_eval.build_items(1, min(args.cfg5_images, max(args.warmup, N + 1)), N - 1)]
+        for j, it in enumerate(warm[:max(1, args.warmup)]):
+            with torch.cuda.stream(runner.lanes[j % runner.slots]):
+                runner(it, j % runner.slots)
         torch.cuda.synchronize()
+        runner.cache.hits = runner.cache.misses = runner.cache.max_entries = 0
+        runner.n_images_prepared = 0
         torch.cuda.reset_peak_memory_stats()
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        res, n_mine = scan_eval.run_scans(items, forward, gather_batch=args.gather_batch, dst=0, to_host=(distributed and args.backend != "nccl"))
+        res, n_mine = scan_eval.run_scans(items, runner, gather_batch=args.gather_batch, dst=0, to_host=(distributed and args.backend != "nccl"))
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        feats = runner.cache
+        # a sample of this rank's views again, one at a time, eagerly, from freshly computed pyramids: bitwise the gathered maps?
+        n_checked = n_bad = 0
+        if rank == 0 and res is not None and args.cfg5_check > 0:
+            lo, hi = scan_eval.shard_bounds(len(items), 0, world)
+            picks = sorted({lo + (hi - 1 - lo) * k // max(args.cfg5_check - 1, 1) for k in range(args.cfg5_check)})
+            br0 = ops.get_branches()
+            ops.set_branches(False)
+            for i_ in picks:
+                scan, ref, srcs = items[i_]
+                f = [net.feature(image(scan, v)) for v in (ref,) + tuple(srcs)]
+                o = net.forward_hot(f, net.cnet_depth(image(scan, ref)), pm, dv)
+                ok_d = torch.equal(o["depth"][-1][0], res["depth"][i_].to(dev))
+                ok_c = torch.equal(o["photometric_confidence"][0], res["confidence"][i_].to(dev))
+                n_checked += 1
+                n_bad += 0 if (ok_d and ok_c) else 1
+            ops.set_branches(br0)
     peak = torch.cuda.max_memory_allocated()
     stats = torch.tensor([dt, float(peak), float(feats.misses), float(feats.hits), float(n_mine)], dtype=torch.float64,
                          device=dev if (not distributed or args.backend == "nccl") else "cpu")
@@ -142,7 +155,8 @@ def run_cfg5(args, torch, dist, rank, world, dev):
         mx = sm = stats
     if rank == 0:
         dt = float(mx[0])
-        ok = res is not None and res["depth"].shape[0] == len(items) and bool(torch.isfinite(res["depth"]).all())
+        ok = res is not None and res["depth"].shape[0] == len(items) and bool(torch.isfinite(res["depth"]).all()) \
+            and bool(torch.isfinite(res["confidence"]).all())
         print(json.dumps({
             "metric": "ref-views/sec (whole evaluation set: pyramids + cost-volume hot path + batched gather to rank 0)",
             "value": len(items) / dt, "unit": "views/s", "n_gpus": world, "steps": len(items), "warmup": max(1, args.warmup),
@@ -151,7 +165,9 @@ def run_cfg5(args, torch, dist, rank, world, dev):
             "config": {"workload": f"cfg5: {args.cfg5_scans} scans x {args.cfg5_images} reference views = {len(items)} items at {W}x{H}, N={N} "
                                    f"(S={N - 1} sources from a ring pair list), ndepths={nd}, GRU iters 3,3,3, seeded-random weights, synthetic images "
                                    "generated on the device inside the timed region",
-                       "launch": "per item: pyramids of uncached images (eager), context pyramid, one hipGraph replay of the hot path",
+                       "launch": f"{runner.slots} reference views in flight (one lane = stream + captured hipGraph of context pyramid + hot path "
+                                 "each); feature pyramids of uncached images eagerly on a producer stream; the graph reads the item's cached "
+                                 "feature maps through a device pointer table (no copy into static inputs)",
                        "parallelism": (f"items sharded contiguously over {world} ranks, {'RCCL' if args.backend == 'nccl' else 'gloo (rehearsal)'} "
                                        f"gather of depth + confidence to rank 0 every {args.gather_batch} views, asynchronous, inside the timed region")
                                       if world > 1 else "single GPU (same code path: staging batches, no collective)"},
@@ -160,11 +176,16 @@ def run_cfg5(args, torch, dist, rank, world, dev):
                               "note": "an image's feature pyramid is computed once per rank and scan and reused while it is a source view"},
             "hbm_high_water_bytes_max_over_ranks": int(mx[1]),
             "gathered_on_rank0": {"depth": list(res["depth"].shape), "confidence": list(res["confidence"].shape), "finite": ok},
+            "recomputed_one_at_a_time": {"views": n_checked, "differing_bitwise": n_bad,
+                                         "note": "rank 0's sample of gathered views against an eager single-stream forward from fresh pyramids"},
             "scaling_curve": "NOT measured by this run: one run is one N.  Comparing N = 1, 2, 4, 8 needs the driver's multi-GPU node; "
                              "no efficiency is claimed here" if world == 1 else "one point of the curve (this N); efficiency is the driver's to compute",
         }))
         if not ok:
             sys.exit(4)
+        if n_bad:
+            print(f"[bench] {n_bad} of {n_checked} recomputed views differ bitwise from the gathered maps", file=sys.stderr)
+            sys.exit(3)
 
 
 def self_launch(n, backend, ndev):
@@ -226,6 +247,10 @@ def main():
     ap.add_argument("--cfg5-scans", type=int, default=22, help="--workload cfg5: scans in the evaluation set (DTU test list: 22)")
     ap.add_argument("--cfg5-images", type=int, default=49, help="--workload cfg5: images = reference views per scan (DTU: 49)")
     ap.add_argument("--gather-batch", type=int, default=8, help="--workload cfg5: views per asynchronous gather to rank 0")
+    ap.add_argument("--cfg5-slots", type=int, default=3, help="--workload cfg5: reference views in flight per rank (lanes)")
+    ap.add_argument("--cfg5-check", type=int, default=6, help="--workload cfg5: gathered views recomputed one at a time after the timed "
+                                                               "region and compared bitwise (0 = skip)")
+    ap.add_argument("--cfg5-size", default=None, help="--workload cfg5: WxH instead of 1600x1184 (rehearsals)")
     ap.add_argument("--fusion-torch-baseline", action="store_true",
                     help="also time the reference's fusion op sequence on the GPU (element-wise 3x3 algebra instead of the 19 M-batch "
                          "GEMM that faulted in round 1); opt-in, never part of the default run")

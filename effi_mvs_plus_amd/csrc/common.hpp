@@ -43,7 +43,17 @@ static inline int effi_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 struct EffiPtrList {            // by-value kernel argument: device pointers of the source views
     const float* p[EFFI_MAX_VIEWS + 1];
+    // View-table form (effi_*_tbl_f32 entries): non-null = the pointers live in DEVICE memory, tbl[0] = the reference map,
+    // tbl[1 + v] = source view v (EFFI_MAX_VIEWS + 2 entries, unused ones null).  A captured hipGraph bakes kernel arguments in, a
+    // table it reads at run time does not: the evaluation-set runner (scan_eval.py) points a replay at the cached feature maps of
+    // its (reference, sources) item instead of copying 150 MB of them into static inputs.
+    const float* const* tbl;
 };
+// the reference map of a forward warp kernel, whichever form the launch uses (uniform select; nothing is copied: a mutable copy of
+// the list costs the kernels a private segment and 8-18 registers)
+__device__ __forceinline__ const float* effi_resolve_views(const float* ref, const EffiPtrList& l) {
+    return l.tbl ? l.tbl[0] : ref;
+}
 struct EffiOutList {
     float* p[EFFI_MAX_VIEWS + 1];
 };

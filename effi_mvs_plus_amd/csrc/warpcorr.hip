@@ -25,12 +25,16 @@ template <int C> struct WarpGeom {
     static constexpr int TH = PIX / TW;               // tile height (4, 4, 8)
 };
 
-__device__ __forceinline__ const float* pick_view(const EffiPtrList& l, int v) {
+__device__ __forceinline__ const float* pick_view_list(const EffiPtrList& l, int v) {
     const float* p = l.p[0];
 #pragma unroll
     for (int i = 1; i <= EFFI_MAX_VIEWS; ++i)
         if (v == i) p = l.p[i];
     return p;
+}
+__device__ __forceinline__ const float* pick_view(const EffiPtrList& l, int v) {
+    if (l.tbl) return l.tbl[1 + v];                   // view-table form (uniform branch, scalar load)
+    return pick_view_list(l, v);
 }
 
 struct Taps {
@@ -143,12 +147,13 @@ __device__ __forceinline__ bool tile_pixel(int bid, int nblk, int h, int w, int&
 // stage 1: per-view similarity volume + softmax entropy over D   (grid.y = source view)
 // ------------------------------------------------------------------------------------------------
 template <int C>
-__global__ __launch_bounds__(256) void warpcorr_views_kernel(const float* __restrict__ ref, EffiPtrList srcs,
+__global__ __launch_bounds__(256) void warpcorr_views_kernel(const float* ref_arg, EffiPtrList srcs,
                                                              const float* __restrict__ rt_all,
                                                              const float* __restrict__ depth, long dds, long dps,
                                                              int h, int w, int D, float* sim_views,
                                                              float* __restrict__ entropy) {
     using G = WarpGeom<C>;
+    const float* __restrict__ ref = effi_resolve_views(ref_arg, srcs);
     int x, y, sub;
     if (!tile_pixel<C>(blockIdx.x, gridDim.x, h, w, x, y, sub)) return;
     const int view = blockIdx.y;
@@ -415,12 +420,15 @@ __device__ __forceinline__ void win_choose_chunk(const float* __restrict__ rt, c
     (void)ng;
 }
 
+// The kernel's body takes its two maps as restrict-qualified PARAMETERS: both launch forms (pointers in the kernel arguments /
+// pointers read from a device table, TBL) then compile to the same code.  With the table's loads feeding plain locals this kernel,
+// which sits at its 128-register cap, lost the no-alias information and spilled 96 bytes per lane.
 template <int MAXPX>
-__global__ __launch_bounds__(WIN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void warpcorr_views_win_kernel(const float* __restrict__ ref, EffiPtrList srcs,
-                                                                         const float* __restrict__ rt_all,
-                                                                         const float* __restrict__ depth, long dds,
-                                                                         int h, int w, int D, float* sim_views,
-                                                                         float* __restrict__ entropy, int lds_px) {
+__device__ __forceinline__ void warpcorr_views_win_body(const float* __restrict__ ref, const float* __restrict__ src,
+                                                        const float* __restrict__ rt_all,
+                                                        const float* __restrict__ depth, long dds,
+                                                        int h, int w, int D, float* sim_views,
+                                                        float* __restrict__ entropy, int lds_px) {
     constexpr int C = 32, MAXD = 256;
     __shared__ float4 win4[(MAXPX > 0 ? MAXPX : 1) * 8];
     __shared__ float hyp[MAXD + 4];
@@ -435,7 +443,6 @@ __global__ __launch_bounds__(WIN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     const bool valid = (x < w) & (y < h);
     const int xs = min(x, w - 1), ys = min(y, h - 1);          // out-of-image lanes shadow the border pixel (no stores)
     const int view = blockIdx.y;
-    const float* __restrict__ src = pick_view(srcs, view);
     const float* __restrict__ rt = rt_all + view * 12;
     const int hw = h * w, pix = ys * w + xs;
     // the hypotheses (shared by all pixels) once into LDS, padded with the last one to a multiple of 4
@@ -524,6 +531,15 @@ __global__ __launch_bounds__(WIN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
     }
     e = effi_group_sum<4>(e);
     if (sub == 0) entropy[(long)view * hw + pix] = e;
+}
+
+template <int MAXPX, bool TBL>
+__global__ __launch_bounds__(WIN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void warpcorr_views_win_kernel(
+    const float* __restrict__ ref_arg, EffiPtrList srcs, const float* __restrict__ rt_all, const float* __restrict__ depth, long dds,
+    int h, int w, int D, float* sim_views, float* __restrict__ entropy, int lds_px) {
+    const int view = blockIdx.y;
+    warpcorr_views_win_body<MAXPX>(TBL ? srcs.tbl[0] : ref_arg, TBL ? srcs.tbl[1 + view] : pick_view_list(srcs, view), rt_all, depth, dds,
+                                   h, w, D, sim_views, entropy, lds_px);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -668,7 +684,7 @@ __global__ __launch_bounds__(WIN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 // stages 2/3: hypotheses around the current depth, all views, view-weighted aggregate
 // ------------------------------------------------------------------------------------------------
 template <int C, bool NODPP = true, bool SHFL = false, bool FAST = false>
-__global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* __restrict__ ref, EffiPtrList srcs, int S,
+__global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* ref_arg, EffiPtrList srcs, int S,
                                                            const float* __restrict__ rt_all,
                                                            const float* __restrict__ cur_depth,
                                                            const float* __restrict__ interval,
@@ -676,6 +692,7 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* __restri
                                                            int h, int w, int D, float* __restrict__ sim,
                                                            float* __restrict__ samples) {
     using G = WarpGeom<C>;
+    const float* __restrict__ ref = effi_resolve_views(ref_arg, srcs);
     int x, y, sub;
     if (!tile_pixel<C>(blockIdx.x, gridDim.x, h, w, x, y, sub)) return;
     const int hw = h * w, pix = y * w + x, sub4 = 4 * sub;
@@ -822,7 +839,7 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* __restri
 // so a pixel's D x S set-ups are computed exactly once, and nothing crosses lanes (no exchange, no reduction).  Same FAST set-up
 // arithmetic as above; the channel sum runs over C in one lane (a different association than 4 + butterfly: ~1e-7 relative).
 template <int C>
-__global__ __launch_bounds__(256) void warpcorr_dyn_hyp_kernel(const float* __restrict__ ref, EffiPtrList srcs, int S,
+__global__ __launch_bounds__(256) void warpcorr_dyn_hyp_kernel(const float* ref_arg, EffiPtrList srcs, int S,
                                                                const float* __restrict__ rt_all,
                                                                const float* __restrict__ cur_depth,
                                                                const float* __restrict__ interval,
@@ -830,6 +847,7 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_hyp_kernel(const float* __re
                                                                int h, int w, int D, float* __restrict__ sim,
                                                                float* __restrict__ samples) {
     using G = WarpGeom<C>;
+    const float* __restrict__ ref = effi_resolve_views(ref_arg, srcs);
     int x, y, sub;
     if (!tile_pixel<C>(blockIdx.x, gridDim.x, h, w, x, y, sub)) return;
     const int hw = h * w, pix = y * w + x;
@@ -1100,6 +1118,7 @@ template <int C> int grid_blocks(int h, int w) {
 }
 
 bool fill_views(const float* const* src, int S, EffiPtrList& l) {
+    l.tbl = nullptr;
     if (!src || S < 1 || S > EFFI_MAX_VIEWS) return false;
     for (int i = 0; i <= EFFI_MAX_VIEWS; ++i) l.p[i] = nullptr;
     for (int i = 0; i < S; ++i) {
@@ -1152,19 +1171,29 @@ static int warp_lds_px() {
     return min(WIN_MAXPX, (int)(kb * 1024 / 128));
 }
 
-extern "C" int effi_warpcorr_views_f32(const float* ref_nhwc, const float* const* src_nhwc, int S, const float* rt,
-                                       const float* depth, long dds, long dps, int C, int h, int w, int D,
-                                       float* sim_views, float* entropy, effi_stream_t stream) {
-    EffiPtrList l;
-    if (!fill_views(src_nhwc, S, l) || !ref_nhwc || !rt || !depth || !sim_views || !entropy) return EFFI_ERR_BADARG;
+// A view table (device memory, EFFI_MAX_VIEWS + 2 pointers: reference, sources, nulls) as the kernels' view list
+static bool fill_table(const float* const* table_dev, int S, EffiPtrList& l) {
+    if (!table_dev || S < 1 || S > EFFI_MAX_VIEWS) return false;
+    for (int i = 0; i <= EFFI_MAX_VIEWS; ++i) l.p[i] = nullptr;
+    l.tbl = table_dev;
+    return true;
+}
+
+static int launch_warpcorr_views(const float* ref_nhwc, const EffiPtrList& l, int S, const float* rt, const float* depth, long dds,
+                                 long dps, int C, int h, int w, int D, float* sim_views, float* entropy, effi_stream_t stream) {
+    if (!rt || !depth || !sim_views || !entropy) return EFFI_ERR_BADARG;
     if (h < 2 || w < 2 || D < 1) return EFFI_ERR_BADARG;
     hipStream_t s = effi_s(stream);
     const int lds_px = warp_lds_px();
     if (C == 32 && dps == 0 && lds_px >= 0 && D <= 256) {
         // hypotheses shared by all pixels (the cascade's stage 1): taps served from an LDS window
         const int tiles = ((w + WIN_TW - 1) / WIN_TW) * ((h + WIN_TH - 1) / WIN_TH);
-        hipLaunchKernelGGL(warpcorr_views_win_kernel<WIN_MAXPX>, dim3(tiles, S), dim3(WIN_THREADS), 0, s, ref_nhwc, l, rt, depth,
-                           dds, h, w, D, sim_views, entropy, lds_px);
+        if (l.tbl)
+            hipLaunchKernelGGL((warpcorr_views_win_kernel<WIN_MAXPX, true>), dim3(tiles, S), dim3(WIN_THREADS), 0, s, ref_nhwc, l, rt, depth,
+                               dds, h, w, D, sim_views, entropy, lds_px);
+        else
+            hipLaunchKernelGGL((warpcorr_views_win_kernel<WIN_MAXPX, false>), dim3(tiles, S), dim3(WIN_THREADS), 0, s, ref_nhwc, l, rt, depth,
+                               dds, h, w, D, sim_views, entropy, lds_px);
         EFFI_LAUNCH_CHECK();
         return EFFI_OK;
     }
@@ -1176,6 +1205,22 @@ extern "C" int effi_warpcorr_views_f32(const float* ref_nhwc, const float* const
     }
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
+}
+
+extern "C" int effi_warpcorr_views_f32(const float* ref_nhwc, const float* const* src_nhwc, int S, const float* rt,
+                                       const float* depth, long dds, long dps, int C, int h, int w, int D,
+                                       float* sim_views, float* entropy, effi_stream_t stream) {
+    EffiPtrList l;
+    if (!fill_views(src_nhwc, S, l) || !ref_nhwc) return EFFI_ERR_BADARG;
+    return launch_warpcorr_views(ref_nhwc, l, S, rt, depth, dds, dps, C, h, w, D, sim_views, entropy, stream);
+}
+
+extern "C" int effi_warpcorr_views_tbl_f32(const float* const* view_table_dev, int S, const float* rt, const float* depth, long dds,
+                                           long dps, int C, int h, int w, int D, float* sim_views, float* entropy,
+                                           effi_stream_t stream) {
+    EffiPtrList l;
+    if (!fill_table(view_table_dev, S, l)) return EFFI_ERR_BADARG;
+    return launch_warpcorr_views(nullptr, l, S, rt, depth, dds, dps, C, h, w, D, sim_views, entropy, stream);
 }
 
 extern "C" int effi_warpcorr_views_bwd_f32(const float* ref_nhwc, const float* const* src_nhwc, int S, const float* rt,
@@ -1209,12 +1254,10 @@ extern "C" int effi_warpcorr_views_bwd_f32(const float* ref_nhwc, const float* c
     return EFFI_OK;
 }
 
-extern "C" int effi_warpcorr_dyn_f32(const float* ref_nhwc, const float* const* src_nhwc, int S, const float* rt,
-                                     const float* cur_depth, const float* interval, const float* view_w, int vw_shift,
-                                     int C, int h, int w, int D, float* sim, float* samples, effi_stream_t stream) {
-    EffiPtrList l;
-    if (!fill_views(src_nhwc, S, l) || !ref_nhwc || !rt || !cur_depth || !interval || !view_w || !sim || !samples)
-        return EFFI_ERR_BADARG;
+static int launch_warpcorr_dyn(const float* ref_nhwc, const EffiPtrList& l, int S, const float* rt, const float* cur_depth,
+                               const float* interval, const float* view_w, int vw_shift, int C, int h, int w, int D, float* sim,
+                               float* samples, effi_stream_t stream) {
+    if (!rt || !cur_depth || !interval || !view_w || !sim || !samples) return EFFI_ERR_BADARG;
     if (h < 2 || w < 2 || D < 2 || vw_shift < 0 || vw_shift > 4) return EFFI_ERR_BADARG;
     if ((h >> vw_shift) << vw_shift != h || (w >> vw_shift) << vw_shift != w) return EFFI_ERR_BADARG;
     hipStream_t s = effi_s(stream);
@@ -1266,6 +1309,44 @@ extern "C" int effi_warpcorr_dyn_f32(const float* ref_nhwc, const float* const* 
         case 8:  hipLaunchKernelGGL(warpcorr_dyn_kernel<8>, dim3(grid_blocks<8>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples); break;
         default: return EFFI_ERR_UNSUPPORTED;
     }
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_warpcorr_dyn_f32(const float* ref_nhwc, const float* const* src_nhwc, int S, const float* rt,
+                                     const float* cur_depth, const float* interval, const float* view_w, int vw_shift,
+                                     int C, int h, int w, int D, float* sim, float* samples, effi_stream_t stream) {
+    EffiPtrList l;
+    if (!fill_views(src_nhwc, S, l) || !ref_nhwc) return EFFI_ERR_BADARG;
+    return launch_warpcorr_dyn(ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, C, h, w, D, sim, samples, stream);
+}
+
+extern "C" int effi_warpcorr_dyn_tbl_f32(const float* const* view_table_dev, int S, const float* rt, const float* cur_depth,
+                                         const float* interval, const float* view_w, int vw_shift, int C, int h, int w, int D,
+                                         float* sim, float* samples, effi_stream_t stream) {
+    EffiPtrList l;
+    if (!fill_table(view_table_dev, S, l)) return EFFI_ERR_BADARG;
+    return launch_warpcorr_dyn(nullptr, l, S, rt, cur_depth, interval, view_w, vw_shift, C, h, w, D, sim, samples, stream);
+}
+
+// effi_view_table_set: n pointers, by value, into a device table (stream-ordered: the replay that follows on the same stream reads them)
+struct EffiTableArgs { const void* p[EFFI_VIEW_TABLE_MAX]; };
+__global__ void view_table_set_kernel(const void** __restrict__ table, EffiTableArgs a, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const void* v = a.p[0];
+#pragma unroll
+        for (int k = 1; k < EFFI_VIEW_TABLE_MAX; ++k)
+            if (i == k) v = a.p[k];
+        table[i] = v;
+    }
+}
+extern "C" int effi_view_table_set(const void** table_dev, const void* const* ptrs, int n, effi_stream_t stream) {
+    if (!table_dev || !ptrs || n < 1 || n > EFFI_VIEW_TABLE_MAX) return EFFI_ERR_BADARG;
+    EffiTableArgs a;
+    for (int i = 0; i < EFFI_VIEW_TABLE_MAX; ++i) a.p[i] = (i < n) ? ptrs[i] : nullptr;
+    hipStream_t s = effi_s(stream);
+    hipLaunchKernelGGL(view_table_set_kernel, dim3(1), dim3(64), 0, s, table_dev, a, n);
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
 }

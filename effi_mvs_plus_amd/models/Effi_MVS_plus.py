@@ -343,7 +343,11 @@ class Effi_MVS_plus(nn.Module):
         else:
             rts = [ops.compose_rel_proj(pairs[k]) for k in keys]
 
+        table = feats if isinstance(feats, ops.ViewTable) else None     # maps read through a device pointer table (scan_eval.py)
+
         def geometry(s):
+            if table is not None:
+                return (), rts[s], table.shapes[s]
             maps = [f[keys[s]] for f in feats]
             return ops.to_nhwc(maps), rts[s], maps[0].shape
 
@@ -381,7 +385,10 @@ class Effi_MVS_plus(nn.Module):
                 ops.mark("stage{}".format(s))              # end of the previous stage
             nhwc, rt, (_, h, w) = geo[s]
             if s == 0:
-                sim_views, entropy = ops.warpcorr_views(nhwc[0], nhwc[1:], rt, hyp, D1)
+                if table is not None:
+                    sim_views, entropy = ops.warpcorr_views_tbl(table, 0, rt, hyp, D1)
+                else:
+                    sim_views, entropy = ops.warpcorr_views(nhwc[0], nhwc[1:], rt, hyp, D1)
                 weights = self.PixelwiseNet.run(entropy)
                 cur_vol = ops.view_aggregate(sim_views, weights)
                 reg_vol = self.cost_regularization.run(cur_vol.unsqueeze(0))[0][0]
@@ -392,7 +399,10 @@ class Effi_MVS_plus(nn.Module):
                 lo_cur, hi_cur = g_min, g_max
             else:
                 D = self.depth_stage_nums[s]
-                sim, samples = ops.warpcorr_dyn(nhwc[0], nhwc[1:], rt, preds[-1], misc[s:s + 1], weights, D)
+                if table is not None:
+                    sim, samples = ops.warpcorr_dyn_tbl(table, s, rt, preds[-1], misc[s:s + 1], weights, D)
+                else:
+                    sim, samples = ops.warpcorr_dyn(nhwc[0], nhwc[1:], rt, preds[-1], misc[s:s + 1], weights, D)
                 x = sim.unsqueeze(0)
                 # the two cross-scale blocks are independent chains of 5 kernels on volumes of the same shape
                 csp_r, csp_c = self.CSP_R[s - 1], self.CSP_C[s - 1]
@@ -473,15 +483,18 @@ class Effi_MVS_plus(nn.Module):
         """The accelerated path: everything of ``forward`` after the FPN (reference: Effi_MVS_plus.py:437-568).
 
         features: list over views of {"stageK": [B,C,h,w]}; cnet_depth: {"stageK": [B,hd+cd,h,w]};
-        proj_matrices: {"stageK": [B,N,2,4,4]}; depth_values [B,384].
+        proj_matrices: {"stageK": [B,N,2,4,4]}; depth_values [B,384].  ``features`` may also be an ``ops.ViewTable`` (B = 1,
+        inference): the maps of this item's views behind a device pointer table, as the evaluation-set runner passes them.
         """
         if self.training:
             from .. import train_path
             return train_path.hot_path(self, features, cnet_depth, proj_matrices, depth_values)
         B = depth_values.shape[0]
+        if isinstance(features, ops.ViewTable) and B != 1:
+            raise ValueError("forward_hot: a ViewTable describes ONE sample (B = 1)")
         outs = []
         for b in range(B):
-            feats = [{k: v[b] for k, v in f.items()} for f in features]
+            feats = features if isinstance(features, ops.ViewTable) else [{k: v[b] for k, v in f.items()} for f in features]
             ctx = {k: v[b] for k, v in cnet_depth.items()}
             pairs = {k: v[b].contiguous() for k, v in proj_matrices.items()}
             outs.append(self._hot_single(feats, ctx, pairs, depth_values[b].contiguous(), want_intermediates))

@@ -465,6 +465,87 @@ def warpcorr_views_bwd(ref_nhwc, srcs_nhwc, rt, depth, D, grad_sim):
     return g_ref, g_src
 
 
+VIEW_TABLE_ROW = MAX_VIEWS + 2        # include/effi_mvs_hip.h: EFFI_VIEW_TABLE_ROW
+
+
+class ViewTable:
+    """The feature maps of one reference view's (reference, sources) item as a table of device pointers the warp kernels read
+    WHEN THEY RUN (``effi_warpcorr_views_tbl_f32`` / ``effi_warpcorr_dyn_tbl_f32``): ``ptrs`` int64 [n_stages, VIEW_TABLE_ROW],
+    row s = channel-last maps [h_s, w_s, C_s] of the reference (entry 0) and of the sources (entries 1..S).  A captured graph of
+    the hot path keeps the table's address, not the maps': ``set()`` points it at another item's cached maps with one small
+    launch on the current stream (scan_eval.py) -- no 150-MB copy into static inputs.  ``shapes``: per stage (C, h, w).
+
+    The maps are NOT kept alive by the table: whoever calls ``set`` owns them until every replay that reads them has finished
+    (scan_eval.ScanFeatureCache does, per scan)."""
+
+    def __init__(self, shapes, n_views, device, ptrs=None):
+        if not 2 <= n_views <= MAX_VIEWS + 1 or not 1 <= len(shapes) <= 4:
+            raise ValueError("ViewTable: 2..MAX_VIEWS+1 views, 1..4 stages")
+        self.shapes = [tuple(int(v) for v in sh) for sh in shapes]
+        self.n_views = int(n_views)
+        self.ptrs = torch.zeros(len(shapes), VIEW_TABLE_ROW, dtype=torch.int64, device=device) if ptrs is None else ptrs
+        if tuple(self.ptrs.shape) != (len(shapes), VIEW_TABLE_ROW) or self.ptrs.dtype != torch.int64 or not self.ptrs.is_contiguous():
+            raise ValueError("ViewTable: ptrs must be a contiguous int64 [n_stages, VIEW_TABLE_ROW] tensor")
+
+    def rebind(self, ptrs):
+        """The same geometry over another pointer tensor (a graph slot's static copy)."""
+        return ViewTable(self.shapes, self.n_views, ptrs.device, ptrs)
+
+    def set(self, maps):
+        """maps[s][v]: channel-last [h_s, w_s, C_s] fp32 map of view v (0 = reference) at stage s."""
+        vals = []
+        for s_, (sh, row) in enumerate(zip(self.shapes, maps)):
+            if len(row) != self.n_views:
+                raise ValueError(f"ViewTable.set: stage {s_} has {len(row)} maps, the table was built for {self.n_views} views")
+            for m in row:
+                _t(m, "feature map")
+                if tuple(m.shape) != (sh[1], sh[2], sh[0]):
+                    raise ValueError(f"ViewTable.set: stage {s_} map {tuple(m.shape)} is not channel-last {(sh[1], sh[2], sh[0])}")
+            vals += [m.data_ptr() for m in row] + [0] * (VIEW_TABLE_ROW - len(row))
+        arr = (C.c_void_p * len(vals))(*vals)
+        check(_lib.lib().effi_view_table_set(C.c_void_p(self.ptrs.data_ptr()), arr, len(vals), _stream()), "effi_view_table_set")
+
+    def row(self, s_):
+        return C.c_void_p(self.ptrs.data_ptr() + 8 * VIEW_TABLE_ROW * s_)
+
+
+def warpcorr_views_tbl(table, stage, rt, depth, D):
+    """``warpcorr_views`` reading its reference / source maps through row ``stage`` of a ViewTable."""
+    Cc, h, w = table.shapes[stage]
+    S = table.n_views - 1
+    _t(rt, "rt"), _t(depth, "depth", contiguous=False)
+    if rt.shape[0] != S:
+        raise ValueError("Different number of images and projection matrices")
+    depth, dds, dps = _depth_strides(depth, D, h, w)
+    sim = torch.empty(S, D, h, w, device=rt.device, dtype=torch.float32)
+    ent = torch.empty(S, h, w, device=rt.device, dtype=torch.float32)
+    work = lambda: {"flops": S * D * h * w * (10.0 * Cc + 20), "bytes": 4.0 * h * w * (S * Cc + Cc + S * D + S)}
+    check(_call(f"warpcorr_views_c{Cc}", work, _lib.lib().effi_warpcorr_views_tbl_f32, table.row(stage), S, _p(rt), _p(depth), dds, dps,
+                Cc, h, w, D, _p(sim), _p(ent), _stream()), "effi_warpcorr_views_tbl_f32")
+    return sim, ent
+
+
+def warpcorr_dyn_tbl(table, stage, rt, cur_depth, interval, view_w, D):
+    """``warpcorr_dyn`` reading its reference / source maps through row ``stage`` of a ViewTable."""
+    Cc, h, w = table.shapes[stage]
+    S = table.n_views - 1
+    _t(rt, "rt"), _t(cur_depth, "cur_depth"), _t(interval, "interval"), _t(view_w, "view_w")
+    if view_w.shape[0] != S or rt.shape[0] != S:
+        raise ValueError("view weights / projections / sources disagree on the number of views")
+    vh, vw = view_w.shape[1], view_w.shape[2]
+    shift = 0
+    while (vh << shift) < h:
+        shift += 1
+    if (vh << shift) != h or (vw << shift) != w:
+        raise ValueError(f"view weights {vh}x{vw} are not a power-of-two downsampling of {h}x{w}")
+    sim = torch.empty(D, h, w, device=rt.device, dtype=torch.float32)
+    samples = torch.empty(D, h, w, device=rt.device, dtype=torch.float32)
+    work = lambda: {"flops": S * D * h * w * (10.0 * Cc + 20), "bytes": 4.0 * h * w * (S * Cc + Cc + 2 * D + 1 + S / 4.0 ** shift)}
+    check(_call(f"warpcorr_dyn_c{Cc}", work, _lib.lib().effi_warpcorr_dyn_tbl_f32, table.row(stage), S, _p(rt), _p(cur_depth),
+                _p(interval), _p(view_w), shift, Cc, h, w, D, _p(sim), _p(samples), _stream()), "effi_warpcorr_dyn_tbl_f32")
+    return sim, samples
+
+
 def pixelwise_net(entropy, params):
     n, h, w = entropy.shape
     _t(entropy, "entropy"), _t(params, "params")

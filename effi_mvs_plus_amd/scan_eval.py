@@ -58,16 +58,23 @@ class ScanFeatureCache:
     """``get(scan, image)`` -> the image's feature pyramid, computed by ``compute(scan, image)`` once per scan on this rank.
     Entries of a scan are dropped when a later scan is first asked for (shards are contiguous: a rank never returns to a scan)."""
 
-    def __init__(self, compute: Callable[[int, int], object]):
+    def __init__(self, compute: Callable[[int, int], object], on_drop: Callable[[], None] = None):
         self.compute = compute
+        self.on_drop = on_drop          # called before a scan's entries are released (stream ordering of their memory, ScanRunner)
         self.scan = None
         self.store: Dict[int, object] = {}
         self.hits = self.misses = 0
         self.max_entries = 0
 
+    def drop(self):
+        if self.store and self.on_drop is not None:
+            self.on_drop()
+        self.store.clear()
+        self.scan = None
+
     def get(self, scan: int, image: int):
         if scan != self.scan:
-            self.store.clear()
+            self.drop()
             self.scan = scan
         if image in self.store:
             self.hits += 1
@@ -85,7 +92,12 @@ class BatchedGather:
     order), None elsewhere.  Collectives are issued with ``async_op=True``; at most ``max_in_flight`` batches are pending (their
     staging tensors stay alive until waited for).  ``to_host``: stage through CPU tensors (gloo)."""
 
-    def __init__(self, n_total: int, k: int, dst: int = 0, to_host: bool = False, max_in_flight: int = 2):
+    def __init__(self, n_total: int, k: int, dst: int = 0, to_host: bool = False, max_in_flight: int = 2, lanes=None):
+        # ``lanes``: the streams ``add`` is called under when several views are in flight (run_scans with a ScanRunner).  Staging
+        # batches are then allocated on the stream that was current at construction ("main"), every lane waits for a new batch's
+        # zero fill before copying into it, and main waits for the lanes before a batch leaves (collective / host copy / finish).
+        self.lanes = list(lanes) if lanes else None
+        self.main = torch.cuda.current_stream() if self.lanes else None
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         if n_total < self.world:
@@ -103,7 +115,18 @@ class BatchedGather:
 
     def _new_stage(self):
         (sd, dd, dev), (sc, dc, _) = self._shapes
-        return (torch.zeros((self.k,) + sd, dtype=dd, device=dev), torch.zeros((self.k,) + sc, dtype=dc, device=dev))
+        if self.lanes is None:
+            return (torch.zeros((self.k,) + sd, dtype=dd, device=dev), torch.zeros((self.k,) + sc, dtype=dc, device=dev))
+        with torch.cuda.stream(self.main):
+            st = (torch.zeros((self.k,) + sd, dtype=dd, device=dev), torch.zeros((self.k,) + sc, dtype=dc, device=dev))
+        for lane in self.lanes:
+            lane.wait_stream(self.main)
+        return st
+
+    def _join_lanes(self):
+        if self.lanes is not None:
+            for lane in self.lanes:
+                self.main.wait_stream(lane)
 
     def add(self, depth: torch.Tensor, conf: torch.Tensor):
         if self._shapes is None:
@@ -120,9 +143,20 @@ class BatchedGather:
     def _issue(self):
         d, c = self.stage if self.stage is not None else self._new_stage()        # an empty (all-zero) batch keeps the collectives matched
         self.stage, self.fill = None, 0
+        self.issued += 1
+        if self.world == 1 and not self.to_host:
+            self.received.append(([d], [c]))       # nothing leaves the device: finish() joins the lanes once
+            return
+        if self.lanes is None:
+            self._send(d, c)
+        else:
+            self._join_lanes()                     # the batch's views were written on the lanes
+            with torch.cuda.stream(self.main):
+                self._send(d, c)
+
+    def _send(self, d, c):
         if self.to_host:
             d, c = d.cpu(), c.cpu()
-        self.issued += 1
         if self.world == 1:
             self.received.append(([d], [c]))
             return
@@ -150,6 +184,7 @@ class BatchedGather:
             self._issue()
         while self.pending:
             self._wait_one()
+        self._join_lanes()
         if self.rank != self.dst:
             return None
         depth, conf = [], []
@@ -168,14 +203,136 @@ class BatchedGather:
 def run_scans(items: Sequence[Item], forward: Callable[[Item], Tuple[torch.Tensor, torch.Tensor]], gather_batch: int = 8, dst: int = 0,
               to_host: bool = False, on_view: Callable[[int], None] = None):
     """This rank's contiguous shard of ``items`` through ``forward(item) -> (depth, confidence)`` with the batched gather.
-    Returns ({"depth", "confidence"} on dst else None, number of views this rank computed)."""
+    Returns ({"depth", "confidence"} on dst else None, number of views this rank computed).
+
+    ``forward`` may be a ``ScanRunner``: it has ``lanes`` (streams) and is then called as ``forward(item, slot)`` under lane
+    ``slot`` = position in the shard modulo the number of lanes, so that many views are in flight; the maps it returns are the
+    slot's static graph outputs, copied into the gather's staging batch on the same lane before the slot is replayed again."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    gather = BatchedGather(len(items), gather_batch, dst=dst, to_host=to_host)       # validates len(items) >= world on every rank
+    lanes = getattr(forward, "lanes", None)
+    gather = BatchedGather(len(items), gather_batch, dst=dst, to_host=to_host, lanes=lanes)   # validates len(items) >= world on every rank
     lo, hi = shard_bounds(len(items), rank, world)
-    for i in range(lo, hi):
-        d, c = forward(items[i])
-        gather.add(d, c)
+    for j, i in enumerate(range(lo, hi)):
+        if lanes:
+            slot = j % len(lanes)
+            with torch.cuda.stream(lanes[slot]):
+                d, c = forward(items[i], slot)
+                gather.add(d, c)
+        else:
+            d, c = forward(items[i])
+            gather.add(d, c)
         if on_view is not None:
             on_view(i)
     return gather.finish(), hi - lo
+
+
+class ScanRunner:
+    """images -> feature pyramids (cached per scan) -> context pyramid + cost-volume hot path, ``slots`` reference views in flight.
+
+    What one item (scan, ref, sources) costs on the device: the feature pyramid of every image of the item this rank has not seen in
+    this scan (on average ONE per item), the reference image's context pyramid and the hot path.  How it is launched:
+
+    * a **producer stream** computes missing feature pyramids eagerly (``net.feature``: channel-last stage maps) into the per-scan
+      cache; it owns every cache allocation, and waits for all lanes before a scan's entries are dropped, so that the memory is
+      never handed out again while a replay still reads it;
+    * each of the ``slots`` **lanes** (a stream + a captured hipGraph with static inputs) replays ``context pyramid -> forward_hot``.
+      The graph reads the item's feature maps through an ``ops.ViewTable`` -- a 3 x 14 table of device pointers that one small
+      launch rewrites per item -- so nothing of the 150 MB of maps is copied; the reference image is written straight into the
+      slot's static image buffer by ``image_fn(scan, image, out)``; cameras / depth range are copied into the slot (a few KB);
+    * the lane waits for the producer's event of the newest pyramid it reads, nothing else.
+
+    ``__call__(item, slot)`` must run under ``lanes[slot]`` (``run_scans`` does that) and returns the slot's static
+    (final depth [H, W], confidence [H/2, W/2]); they are valid until the slot's next replay.  Results are bitwise those of
+    ``net.forward_hot`` on the same maps (tests/test_gpu_scan.py).  Reference behaviour: every reference view is an independent
+    forward over its pair.txt sources (test_dtu_dypcd.py:424-439, datasets/general_eval.py:26-51)."""
+
+    def __init__(self, net, image_fn, example_item: Item, proj_matrices, depth_values, slots: int = 3, branches=None):
+        from . import ops
+        from .graph import ReplayGraph
+        self.net, self.image_fn = net, image_fn
+        self.slots = max(1, int(slots))
+        dev = depth_values.device
+        self.device = dev
+        scan, ref, srcs = example_item
+        self.n_views = 1 + len(srcs)
+        self.producer = torch.cuda.Stream(device=dev)
+        self.lanes = [torch.cuda.Stream(device=dev) for _ in range(self.slots)]
+        self._seq = 0
+        self._lane_seq = [0] * self.slots
+        self.cache = ScanFeatureCache(self._pyramid, on_drop=self._before_drop)
+        self.n_images_prepared = 0
+        with torch.no_grad():
+            img0 = self._image(scan, ref)
+            self._img_shape = tuple(img0.shape)
+            self._scratch = torch.empty_like(img0)          # the producer's image buffer (stream-ordered reuse)
+            ents = [self.cache.get(scan, v) for v in (ref,) + tuple(srcs)]
+            shapes = [(m.shape[2], m.shape[0], m.shape[1]) for m in ents[0].maps]
+            proto = ops.ViewTable(shapes, self.n_views, dev)
+            torch.cuda.current_stream().wait_stream(self.producer)
+            proto.set([[e.maps[s] for e in ents] for s in range(len(shapes))])
+
+            def fn(img, ptrs, pm, dv):
+                return net.forward_hot(proto.rebind(ptrs), net.cnet_depth(img), pm, dv)
+
+            br0 = ops.get_branches()
+            ops.set_branches((self.slots > 1) if branches is None else bool(branches))     # views in flight: each graph keeps the pass's side stream
+            try:
+                self.graph = ReplayGraph(fn, (img0, proto.ptrs, proj_matrices, depth_values), slots=self.slots)
+            finally:
+                ops.set_branches(br0)
+            self.tables = [proto.rebind(self.graph.inputs[i][1]) for i in range(self.slots)]
+            torch.cuda.synchronize(dev)
+            del ents
+        self.cache.drop()
+        self.cache.hits = self.cache.misses = self.cache.max_entries = 0
+        self.n_images_prepared = 0
+
+    # -- producer side ------------------------------------------------------------------------------------------------------------
+    def _image(self, scan, image, out=None):
+        self.n_images_prepared += 1
+        return self.image_fn(scan, image, out)
+
+    def _pyramid(self, scan, image):
+        from . import ops
+        with torch.cuda.stream(self.producer):
+            img = self._image(scan, image, getattr(self, "_scratch", None))
+            f = self.net.feature(img)
+            maps = ops.to_nhwc([f[k][0] for k in sorted(f)])       # zero-copy: the heads write channel-last
+            ev = torch.cuda.Event()
+            ev.record(self.producer)
+        self._seq += 1
+        return _CacheEntry(maps, ev, self._seq)
+
+    def _before_drop(self):
+        for lane in self.lanes:                     # every replay enqueued so far may still read the entries being dropped
+            self.producer.wait_stream(lane)
+
+    # -- lane side ----------------------------------------------------------------------------------------------------------------
+    def __call__(self, item: Item, slot: int, proj_matrices=None, depth_values=None):
+        scan, ref, srcs = item
+        if 1 + len(srcs) != self.n_views:
+            raise ValueError(f"ScanRunner: captured for {self.n_views} views, item has {1 + len(srcs)}")
+        lane = self.lanes[slot]
+        ents = [self.cache.get(scan, v) for v in (ref,) + tuple(srcs)]
+        newest = max(ents, key=lambda e: e.seq)
+        if newest.seq > self._lane_seq[slot]:       # the producer stream is in order: its newest event covers the older ones
+            lane.wait_event(newest.event)
+            self._lane_seq[slot] = newest.seq
+        img, _, pm, dv = self.graph.inputs[slot]
+        self._image(scan, ref, img)
+        if proj_matrices is not None:
+            for k in pm:
+                pm[k].copy_(proj_matrices[k], non_blocking=True)
+        if depth_values is not None:
+            dv.copy_(depth_values, non_blocking=True)
+        self.tables[slot].set([[e.maps[s] for e in ents] for s in range(len(self.tables[slot].shapes))])
+        out = self.graph.replay(slot)
+        return out["depth"][-1][0], out["photometric_confidence"][0]
+
+
+class _CacheEntry:
+    __slots__ = ("maps", "event", "seq")
+
+    def __init__(self, maps, event, seq):
+        self.maps, self.event, self.seq = maps, event, seq

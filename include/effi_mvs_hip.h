@@ -29,6 +29,8 @@ extern "C" {
 
 #define EFFI_MAX_VIEWS 12         /* source views per call (T&T script uses num_view=11 -> 10 sources) */
 #define EFFI_MAX_SRC    3         /* concatenated input tensors of one 2-D / 3-D convolution */
+#define EFFI_VIEW_TABLE_ROW (EFFI_MAX_VIEWS + 2)   /* pointers per row of a view table: reference, sources, nulls */
+#define EFFI_VIEW_TABLE_MAX 64    /* pointers one effi_view_table_set call writes (4 rows) */
 
 typedef void* effi_stream_t;
 
@@ -104,6 +106,19 @@ int effi_warpcorr_views_f32(const float* ref_nhwc, const float* const* src_nhwc,
                             int C, int h, int w, int D, float* sim_views, float* entropy,
                             effi_stream_t stream);
 
+/* View-table form of effi_warpcorr_views_f32 (round 4; the evaluation-set runner, datasets/general_eval.py:26-51 +
+ * test_dtu_dypcd.py:424-439: every reference view is a forward over ITS (reference, sources) subset of a scan's images).
+ * view_table_dev: DEVICE array of EFFI_VIEW_TABLE_ROW pointers -- [0] the reference map, [1..S] the sources, the rest null -- read by
+ * the kernel when it runs, not when it is enqueued: a captured hipGraph of the hot path is pointed at another item's cached feature
+ * maps by rewriting the table (effi_view_table_set) instead of copying ~150 MB of maps into static inputs.  Same kernels, same
+ * arithmetic, bitwise the same result as the pointer form. */
+int effi_warpcorr_views_tbl_f32(const float* const* view_table_dev, int S, const float* rt, const float* depth,
+                                long depth_dstride, long depth_pstride, int C, int h, int w, int D, float* sim_views,
+                                float* entropy, effi_stream_t stream);
+/* n (<= EFFI_VIEW_TABLE_MAX) device pointers, given in a HOST array, written to table_dev[0..n) by a one-workgroup kernel on
+ * `stream` (stream-ordered like every other entry; no host memory is read after the call returns). */
+int effi_view_table_set(const void** table_dev, const void* const* ptrs, int n, effi_stream_t stream);
+
 /* ---- K4: view-weight net, fused 3x(3x3 conv+BN+ReLU) -> 1x1 conv -> sigmoid.
  * models/Effi_MVS_plus.py:361-362, models/module.py:213-220.  BN is folded by the host.
  * entropy [n][h][w] -> weight [n][h][w].  params: packed fp32 block, every 3x3 layer stored
@@ -126,6 +141,11 @@ int effi_view_aggregate_f32(const float* sim_views, const float* weights, int S,
 int effi_warpcorr_dyn_f32(const float* ref_nhwc, const float* const* src_nhwc, int S, const float* rt,
                           const float* cur_depth, const float* interval, const float* view_w, int vw_shift,
                           int C, int h, int w, int D, float* sim, float* samples, effi_stream_t stream);
+
+/* View-table form of effi_warpcorr_dyn_f32 (see effi_warpcorr_views_tbl_f32). */
+int effi_warpcorr_dyn_tbl_f32(const float* const* view_table_dev, int S, const float* rt, const float* cur_depth,
+                              const float* interval, const float* view_w, int vw_shift, int C, int h, int w, int D,
+                              float* sim, float* samples, effi_stream_t stream);
 
 /* ---- K5/K6: 3-D convolutions, kernel 3, padding 1, BN folded into (weight, bias) by the host.
  * models/module.py:124-160 (Conv3d), :168-203 (Deconv3d), :439-452, :505-508.
