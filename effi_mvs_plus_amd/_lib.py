@@ -23,6 +23,9 @@ SIGNATURES = {
     "effi_fusion_dynamic_filter_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _f, _i, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp],
     "effi_fusion_dtu_filter_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _f, _f, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "effi_fusion_vis_filter_f32": [_vp, _vp, _i, _i, _i, _i, _f, _f, _i, _i, _vp, _vp],
+    "effi_fusion_points_f32": [_i, _vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "effi_fusion_dtu_reproject_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp],
     "effi_compose_rel_proj_f32": [_vp, _i, _vp, _vp],
     "effi_rel_proj_f32": [_vp, _vp, _vp, _vp],
     "effi_planar_to_nhwc_f32": [_vp, _vp, _i, _i, _i, _vp],

@@ -269,6 +269,33 @@ __device__ __forceinline__ float cv_remap_linear(const float* __restrict__ img, 
 
 constexpr int DTU_MAX_THR = 16;
 
+// reproject_with_depth for ONE reference pixel and one source view (test_dtu_dypcd.py:164-205), shared by the fused filter kernel and
+// the per-function kernel below: one arithmetic.
+struct DtuReproj {
+    float x_src, y_src, depth_rep, x_rep, y_rep;
+};
+__device__ __forceinline__ DtuReproj dtu_reproject_pixel(const float* __restrict__ Mr, const float* __restrict__ Ms,
+                                                         const float* __restrict__ src_depth, int h, int w, double xd, double yd,
+                                                         float dref) {
+    // reference 3-D point: K_ref^-1 . ([x y 1] * depth)                                                     (:172-173)
+    const D3 xyz_ref = dmul3(Mr + 9, xd * (double)dref, yd * (double)dref, (double)dref);
+    const D3 xs = dmul4_xyz(Ms + 18, xyz_ref);                                                             // (:175-176)
+    const D3 kx = dmul3(Ms, xs.x, xs.y, xs.z);                                                             // (:178-179)
+    const double u = kx.x / kx.z, v = kx.y / kx.z;
+    DtuReproj r;
+    r.x_src = (float)u;                                                                                    // (:182-183)
+    r.y_src = (float)v;
+    const float samp = cv_remap_linear(src_depth, h, w, r.x_src, r.y_src);                                 // (:184)
+    const D3 s3 = dmul3(Ms + 9, u * (double)samp, v * (double)samp, (double)samp);                         // (:190-191)
+    const D3 rp = dmul4_xyz(Ms + 34, s3);                                                                  // (:193-194)
+    r.depth_rep = (float)rp.z;                                                                             // (:196)
+    D3 kr = dmul3(Mr, rp.x, rp.y, rp.z);                                                                   // (:197)
+    if (kr.z == 0.0) kr.z += 0.00001;                                                                      // (:198)
+    r.x_rep = (float)(kr.x / kr.z);                                                                        // (:199-201)
+    r.y_rep = (float)(kr.y / kr.z);
+    return r;
+}
+
 __global__ __launch_bounds__(256) void fusion_dtu_filter_kernel(
     const float* __restrict__ ref_depth, const float* __restrict__ src_depths, int V, int h, int w, const float* __restrict__ mats,
     const float* __restrict__ conf, float conf_thr, float conf_keep, int s_lo, int e_hi, float dist_base, float diff_base,
@@ -281,8 +308,6 @@ __global__ __launch_bounds__(256) void fusion_dtu_filter_kernel(
     const double xd = (double)x, yd = (double)y;
     const float* Mr = mats;
     const float dref = ref_depth[p];
-    // reference 3-D point: K_ref^-1 . ([x y 1] * depth)                                                     (:172-173)
-    const D3 xyz_ref = dmul3(Mr + 9, xd * (double)dref, yd * (double)dref, (double)dref);
     const int nthr = e_hi - s_lo;
     float thr_diff[DTU_MAX_THR];
     double thr_dist[DTU_MAX_THR];
@@ -298,16 +323,8 @@ __global__ __launch_bounds__(256) void fusion_dtu_filter_kernel(
     int nlast = 0;
     for (int sv = 0; sv < V; ++sv) {
         const float* Ms = mats + (long)(sv + 1) * MAT_STRIDE;
-        const D3 xs = dmul4_xyz(Ms + 18, xyz_ref);                                                             // (:175-176)
-        const D3 kx = dmul3(Ms, xs.x, xs.y, xs.z);                                                             // (:178-179)
-        const double u = kx.x / kx.z, v = kx.y / kx.z;
-        const float samp = cv_remap_linear(src_depths + (long)sv * hw, h, w, (float)u, (float)v);              // (:182-184)
-        const D3 s3 = dmul3(Ms + 9, u * (double)samp, v * (double)samp, (double)samp);                         // (:190-191)
-        const D3 rp = dmul4_xyz(Ms + 34, s3);                                                                  // (:193-194)
-        const float depth_rep = (float)rp.z;                                                                   // (:196)
-        D3 kr = dmul3(Mr, rp.x, rp.y, rp.z);                                                                   // (:197)
-        if (kr.z == 0.0) kr.z += 0.00001;                                                                      // (:198)
-        const float xr = (float)(kr.x / kr.z), yr = (float)(kr.y / kr.z);                                      // (:199-201)
+        const DtuReproj rr = dtu_reproject_pixel(Mr, Ms, src_depths + (long)sv * hw, h, w, xd, yd, dref);     // (:164-205)
+        const float depth_rep = rr.depth_rep, xr = rr.x_rep, yr = rr.y_rep;
         const double dxr = (double)xr - xd, dyr = (double)yr - yd;
         const double dist = sqrt(dxr * dxr + dyr * dyr);                                                       // (:218) float32 - int64 -> float64
         const float ddiff = fabsf(depth_rep - dref);                                                           // (:225)
@@ -346,7 +363,158 @@ __global__ __launch_bounds__(256) void fusion_dtu_filter_kernel(
     }
 }
 
+// reproject_with_depth (test_dtu_dypcd.py:164-205) and, with ``masks``, check_geometric_consistency (:208-233) for one
+// (reference, source) pair as functions of their own: out5 = depth_reprojected, x_reprojected, y_reprojected, x_src, y_src.
+// With masks: masks[k] = dist < (s+k) * dist_base & depth_diff < log10(max(s+k, 1.05)) * diff_base, and the first three outputs are
+// zeroed where the LAST mask is false (:229-231).  PARITY UNPINNED like the fused DTU kernel (cv2.remap restated).
+__global__ __launch_bounds__(256) void fusion_dtu_reproject_kernel(const float* __restrict__ ref_depth, const float* __restrict__ src_depth,
+                                                                   int h, int w, const float* __restrict__ mats, int s_lo, int e_hi,
+                                                                   float dist_base, float diff_base, float* __restrict__ out5,
+                                                                   unsigned char* __restrict__ masks) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const long hw = (long)h * w;
+    if (p >= hw) return;
+    const int y = p / w, x = p - y * w;
+    const double xd = (double)x, yd = (double)y;
+    const float dref = ref_depth[p];
+    DtuReproj r = dtu_reproject_pixel(mats, mats + MAT_STRIDE, src_depth, h, w, xd, yd, dref);
+    if (masks) {
+        const double dxr = (double)r.x_rep - xd, dyr = (double)r.y_rep - yd;
+        const double dist = sqrt(dxr * dxr + dyr * dyr);
+        const float ddiff = fabsf(r.depth_rep - dref);
+        bool last = false;
+        for (int k = 0; k < e_hi - s_lo; ++k) {
+            const int i = s_lo + k;
+            const float thr_diff = (float)(log(fmax((double)i, 1.05)) / log(10.0) * (double)diff_base);
+            last = (dist < (double)i * (double)dist_base) & (ddiff < thr_diff);
+            masks[(long)k * hw + p] = last ? 1 : 0;
+        }
+        if (!last) r.depth_rep = r.x_rep = r.y_rep = 0.0f;
+    }
+    out5[p] = r.depth_rep;
+    out5[hw + p] = r.x_rep;
+    out5[2 * hw + p] = r.y_rep;
+    out5[3 * hw + p] = r.x_src;
+    out5[4 * hw + p] = r.y_src;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The reference's misc/fusion.py functions the T&T driver calls ONE BY ONE (test_tank.py:486-509) -- vis_filter_dynamic and the
+// idx_* point transforms -- as kernels of their own, so that the driver's lines run unchanged on this package.
+// The fused kernel above remains the fast path (dynamic_filter); these reproduce the individual functions' outputs.
+
+// vis_filter_dynamic (misc/fusion.py:157-181): masks[n][v][k][p] = |reproj_xy - pixel centre| < (thres+k)/dist_base  AND
+// |ref_depth - reproj_depth| (/ ref_depth) < (thres+k)/rel_diff_base, k = 0 .. v - thres
+__global__ __launch_bounds__(256) void fusion_vis_filter_kernel(const float* __restrict__ ref_depth, const float* __restrict__ xyd,
+                                                                int V, int h, int w, float dist_base, float rel_base, int thres,
+                                                                int relative, unsigned char* __restrict__ masks) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    const long hw = (long)h * w;
+    if (p >= hw) return;
+    const int b = blockIdx.y / V, s = blockIdx.y - b * V;
+    const int y = p / w, x = p - y * w;
+    const float u = (float)x + 0.5f, vv = (float)y + 0.5f;
+    const float dref = ref_depth[(long)b * hw + p];
+    const float* q = xyd + ((long)(b * V + s) * 3) * hw + p;
+    const float dx = q[0] - u, dy = q[hw] - vv;
+    const float cdiff = sqrtf(dx * dx + dy * dy);
+    float ddiff = fabsf(dref - q[2 * hw]);
+    if (relative) ddiff = ddiff / dref;
+    const int nthr = V + 1 - thres;
+    unsigned char* m = masks + ((long)(b * V + s) * nthr) * hw + p;
+    for (int k = 0; k < nthr; ++k) {
+        const float step = (float)(thres + k);
+        m[(long)k * hw] = ((cdiff < step / dist_base) & (ddiff < step / rel_base)) ? 1 : 0;
+    }
+}
+
+// one camera per batch element: K[9] Kinv[9] E[16] Einv[16]
+__global__ void fusion_prepare_batch_kernel(const float* __restrict__ cams, int n, float* __restrict__ mats) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const float* cam = cams + (long)v * 32;
+    double K[9], Ki[9], E[16], Ei[16];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) K[r * 3 + c] = (double)cam[16 + r * 4 + c];
+    for (int i = 0; i < 16; ++i) E[i] = (double)cam[i];
+    fus_invert(K, 3, Ki);
+    fus_invert(E, 4, Ei);
+    float* m = mats + (long)v * MAT_STRIDE;
+    for (int i = 0; i < 9; ++i) { m[i] = (float)K[i]; m[9 + i] = (float)Ki[i]; }
+    for (int i = 0; i < 16; ++i) { m[18 + i] = (float)E[i]; m[34 + i] = (float)Ei[i]; }
+}
+
+// MODE 0: idx_img2cam (:23-28)  in [..,3] (+ depth) -> out [..,4];  1: idx_cam2world (:31-34)  4 -> 4;
+//      2: idx_world2cam (:37-40) 4 -> 4;                             3: idx_cam2img (:43-47)    4 -> 3
+template <int MODE>
+__global__ __launch_bounds__(256) void fusion_points_kernel(const float* __restrict__ in, long in_bstride, const float* __restrict__ depth,
+                                                            const float* __restrict__ mats, int hw, float* __restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= hw) return;
+    const int b = blockIdx.y;
+    const float* M = mats + (long)b * MAT_STRIDE;
+    constexpr int NI = (MODE == 0) ? 3 : 4, NO = (MODE == 3) ? 3 : 4;
+    const float* q = in + (long)b * in_bstride + (long)p * NI;
+    float* o = out + ((long)b * hw + p) * NO;
+    if (MODE == 0) {
+        const V3 c = mul3(M + 9, {q[0], q[1], q[2]});
+        const float d = c.z + 1e-9f, dep = depth[(long)b * hw + p];
+        o[0] = c.x / d * dep; o[1] = c.y / d * dep; o[2] = c.z / d * dep; o[3] = 1.0f;
+    } else if (MODE == 1 || MODE == 2) {
+        const V4 r = xform<true>(M + (MODE == 1 ? 34 : 18), {q[0], q[1], q[2], q[3]});
+        o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w;
+    } else {
+        const V3 r = cam2img<true>(M, {q[0], q[1], q[2], q[3]});
+        o[0] = r.x; o[1] = r.y; o[2] = r.z;
+    }
+}
+
 }  // namespace
+
+extern "C" int effi_fusion_vis_filter_f32(const float* ref_depth, const float* reproj_xyd, int n, int n_src, int h, int w,
+                                          float dist_base, float rel_diff_base, int thres_view, int relative, unsigned char* masks,
+                                          effi_stream_t stream) {
+    if (!ref_depth || !reproj_xyd || !masks || n < 1 || n_src < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    if (thres_view < 0 || thres_view > n_src || dist_base <= 0.0f || rel_diff_base <= 0.0f || (long)n * n_src > 65535) return EFFI_ERR_BADARG;
+    hipStream_t st = effi_s(stream);
+    hipLaunchKernelGGL(fusion_vis_filter_kernel, dim3(effi_cdiv((long)h * w, 256), n * n_src), dim3(256), 0, st, ref_depth, reproj_xyd,
+                       n_src, h, w, dist_base, rel_diff_base, thres_view, relative, masks);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_fusion_points_f32(int mode, const float* in, long in_batch_stride, const float* depth, const float* cams, int n,
+                                      int h, int w, float* mats_scratch, float* out, effi_stream_t stream) {
+    if (!in || !cams || !mats_scratch || !out || n < 1 || n > 65535 || h < 1 || w < 1 || mode < 0 || mode > 3) return EFFI_ERR_BADARG;
+    if (mode == 0 && !depth) return EFFI_ERR_BADARG;
+    hipStream_t st = effi_s(stream);
+    const int hw = h * w;
+    hipLaunchKernelGGL(fusion_prepare_batch_kernel, dim3(effi_cdiv(n, 64)), dim3(64), 0, st, cams, n, mats_scratch);
+    EFFI_LAUNCH_CHECK();
+    const dim3 grid(effi_cdiv(hw, 256), n), blk(256);
+    switch (mode) {
+        case 0: hipLaunchKernelGGL(fusion_points_kernel<0>, grid, blk, 0, st, in, in_batch_stride, depth, mats_scratch, hw, out); break;
+        case 1: hipLaunchKernelGGL(fusion_points_kernel<1>, grid, blk, 0, st, in, in_batch_stride, depth, mats_scratch, hw, out); break;
+        case 2: hipLaunchKernelGGL(fusion_points_kernel<2>, grid, blk, 0, st, in, in_batch_stride, depth, mats_scratch, hw, out); break;
+        default: hipLaunchKernelGGL(fusion_points_kernel<3>, grid, blk, 0, st, in, in_batch_stride, depth, mats_scratch, hw, out); break;
+    }
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_fusion_dtu_reproject_f32(const float* ref_depth, const float* src_depth, const float* ref_cam, const float* src_cam,
+                                             int h, int w, int s, int e, float dist_base, float diff_base, float* mats_scratch,
+                                             float* out5, unsigned char* masks, effi_stream_t stream) {
+    if (!ref_depth || !src_depth || !ref_cam || !src_cam || !mats_scratch || !out5 || h < 2 || w < 2) return EFFI_ERR_BADARG;
+    if (masks && (s < 1 || e <= s || dist_base <= 0.0f || diff_base <= 0.0f)) return EFFI_ERR_BADARG;
+    hipStream_t st = effi_s(stream);
+    hipLaunchKernelGGL(fusion_dtu_prepare_kernel, dim3(1), dim3(64), 0, st, ref_cam, src_cam, 1, mats_scratch);
+    EFFI_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fusion_dtu_reproject_kernel, dim3(effi_cdiv((long)h * w, 256)), dim3(256), 0, st, ref_depth, src_depth, h, w,
+                       mats_scratch, s, e, dist_base, diff_base, out5, masks);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
 
 extern "C" int effi_fusion_dtu_filter_f32(const float* ref_depth, const float* src_depths, const float* ref_cam, const float* src_cams,
                                           int n_src, int h, int w, const float* confidence, float conf_threshold, float conf_keep,

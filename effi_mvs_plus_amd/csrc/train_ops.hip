@@ -22,6 +22,11 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 
 // Positions [i0, i1) of the flattened (sample b, position r < n) range of ONE channel, TPB threads striding: the sample index is
 // advanced by comparison instead of a 64-bit division per element (the division was most of these kernels' instructions).
@@ -282,37 +287,40 @@ __global__ __launch_bounds__(TPB) void bn_apply_kernel(const float* __restrict__
     }
 }
 
-// s1[c] = sum g', s2[c] = sum g' * xhat, with g' = gy masked by the ReLU (y > 0) and xhat = (x - mean) * invstd
+// s1[c] = sum g', s2[c] = sum g' * xhat, with g' = gy masked by the ReLU (y > 0) and xhat = (x - mean) * invstd.
+// Both sums are accumulated in DOUBLE (threads, waves, workgroup partials): gx = gamma * invstd * (g' - s1/N - xhat * s2/N) below is a
+// projection that cancels most of g' -- on a 8 x 148 x 200 volume a relative 1e-6 on s1 / N is as large as the small entries of gx, and
+// the weight gradients of the layers behind it inherit that (round 4; the products g' * xhat themselves stay fp32, as in torch).
 __global__ __launch_bounds__(TPB) void bn_bwd_reduce_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                                             const float* __restrict__ x, int Bn, int C, long n,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd, int relu,
-                                                            float* __restrict__ s1, float* __restrict__ s2, float* __restrict__ partial) {
+                                                            float* __restrict__ s1, float* __restrict__ s2, double* __restrict__ partial) {
     const int c = blockIdx.x;
     const long total = (long)Bn * n;
     const long per = (total + gridDim.y - 1) / gridDim.y;
     const long i0 = blockIdx.y * per, i1 = min(total, i0 + per);
     const float mu = mean[c], is = invstd[c];
-    float a = 0.0f, b2 = 0.0f;
+    double a = 0.0, b2 = 0.0;
     EFFI_FOR_BATCH_RANGE(i0, i1, n, b, r) {
         const long e = ((long)b * C + c) * n + r;
         float g = gy[e];
         if (relu && !(y[e] > 0.0f)) g = 0.0f;
-        a += g;
-        b2 += g * ((x[e] - mu) * is);
+        a += (double)g;
+        b2 += (double)(g * ((x[e] - mu) * is));
     }
-    __shared__ float red[2][TPB / 64];
+    __shared__ double red[2][TPB / 64];
     a = wave_sum(a);
     b2 = wave_sum(b2);
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b2; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const float t1 = red[0][0] + red[0][1] + red[0][2] + red[0][3], t2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const double t1 = red[0][0] + red[0][1] + red[0][2] + red[0][3], t2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
         if (partial) {
             partial[((long)c * gridDim.y + blockIdx.y) * 2 + 0] = t1;
             partial[((long)c * gridDim.y + blockIdx.y) * 2 + 1] = t2;
         } else {
-            s1[c] = t1;
-            s2[c] = t2;
+            s1[c] = (float)t1;
+            s2[c] = (float)t2;
         }
     }
 }
@@ -323,22 +331,22 @@ __global__ __launch_bounds__(TPB) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gamma, float* __restrict__ s1,
                                                            float* __restrict__ s2, int relu, float* __restrict__ gx,
-                                                           const float* __restrict__ partial, int ns) {
-    const float invN = 1.0f / (float)((long)Bn * n);
+                                                           const double* __restrict__ partial, int ns) {
+    const double N = (double)((long)Bn * n);
     const int c = (int)(blockIdx.y % C);                       // grid (chunks of a plane, planes = Bn * C)
-    float t1, t2;
-    if (partial) {        // the reduce kernel's partial sums [C][ns][2]: added here (ascending order), published by the channel's first workgroup
-        t1 = t2 = 0.0f;
+    double t1, t2;
+    if (partial) {        // the reduce kernel's partial sums [C][ns][2] (double): added here (ascending order), published by the channel's first workgroup
+        t1 = t2 = 0.0;
         for (int j = 0; j < ns; ++j) {
             t1 += partial[((long)c * ns + j) * 2 + 0];
             t2 += partial[((long)c * ns + j) * 2 + 1];
         }
-        if (blockIdx.x == 0 && blockIdx.y == (unsigned)c && threadIdx.x == 0) { s1[c] = t1; s2[c] = t2; }
+        if (blockIdx.x == 0 && blockIdx.y == (unsigned)c && threadIdx.x == 0) { s1[c] = (float)t1; s2[c] = (float)t2; }
     } else {
-        t1 = s1[c];
-        t2 = s2[c];
+        t1 = (double)s1[c];
+        t2 = (double)s2[c];
     }
-    const float mu = mean[c], is = invstd[c], ga = gamma[c], a1 = t1 * invN, a2 = t2 * invN;
+    const float mu = mean[c], is = invstd[c], ga = gamma[c], a1 = (float)(t1 / N), a2 = (float)(t2 / N);
     const long base = (long)blockIdx.y * n;
     for (long r = (long)blockIdx.x * TPB + threadIdx.x; r < n; r += (long)gridDim.x * TPB) {
         const long i = base + r;
@@ -672,10 +680,12 @@ extern "C" int effi_bn_bwd_f32(const float* gy, const float* y, const float* x, 
     if ((long)B * C > 65535) return EFFI_ERR_UNSUPPORTED;
     hipStream_t s = effi_s(stream);
     const int ns = effi_nsplit(scratch, nsplit);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, ns), dim3(TPB), 0, s, gy, y, x, B, C, n, mean, invstd, relu, s1, s2,
-                       ns > 1 ? scratch : nullptr);
+    // scratch: [C][ns][2] DOUBLES (8-byte aligned; the caller sizes it as 4 floats per (channel, split))
+    if (ns > 1 && (reinterpret_cast<uintptr_t>(scratch) & 7)) return EFFI_ERR_BADARG;
+    double* part = ns > 1 ? reinterpret_cast<double*>(scratch) : nullptr;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, ns), dim3(TPB), 0, s, gy, y, x, B, C, n, mean, invstd, relu, s1, s2, part);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, effi_plane_grid(n, B * C), dim3(TPB), 0, s, gy, y, x, B, C, n, mean, invstd, gamma, s1, s2, relu, gx,
-                       (const float*)(ns > 1 ? scratch : nullptr), ns);
+                       (const double*)part, ns);
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
 }

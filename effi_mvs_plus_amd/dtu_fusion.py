@@ -70,6 +70,43 @@ def _cam_tensor(intrinsics, extrinsics, device):
     return cam.to(device)
 
 
+def _dev_map(a, device):
+    return a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
+
+
+def _like_input(t_, like):
+    return t_ if isinstance(like, torch.Tensor) else t_.cpu().numpy()
+
+
+def reproject_with_depth(depth_ref, intrinsics_ref, extrinsics_ref, depth_src, intrinsics_src, extrinsics_src, device="cuda"):
+    """test_dtu_dypcd.py:164-205 with the reference's arguments: project the reference pixels into the source view, sample its
+    depth (cv2.remap's INTER_LINEAR arithmetic), project back -> (depth_reprojected, x_reprojected, y_reprojected, x_src, y_src),
+    [h,w] float32 each.  numpy arrays in -> numpy arrays out (the reference's types); CUDA tensors in -> CUDA tensors out.  One
+    kernel (``effi_fusion_dtu_reproject_f32``); PARITY UNPINNED (module docstring)."""
+    dev = depth_ref.device if isinstance(depth_ref, torch.Tensor) else torch.device(device)
+    with torch.cuda.device(dev):
+        out5, _ = ops.fusion_dtu_reproject(_dev_map(depth_ref, dev).contiguous(), _dev_map(depth_src, dev).contiguous(),
+                                           _cam_tensor(np.asarray(intrinsics_ref), np.asarray(extrinsics_ref), dev),
+                                           _cam_tensor(np.asarray(intrinsics_src), np.asarray(extrinsics_src), dev))
+    return tuple(_like_input(out5[k], depth_ref) for k in range(5))
+
+
+def check_geometric_consistency(depth_ref, intrinsics_ref, extrinsics_ref, depth_src, intrinsics_src, extrinsics_src, confidence=None,
+                                device="cuda"):
+    """test_dtu_dypcd.py:208-233 with the reference's arguments (``confidence`` is unused there too) -> (masks: list of e - s bool
+    maps, mask = the last of them, depth_reprojected, x2d_src, y2d_src, x2d_reprojected, y2d_reprojected), the three reprojected
+    maps zeroed outside ``mask``.  Types follow the input as in ``reproject_with_depth``; PARITY UNPINNED."""
+    dev = depth_ref.device if isinstance(depth_ref, torch.Tensor) else torch.device(device)
+    with torch.cuda.device(dev):
+        out5, m = ops.fusion_dtu_reproject(_dev_map(depth_ref, dev).contiguous(), _dev_map(depth_src, dev).contiguous(),
+                                           _cam_tensor(np.asarray(intrinsics_ref), np.asarray(extrinsics_ref), dev),
+                                           _cam_tensor(np.asarray(intrinsics_src), np.asarray(extrinsics_src), dev),
+                                           s=s, e=e, dist_base=dist_base, diff_base=diff_base)
+    masks = [_like_input(m[k].bool(), depth_ref) for k in range(m.shape[0])]
+    o = [_like_input(out5[k], depth_ref) for k in range(5)]
+    return masks, masks[-1], o[0], o[3], o[4], o[1], o[2]
+
+
 @ops.on_tensor_device
 def filter_view(ref_depth_est, ref_intrinsics, ref_extrinsics, src_depth_ests, src_intrinsics, src_extrinsics, confidence, conf=0.5):
     """The array part of ``filter_depth`` for one reference view (test_dtu_dypcd.py:257-333) on the device: depth maps [h,w] /

@@ -535,15 +535,18 @@ def get_depth_range_samples(cur_depth, ndepth, depth_inteval_pixel, device, dtyp
 
 
 def mvs_loss_static(inputs, depth_gt_ms, mask_ms, dloss, depth_values=[425, 935], loss_rate=0.9):
-    """``mvs_loss`` without data-dependent shapes: the mean over the valid pixels as sum(loss * valid) / count instead of boolean
-    indexing (which synchronises with the host and cannot be captured into a graph).  Same value up to the order of the additions."""
+    """``mvs_loss`` without data-dependent shapes: the mean over the valid pixels as sum(where(valid, loss, 0)) / count instead of
+    boolean indexing (which synchronises with the host and cannot be captured into a graph).  Same value up to the order of the
+    additions; an Inf / NaN estimate at a MASKED pixel is dropped as the reference's indexing drops it (``where`` selects, a
+    product with a 0 / 1 mask would turn it into NaN), forward and backward."""
     total = torch.zeros((), dtype=torch.float32, device=mask_ms["stage1"].device)
     per_output = {}
     n = len(inputs)
     for i, est in enumerate(inputs):
         key = "stage{}".format(dloss[i])
-        valid = (mask_ms[key] > 0.5).to(est.dtype)
-        li = (F.smooth_l1_loss(est, depth_gt_ms[key], reduction="none") * valid).sum() / valid.sum()
+        valid = mask_ms[key] > 0.5
+        diff = torch.where(valid, est - depth_gt_ms[key], torch.zeros((), dtype=est.dtype, device=est.device))   # masked pixels: zero loss
+        li = F.smooth_l1_loss(diff, torch.zeros_like(diff), reduction="none").sum() / valid.sum().to(est.dtype)     # AND zero gradient
         per_output["l{}".format(i)] = li
         total = total + (1.0 if i == 0 else loss_rate ** (n - i - 1)) * li
     return total, per_output

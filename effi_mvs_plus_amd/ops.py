@@ -738,6 +738,66 @@ def fusion_dynamic_filter(ref_depth, src_depths, ref_cam, src_cams, ref_conf=Non
     return out
 
 
+def fusion_vis_filter(ref_depth, reproj_xyd, dist_base=4.0, rel_diff_base=1300.0, thres_view=2, relative=False):
+    """misc/fusion.py:157-181 (vis_filter_dynamic's arithmetic): ref_depth [n,1,h,w], reproj_xyd [n,v,3,h,w] ->
+    masks [n,v,v+1-thres_view,h,w] uint8."""
+    _t(ref_depth, "ref_depth"), _t(reproj_xyd, "reproj_xyd")
+    n, v, three, h, w = reproj_xyd.shape
+    if three != 3 or tuple(ref_depth.shape) != (n, 1, h, w):
+        raise ValueError("fusion_vis_filter: ref_depth [n,1,h,w], reproj_xyd [n,v,3,h,w]")
+    nthr = v + 1 - int(thres_view)
+    masks = torch.empty(n, v, max(nthr, 0), h, w, device=ref_depth.device, dtype=torch.uint8)
+    if nthr <= 0:
+        return masks
+    check(_lib.lib().effi_fusion_vis_filter_f32(_p(ref_depth), _p(reproj_xyd), n, v, h, w, float(dist_base), float(rel_diff_base),
+                                                int(thres_view), int(bool(relative)), _p(masks), _stream()), "effi_fusion_vis_filter_f32")
+    return masks
+
+
+def fusion_dtu_reproject(ref_depth, src_depth, ref_cam, src_cam, s=None, e=None, dist_base=0.5, diff_base=0.25):
+    """test_dtu_dypcd.py:164-233 for one (reference, source) pair (PARITY UNPINNED): depth maps [h,w], cameras [2,4,4] ->
+    (out5 [5,h,w] = depth_reprojected, x_reprojected, y_reprojected, x_src, y_src; masks [e-s,h,w] uint8 or None).  With s / e
+    given the call is check_geometric_consistency (masks + zeroing under the last mask), without it reproject_with_depth."""
+    for name, t_ in (("ref_depth", ref_depth), ("src_depth", src_depth), ("ref_cam", ref_cam), ("src_cam", src_cam)):
+        _t(t_, name)
+    h, w = ref_depth.shape
+    if tuple(src_depth.shape) != (h, w) or tuple(ref_cam.shape) != (2, 4, 4) or tuple(src_cam.shape) != (2, 4, 4):
+        raise ValueError("fusion_dtu_reproject: depth maps [h,w], cameras [2,4,4]")
+    dev = ref_depth.device
+    out5 = torch.empty(5, h, w, device=dev, dtype=torch.float32)
+    masks = torch.empty(e - s, h, w, device=dev, dtype=torch.uint8) if s is not None else None
+    scratch = torch.empty(104, device=dev, dtype=torch.float32)
+    check(_lib.lib().effi_fusion_dtu_reproject_f32(_p(ref_depth), _p(src_depth), _p(ref_cam), _p(src_cam), h, w, int(s or 1), int(e or 2),
+                                                   float(dist_base), float(diff_base), _p(scratch), _p(out5), _p(masks), _stream()),
+          "effi_fusion_dtu_reproject_f32")
+    return out5, masks
+
+
+FUSION_IMG2CAM, FUSION_CAM2WORLD, FUSION_WORLD2CAM, FUSION_CAM2IMG = 0, 1, 2, 3
+
+
+def fusion_points(mode, pts, cam, depth=None):
+    """The point transforms of misc/fusion.py:23-47 with one camera per batch element.  pts [n or 1,h,w,3 or 4,1] (a leading 1 is
+    broadcast over the batch, as the reference's ``@`` does), cam [n,2,4,4], depth [n,1,h,w] for FUSION_IMG2CAM -> [n,h,w,4 or 3,1]."""
+    _t(pts, "points"), _t(cam, "cam")
+    n = cam.shape[0]
+    ni = 3 if mode == FUSION_IMG2CAM else 4
+    no = 3 if mode == FUSION_CAM2IMG else 4
+    if pts.dim() != 5 or pts.shape[3] != ni or pts.shape[4] != 1 or pts.shape[0] not in (1, n) or tuple(cam.shape[1:]) != (2, 4, 4):
+        raise ValueError(f"fusion_points: points [n|1,h,w,{ni},1] and cam [n,2,4,4] expected, got {tuple(pts.shape)} / {tuple(cam.shape)}")
+    h, w = pts.shape[1], pts.shape[2]
+    if mode == FUSION_IMG2CAM:
+        _t(depth, "depth")
+        if tuple(depth.shape) != (n, 1, h, w):
+            raise ValueError(f"fusion_points: depth {tuple(depth.shape)} is not [n,1,h,w] = {(n, 1, h, w)}")
+    out = torch.empty(n, h, w, no, 1, device=pts.device, dtype=torch.float32)
+    scratch = torch.empty(52 * n, device=pts.device, dtype=torch.float32)
+    bstride = 0 if (pts.shape[0] == 1 and n > 1) else h * w * ni
+    check(_lib.lib().effi_fusion_points_f32(int(mode), _p(pts), bstride, _p(depth), _p(cam), n, h, w, _p(scratch), _p(out), _stream()),
+          "effi_fusion_points_f32")
+    return out
+
+
 def fusion_dtu_filter(ref_depth, src_depths, ref_cam, src_cams, confidence=None, conf_threshold=0.5, conf_keep=0.75, s=1, e=11,
                       dist_base=0.5, diff_base=0.25, want_points=True):
     """Scope row n3, DTU branch (test_dtu_dypcd.py:164-333; PARITY UNPINNED, see the header): one reference view through the dynamic
@@ -1675,6 +1735,12 @@ def bn_train_fwd(x, gamma, beta, eps, momentum, running_mean=None, running_var=N
 _PACK_CACHE = {}
 
 
+def drop_pack_cache():
+    """Forget every packed weight: needed after an update the version counters do not see (a replayed graph's optimizer step,
+    writes through ``p.data``)."""
+    _PACK_CACHE.clear()
+
+
 def pack_conv2d_mfma_dev(weight, bias=None, dgrad=False):
     """``packing.pack_conv2d_mfma`` on the device in one launch (training: every layer, every step); ``dgrad``: the weights of the
     input-gradient convolution (``weight.flip(2, 3).transpose(0, 1)`` packed).  -> (wpack, bias_pack)."""
@@ -1722,7 +1788,7 @@ def bn_bwd(gy, y, x, mean, invstd, gamma, relu):
     s2 = torch.empty(Cc, device=x.device, dtype=torch.float32)
     gx = torch.empty_like(x)
     n = x.numel() // (B * Cc)
-    scratch, nsplit = _reduce_split(B * n, Cc, 2, x.device)
+    scratch, nsplit = _reduce_split(B * n, Cc, 4, x.device)           # [C][nsplit][2] doubles
     check(_lib.lib().effi_bn_bwd_f32(_p(gy), _p(y), _p(x), B, Cc, n, _p(mean), _p(invstd), _p(gamma), int(relu),
                                      _p(s1), _p(s2), _p(gx), _p(scratch), nsplit, _stream()), "effi_bn_bwd_f32")
     return gx, s1, s2

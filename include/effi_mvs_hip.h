@@ -413,6 +413,26 @@ int effi_fusion_dynamic_filter_f32(const float* ref_depth, const float* src_dept
                                    unsigned char* out_prob_mask, unsigned char* out_mask, float* out_points,
                                    float* out_reproj_xyd, effi_stream_t stream);
 
+/* The same row's individual functions, for callers that use them one by one as the T&T driver does (test_tank.py:486-509):
+ * vis_filter_dynamic (misc/fusion.py:157-181): ref_depth [n][1][h][w], reproj_xyd [n][n_src][3][h][w] ->
+ * masks [n][n_src][n_src+1-thres_view][h][w] bytes (0/1); the reference's second return value is the last threshold's plane. */
+int effi_fusion_vis_filter_f32(const float* ref_depth, const float* reproj_xyd, int n, int n_src, int h, int w, float dist_base,
+                               float rel_diff_base, int thres_view, int relative, unsigned char* masks, effi_stream_t stream);
+/* Point transforms of misc/fusion.py with one camera [2][4][4] per batch element (cams [n][2][4][4]); mode 0 = idx_img2cam (:23-28:
+ * in [.][h][w][3] homogeneous pixels, batch stride in_batch_stride floats (0 = one grid for all), depth [n][h][w] -> out [n][h][w][4]),
+ * 1 = idx_cam2world (:31-34), 2 = idx_world2cam (:37-40): [n][h][w][4] -> [n][h][w][4], 3 = idx_cam2img (:43-47): -> [n][h][w][3].
+ * Inverses in fp64 on the device, rounded once.  mats_scratch: >= 52*n floats. */
+int effi_fusion_points_f32(int mode, const float* in, long in_batch_stride, const float* depth, const float* cams, int n, int h,
+                           int w, float* mats_scratch, float* out, effi_stream_t stream);
+
+/* DTU branch, the two functions of test_dtu_dypcd.py:164-233 for ONE (reference, source) pair (PARITY UNPINNED like
+ * effi_fusion_dtu_filter_f32, whose arithmetic they share): out5 [5][h][w] = depth_reprojected, x_reprojected, y_reprojected, x_src,
+ * y_src (reproject_with_depth); masks != NULL -> check_geometric_consistency: masks [e-s][h][w] bytes and the first three planes
+ * zeroed where the last mask is false.  ref_cam / src_cam [2][4][4]; mats_scratch >= 104 floats. */
+int effi_fusion_dtu_reproject_f32(const float* ref_depth, const float* src_depth, const float* ref_cam, const float* src_cam, int h,
+                                  int w, int s, int e, float dist_base, float diff_base, float* mats_scratch, float* out5,
+                                  unsigned char* masks, effi_stream_t stream);
+
 /* ---- scope row n2, first piece: backward of effi_warpcorr_views_f32's similarity output ------------------------------------
  * sim[v][d][p] = mean_c ref[p][c] * bilinear(src_v)[c] at the warped position (models/module.py:303-344,
  * models/Effi_MVS_plus.py:38-40); the sampling grid carries no gradient (module.py:313).  Inputs as the forward entry;
@@ -482,7 +502,8 @@ int effi_conv_wgrad_f32(const float* a, const float* b, int ca, int cb, int cb_t
 int effi_conv2d_k5s2_dgrad_f32(const float* grad_out, const float* weight, int cin, int cout, int hin, int win, float* grad_in,
                                effi_stream_t stream);
 /* out[c] = sum over batch and positions of g [B][C][n]  (bias gradients; out is overwritten).  The per-channel reductions of this section take a
- * caller-owned ``scratch`` ([C][nsplit][K] floats; K = 1, 2 for effi_bn_bwd_f32) and ``nsplit``: nsplit workgroups per channel write
+ * caller-owned ``scratch`` ([C][nsplit][K] floats; K = 1, for effi_bn_bwd_f32 K = 4: two DOUBLES, 8-byte aligned -- its two sums are
+ * accumulated in double because gx is a cancelling projection of them) and ``nsplit``: nsplit workgroups per channel write
  * partial sums and a second small launch adds them in ascending order; scratch == NULL or nsplit <= 1: one workgroup per channel.
  * No atomics either way: the results are bitwise repeatable. */
 int effi_channel_sum_f32(const float* g, int B, int C, long n, float* out, float* scratch, int nsplit, effi_stream_t stream);

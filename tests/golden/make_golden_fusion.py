@@ -63,6 +63,11 @@ def main():
         out[f"{tag}_prob_mask"] = prob_mask.reshape(1, 1, h, w).numpy().astype(np.uint8)
         out[f"{tag}_mask"] = mask.reshape(1, 1, h, w).numpy().astype(np.uint8)
         out[f"{tag}_points"] = points.numpy()
+        out[f"{tag}_idx_cam"] = idx_cam.numpy()                       # idx_img2cam of the averaged depth, [1,h,w,4,1]
+        # the two remaining point transforms, on the same points (misc/fusion.py:37-47)
+        w2c = fusion.idx_world2cam(fusion.idx_cam2world(idx_cam, ref_cam), src_cams[:, 0])
+        out[f"{tag}_world2cam_src0"] = w2c.numpy()
+        out[f"{tag}_cam2img_src0"] = fusion.idx_cam2img(w2c, src_cams[:, 0]).numpy()
         print(tag, "geo", float(geo_mask.float().mean()), "mask", float(mask.float().mean()), "vis", vis_masks.float().mean(dim=(0, 1, 3, 4)))
     path = os.path.join(HERE, "g12_fusion.npz")
     np.savez_compressed(path, **out)

@@ -115,6 +115,81 @@ def test_hip_filter_against_reference_vectors_and_oracle(tag):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tag", CASES)
+def test_tank_driver_lines_run_unchanged_on_the_hip_fusion_module(tag):
+    """The tensor lines of the reference's T&T driver, /root/reference/test_tank.py:486-509, typed here as the driver has them with
+    ``fusion`` = effi_mvs_plus_amd.fusion (the maintainer's one-line change: ``from effi_mvs_plus_amd import fusion``): every
+    ``fusion.*`` name the driver calls exists with the reference's signature, and the block reproduces the golden vectors that
+    tests/golden/make_golden_fusion.py produced by running the same lines on the reference's misc/fusion.py."""
+    import torch.nn.functional as F
+    from effi_mvs_plus_amd import fusion
+    g = load_golden("g12_fusion.npz")
+    c, ref_depth, src, ref_cam, src_cams, conf = _inputs(g, tag)
+    sample = {"ref_depth": t(ref_depth, DEV), "src_depths": t(src, DEV), "ref_cam": t(ref_cam, DEV), "src_cams": t(src_cams, DEV),
+              "ref_conf": t(conf, DEV)}
+    filter_dixt = {"prob_threshold": float(c["prob"]), "dh_view_num": int(c["dh"]), "dist_filter": float(c["dist"]),
+                   "depth_filter": float(c["dfilt"])}
+    relative = bool(c["relative"])
+    prob_threshold = filter_dixt["prob_threshold"]
+    # ---- test_tank.py:467-509 ----
+    num_src_views = sample['src_depths'].shape[1]
+    dy_range = num_src_views + 1
+    h, w = sample['ref_depth'].shape[-2:]
+    sample['ref_conf'] = F.interpolate(sample['ref_conf'].unsqueeze(1), size=[h, w], mode='nearest')
+    prob_mask = sample['ref_conf'] > prob_threshold
+    prob_mask = prob_mask.squeeze(1)
+    ref_depth_d = sample['ref_depth']
+    reproj_xyd, ref_idx_cam, src2ref_idx_cam = fusion.get_reproj_dynamic(
+        *[sample[attr] for attr in ['ref_depth', 'src_depths', 'ref_cam', 'src_cams']])
+    dh_view_num = filter_dixt["dh_view_num"]
+    vis_masks, vis_mask = fusion.vis_filter_dynamic(sample['ref_depth'], reproj_xyd, ref_idx_cam, src2ref_idx_cam, dist_base=filter_dixt["dist_filter"],
+                                                    rel_diff_base=filter_dixt["depth_filter"], thres_view=dh_view_num, relative=relative)
+    reproj_depth = reproj_xyd[:, :, -1]
+    assert vis_mask.shape[2] != 0
+    reproj_depth[~vis_mask.squeeze(2)] = 0
+    geo_mask_sums = vis_masks.sum(dim=1)
+    geo_mask_sum = vis_mask.sum(dim=1)
+    depth_est_averaged = (torch.sum(reproj_depth, dim=1, keepdim=True) + ref_depth_d) / (geo_mask_sum + 1)
+    geo_mask = geo_mask_sum >= dy_range
+    for i in range(dh_view_num, dy_range):
+        geo_mask = torch.logical_or(geo_mask, geo_mask_sums[:, i - dh_view_num] >= i)
+    mask = fusion.bin_op_reduce([prob_mask, geo_mask], torch.min)
+    idx_img = fusion.get_pixel_grids(*depth_est_averaged.size()[-2:]).unsqueeze(0)
+    idx_cam = fusion.idx_img2cam(idx_img, depth_est_averaged, sample['ref_cam'])
+    points = fusion.idx_cam2world(idx_cam, sample['ref_cam'])[..., :3, 0].permute(0, 3, 1, 2)
+    # ---- against the reference's outputs for the same lines ----
+    assert vis_masks.dtype == torch.bool and tuple(vis_masks.shape) == tuple(g[f"{tag}_vis_masks"].shape)
+    assert tuple(vis_mask.shape) == (1, num_src_views, 1, h, w)
+    agree = (vis_masks.cpu() == g[f"{tag}_vis_masks"].bool()).float().mean().item()
+    print(f"[{tag}] vis_masks agreement with the reference: {agree:.6f}")
+    assert agree >= 0.9995                  # a pixel whose reprojection error sits within rounding of a threshold may flip
+    d_err = (depth_est_averaged.cpu() - g[f"{tag}_depth"]).abs()
+    assert (d_err <= 2e-3).float().mean().item() >= 0.999
+    for name, got in (("geo_mask", geo_mask), ("prob_mask", prob_mask), ("mask", mask)):
+        a_ = (got.reshape(1, 1, h, w).cpu() == g[f"{tag}_{name}"].bool()).float().mean().item()
+        assert a_ >= 0.999, (name, a_)
+    ok = (d_err <= 2e-3)[0, 0]
+    check_close(f"[{tag}] idx_cam (idx_img2cam)", idx_cam.cpu()[0][ok], g[f"{tag}_idx_cam"][0][ok], rtol=1e-5, atol=5e-3)
+    check_close(f"[{tag}] points (idx_cam2world)", points.cpu()[0][:, ok], g[f"{tag}_points"][0][:, ok], rtol=1e-5, atol=5e-3)
+    # the two transforms the driver does not call directly, fed with the REFERENCE's intermediate so that each function is checked alone
+    gi = t(g[f"{tag}_idx_cam"], DEV)
+    world = fusion.idx_cam2world(gi, sample['ref_cam'])
+    check_close(f"[{tag}] idx_cam2world alone", world[..., :3, 0].permute(0, 3, 1, 2), g[f"{tag}_points"], rtol=1e-5, atol=2e-3)
+    w2c = fusion.idx_world2cam(world, sample['src_cams'][:, 0])
+    check_close(f"[{tag}] idx_world2cam", w2c, g[f"{tag}_world2cam_src0"], rtol=1e-5, atol=2e-3)
+    check_close(f"[{tag}] idx_cam2img", fusion.idx_cam2img(t(g[f"{tag}_world2cam_src0"], DEV), sample['src_cams'][:, 0]),
+                g[f"{tag}_cam2img_src0"], rtol=1e-5, atol=2e-3)
+    check_close(f"[{tag}] idx_img2cam alone", fusion.idx_img2cam(idx_img, t(g[f"{tag}_depth"], DEV), sample['ref_cam']), g[f"{tag}_idx_cam"],
+                rtol=1e-5, atol=2e-3)
+    # vis_filter_dynamic alone on the reference's reproj_xyd: thresholds are exact comparisons of the same fp32 numbers
+    vm, _ = fusion.vis_filter_dynamic(sample['ref_depth'], t(g[f"{tag}_reproj_xyd"], DEV), None, None, dist_base=filter_dixt["dist_filter"],
+                                      rel_diff_base=filter_dixt["depth_filter"], thres_view=dh_view_num, relative=relative)
+    a_ = (vm.cpu() == g[f"{tag}_vis_masks"].bool()).float().mean().item()
+    print(f"[{tag}] vis_filter_dynamic on the reference's reproj_xyd: agreement {a_:.7f}")
+    assert a_ >= 0.99999
+
+
+@pytest.mark.gpu
 def test_hip_filter_edge_cases():
     """All-consistent views, a view that projects outside the image (zero-padded sample), no confidence map, 16 views."""
     from effi_mvs_plus_amd import ops
@@ -194,6 +269,38 @@ def test_dtu_filter_parity_unpinned_kernel_vs_oracle(H, W, N, seed):
     assert dd[same].max() <= 2e-3 and np.median(dd) <= 1e-4, (dd[same].max(), np.median(dd))          # mm, depths ~ 600 mm
     pw = np.abs(got["xyz_world"].cpu().numpy() - want["xyz_world"])
     assert pw[:, same].max() <= 5e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,N,seed", [(96, 128, 3, 3), (75, 101, 3, 5)])
+def test_dtu_filter_parity_unpinned_reference_named_functions(H, W, N, seed):
+    """``reproject_with_depth`` / ``check_geometric_consistency`` (test_dtu_dypcd.py:164-233) under their own names and argument
+    lists (numpy in, numpy out) against the numpy restatement; PARITY UNPINNED like the fused kernel whose arithmetic they share."""
+    import numpy as np
+    from effi_mvs_plus_amd import dtu_fusion
+    from oracle import effi_dtu_filter_oracle as D
+    d, cams, conf, K, E = _dtu_case(H, W, N, seed)
+    dn = [d[v].numpy() for v in range(N)]
+    want = D.reproject_with_depth(dn[0], K[0], E[0], dn[1], K[1], E[1])
+    got = dtu_fusion.reproject_with_depth(dn[0], K[0], E[0], dn[1], K[1], E[1])
+    assert len(got) == 5 and all(isinstance(a, np.ndarray) and a.dtype == np.float32 and a.shape == (H, W) for a in got)
+    names = ("depth_reprojected", "x_reprojected", "y_reprojected", "x_src", "y_src")
+    for nm, a, b in zip(names, got, want):
+        err = np.abs(a - b)
+        print(f"[dtu reproject {H}x{W}] {nm}: max {err.max():.3e} median {np.median(err):.3e}")
+        # a 1/32-pixel quantisation step of the remap coordinate that falls the other way moves a sampled depth by a gradient step
+        assert np.median(err) <= 1e-4 and (err <= 5e-3).mean() >= 0.999, nm
+    wm, wmask, wdep, wxs, wys, wxr, wyr = D.check_geometric_consistency(dn[0].copy(), K[0], E[0], dn[2], K[2], E[2])
+    gm, gmask, gdep, gxs, gys, gxr, gyr = dtu_fusion.check_geometric_consistency(dn[0].copy(), K[0], E[0], dn[2], K[2], E[2], None)
+    assert len(gm) == len(wm) == dtu_fusion.e - dtu_fusion.s and gmask.dtype == bool
+    for k in range(len(wm)):
+        assert (gm[k] == wm[k]).mean() >= 0.998, k
+    same = gmask == wmask
+    assert np.abs(gdep - wdep)[same].max() <= 5e-3 and np.abs(gxr - wxr)[same].max() <= 5e-3 and np.abs(gyr - wyr)[same].max() <= 5e-3
+    assert (gdep[~gmask] == 0).all() and (gxr[~gmask] == 0).all()
+    # CUDA tensors in -> CUDA tensors out, same values
+    tt = dtu_fusion.reproject_with_depth(t(d[0], DEV), K[0], E[0], t(d[1], DEV), K[1], E[1])
+    assert all(isinstance(a, torch.Tensor) and a.is_cuda for a in tt) and np.array_equal(tt[0].cpu().numpy(), got[0])
 
 
 @pytest.mark.gpu

@@ -407,7 +407,7 @@ def test_training_step_matches_autograd_through_the_oracle(B, N):
         # with every mean moved by one ulp: 4.6e-3 / 7.7e-6; the one-entry BatchNorm of round 3 (outputs equal to the old ones to
         # 1e-6 in every one of the 74 calls, no ReLU decision differs): CSP_C1.conv1.conv.weight 3.6e-2, PixelwiseNet.3.bias 1.3-2.1e-2.
         # Something downstream amplifies 1e-6 to 1e-2 for a few parameters; not located (training section).
-        bound = max(5e-2, 2 * e_ref)
+        bound = max(1e-2, 2 * e_ref)
         n += 1
         n_plain += e_hip <= 1e-3
         n_plain_ref += e_ref <= 1e-3
@@ -428,6 +428,75 @@ def test_training_step_matches_autograd_through_the_oracle(B, N):
             assert rel(v, sd2[k]) <= 1e-4, k
         if "num_batches_tracked" in k:
             assert int(v) == int(sd2[k]), k
+
+
+def test_csp_conv1_block_backward_alone_against_fp64():
+    """Where does the gate's worst parameter (CSP_C1.conv1.conv.weight: 3.6e-2 of its peak off fp64 in round 3, against 1.6e-5 for
+    the reference's own fp32 pass) get its error?  This test takes the block OUT of the step: the oracle's own fp32 input of
+    ``CSP_C.0.conv1`` (conv3d 16 -> 8 + BatchNorm on batch statistics + ReLU, models/module.py:124-166,505-513) and the gradient that
+    arrives at its output in the oracle's training pass are fed to (a) the same block in fp64 on the CPU -- the truth --, (b) the same
+    block in fp32 on the CPU (what the reference's own arithmetic gives), (c) the HIP backward of that block alone.  If (c) were
+    ~1e-2 off while (b) is ~1e-5 the block's backward is the amplifier (first suspect: fp32 sums in bn_bwd_reduce_kernel feeding the
+    cancelling projection gx = gamma * invstd * (g' - s1/N - xhat * s2/N)); if (c) is ~1e-6 the amplifier is upstream of the block
+    (discrete decisions -- ReLU masks, lookup taps -- that differ between two fp32 forwards)."""
+    from oracle import effi_oracle as O
+    H, W, nd = 128, 160, (8, 8, 8)
+    net, sd = build_model("8,8,8", seed=13, device=DEV)
+    net.train()
+    imgs, pm, dv = synth.synth_sample(H, W, 3, seed=30)
+    gt, mask = _loss_inputs(H, W, 1, 2)
+    rec = {}
+    orig = O.conv3d_block
+
+    def tapped(x, sd_, prefix, *a, **k):
+        if prefix != "CSP_C.0.conv1":
+            return orig(x, sd_, prefix, *a, **k)
+        x.retain_grad()
+        rec["x"] = x
+        out = orig(x, sd_, prefix, *a, **k)
+        out.register_hook(lambda g: rec.__setitem__("g", g.detach().clone()))
+        return out
+
+    O.conv3d_block = tapped
+    try:
+        _, _, leaves32, _ = _oracle_training_pass(net, sd, imgs, pm, dv, gt, mask, nd)
+    finally:
+        O.conv3d_block = orig
+    x32, g32 = rec["x"].detach().clone(), rec["g"]
+    assert x32.dtype == torch.float32 and tuple(x32.shape[:2]) == (1, 16) and tuple(g32.shape[:2]) == (1, 8)
+    keys = ("conv.weight", "bn.weight", "bn.bias")
+
+    def block_cpu(dtype):
+        sdb = {f"B.{k}": sd[f"CSP_C.0.conv1.{k}"].clone().to(dtype).requires_grad_(True) for k in keys}
+        for k in ("running_mean", "running_var"):
+            sdb[f"B.bn.{k}"] = sd[f"CSP_C.0.conv1.bn.{k}"].clone().to(dtype)
+        sdb["B.bn.num_batches_tracked"] = sd["CSP_C.0.conv1.bn.num_batches_tracked"].clone()
+        xx = x32.to(dtype).requires_grad_(True)
+        with O.training(0.0):
+            y = O.conv3d_block(xx, sdb, "B")
+        y.backward(g32.to(dtype))
+        return xx.grad, {k: sdb[f"B.{k}"].grad for k in keys}, y.detach()
+
+    gx64, gp64, y64 = block_cpu(torch.float64)
+    gx32, gp32, _ = block_cpu(torch.float32)
+    blk = net.CSP_C[0].conv1
+    for p_ in blk.parameters():
+        p_.grad = None
+    xd = x32.to(DEV).requires_grad_(True)
+    y = blk(xd)
+    y.backward(g32.to(DEV))
+    rows = [("gx", rel(xd.grad, gx64), rel(gx32, gx64))]
+    rows += [(k, rel(dict(blk.named_parameters())[k].grad, gp64[k]), rel(gp32[k], gp64[k])) for k in keys]
+    assert rel(y, y64) <= 1e-5
+    for name, e_hip, e_ref in rows:
+        print(f"[CSP_C1.conv1 alone] {name:12s} HIP vs fp64 {e_hip:.3e}   CPU fp32 vs fp64 {e_ref:.3e}")
+    # in the whole step the oracle's fp32 pass gives this weight's gradient to ~1e-5 of its peak; the block alone must do as well
+    # (measured: see the test's output; bound 2e-4 of the peak = 200x tighter than the gate's old 5e-2)
+    for name, e_hip, e_ref in rows:
+        assert e_hip <= max(2e-4, 4 * e_ref), (name, e_hip, e_ref)
+    # and the gradient of that weight in the oracle's own fp32 step, for the record of what "upstream" contributes
+    print(f"[CSP_C1.conv1 alone] incoming gradient peak {float(g32.abs().max()):.3e}, gx peak {float(gx64.abs().max()):.3e}, "
+          f"block variance min {float(y64.var()):.3e}")
 
 
 def test_optimizer_step_reduces_the_loss():
@@ -525,6 +594,99 @@ def test_graphed_training_step_replays_the_eager_step():
         step_d = train_graph.GraphedTrainStep(net, opt_d, *samples[0])
         a, b = float(step_d()), float(step_d())
         assert a != b and abs(a - b) < 0.9 * max(a, b)
+
+
+def test_graphed_training_step_follows_a_scheduler_checks_the_depth_range_and_leaves_no_stale_state():
+    """What the reference's loop does around ``train_sample`` (train.py:119-127,229-263,510-511): ``OneCycleLR.step()`` after every
+    sample.  A captured step must train at the scheduler's rate (tensor lr, filled in place), refuse a sample whose depth range is
+    not the captured one, leave the model's later EAGER train-mode forwards on their own range, and not leave stale packed weights
+    behind for them."""
+    import copy
+    from effi_mvs_plus_amd import ops, train_graph
+    from effi_mvs_plus_amd.models.module import mvs_loss_static
+    H, W, N = 128, 160, 3
+    net, _ = build_model("8,8,8", seed=5, device=DEV)
+    net.train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout2d):
+            m.p = 0.0
+    ref = copy.deepcopy(net)
+    DL = list(train_graph.DLOSS)
+
+    def sample(seed):
+        imgs, pm, dv = synth.synth_sample(H, W, N, seed=seed)
+        g = torch.Generator().manual_seed(seed)
+        gt, mask = {}, {}
+        for k, f in (("stage1", 8), ("stage2", 4), ("stage3", 2), ("stage4", 1)):
+            gt[k] = (synth.DEPTH_MIN_MM + (synth.DEPTH_MAX_MM - synth.DEPTH_MIN_MM) * torch.rand(1, H // f, W // f, generator=g)).to(DEV)
+            mask[k] = (torch.rand(1, H // f, W // f, generator=g) > 0.3).float().to(DEV)
+        return imgs.to(DEV), {k: v.to(DEV) for k, v in pm.items()}, dv.to(DEV), gt, mask
+
+    samples = [sample(s) for s in (41, 42, 43, 44)]
+    max_lr, total = 2e-3, 8
+
+    def sched(opt):          # the reference's scheduler (train.py:510-511) on a short horizon: the rate changes a lot per step
+        return torch.optim.lr_scheduler.OneCycleLR(opt, max_lr, total, pct_start=0.25, cycle_momentum=False, anneal_strategy="linear")
+
+    opt_e = torch.optim.AdamW(ref.parameters(), lr=1e-4, capturable=True)
+    sch_e = sched(opt_e)
+    lrs_e = []
+    for imgs, pm, dv, gt, mask in samples:
+        opt_e.zero_grad(set_to_none=True)
+        loss, _ = mvs_loss_static(ref(imgs, pm, dv)["depth"], gt, mask, DL)
+        loss.backward()
+        lrs_e.append(float(opt_e.param_groups[0]["lr"]))
+        opt_e.step()
+        sch_e.step()
+    opt_g = torch.optim.AdamW(net.parameters(), lr=1e-4, capturable=True)
+    sch_g = sched(opt_g)                                   # built BEFORE the capture, as a training script would
+    step = train_graph.GraphedTrainStep(net, opt_g, *samples[0])
+    assert torch.is_tensor(opt_g.param_groups[0]["lr"]) and opt_g.param_groups[0]["lr"].is_cuda
+    assert getattr(net, "static_depth_range", None) is None       # the captured constant does not stay on the model
+    lrs_g = []
+    for smp in samples:
+        lrs_g.append(float(opt_g.param_groups[0]["lr"]))
+        step(*smp)
+        sch_g.step()
+    assert max(lrs_e) > 5 * min(lrs_e)                             # the schedule really moves
+    assert all(abs(a - b) <= 1e-9 + 1e-6 * abs(b) for a, b in zip(lrs_g, lrs_e)), (lrs_g, lrs_e)
+    # parameters after four scheduled steps: AdamW moves a weight by ~lr per step, so a frozen capture-time rate (1e-4 / 25 at the
+    # start of the cycle) would leave the two models ~sum(lrs) apart; with the schedule followed they agree like the unscheduled test
+    moved = max(float((p - q).abs().max()) for p, q in zip(ref.parameters(), build_model("8,8,8", seed=5, device=DEV)[0].parameters()))
+    apart = [float((p - q).abs().max()) for p, q in zip(net.parameters(), ref.parameters())]
+    close = sum(int(((p - q).abs() <= 0.05 * max(lrs_e)).sum()) for p, q in zip(net.parameters(), ref.parameters()))
+    n_par = sum(p.numel() for p in net.parameters())
+    print(f"[graphed + OneCycleLR] lrs {lrs_e}; eager model moved {moved:.3e}; graph vs eager max {max(apart):.3e}; close {close}/{n_par}")
+    assert moved > 0.5 * sum(lrs_e) and close >= 0.97 * n_par
+    step.check_ranges()                                            # every replayed sample had the captured range
+    # a momentum-cycling scheduler changes betas, which ARE captured by value: refused
+    opt_g.param_groups[0]["betas"] = (0.5, 0.999)
+    with pytest.raises(ValueError):
+        step()
+    opt_g.param_groups[0]["betas"] = step._betas[0]
+    # another depth range: host tensor -> refused at once; device tensor -> counted, reported by check_ranges()
+    imgs, pm, dv, gt, mask = samples[1]
+    dv_bad = dv.clone()
+    dv_bad[:, -1] *= 1.01
+    with pytest.raises(ValueError):
+        step.load_sample(imgs, pm, dv_bad.cpu(), gt, mask)
+    step.load_sample(imgs, pm, dv_bad, gt, mask)
+    with pytest.raises(ValueError):
+        step.check_ranges()
+    step.load_sample(imgs, pm, dv, gt, mask)                       # restore the captured buffers
+    # eager train-mode forward of the SAME model after replays: its own sample's range, and the weights the graph wrote
+    # (ops._PACK_CACHE is dropped after every replay: the device-side optimizer step does not bump Tensor._version)
+    with torch.no_grad():
+        a = net(imgs, pm, dv)["depth"][-1].clone()
+        twin = copy.deepcopy(net)                                  # fresh module objects: nothing cached can be reused
+        b = twin(imgs, pm, dv)["depth"][-1]
+        assert torch.allclose(a, b, rtol=0, atol=1e-3), float((a - b).abs().max())
+        wide = dv.clone()
+        wide[:, 0] *= 0.9                                           # a different range must change the eager result (no stale constant)
+        wide = torch.linspace(float(wide[0, 0]), float(wide[0, -1]), dv.shape[1], device=DEV).view(1, -1)
+        c = net(imgs, pm, wide)["depth"][0]
+        d = twin(imgs, pm, wide)["depth"][0]
+        assert torch.allclose(c, d, rtol=0, atol=1e-3) and not torch.allclose(c, net(imgs, pm, dv)["depth"][0], atol=1e-3)
 
 
 @pytest.mark.parametrize("cout,cin,ks", [(16, 8, 3), (12, 20, 3), (64, 32, 1), (8, 3, 5), (48, 33, 3)])

@@ -192,3 +192,31 @@ def test_synthetic_rig_is_deterministic_and_well_posed():
     sd1 = synth.randomize_state_dict({"a.conv.weight": torch.empty(4, 3, 3, 3), "update_block.0.x.bias": torch.empty(5),
                                       "update_block_depth1.x.bias": torch.empty(5)}, seed=1)
     assert torch.equal(sd1["update_block.0.x.bias"], sd1["update_block_depth1.x.bias"])   # aliases get equal values
+
+
+def test_static_loss_drops_non_finite_estimates_at_masked_pixels_like_the_reference():
+    """``mvs_loss_static`` (the capturable form of models/module.py:526-552) against ``mvs_loss``: depth is 1 / inv_depth and can be
+    Inf where inv_depth is 0; the reference's boolean indexing drops masked pixels, a product with a 0 / 1 mask would turn them into
+    NaN.  Value and gradient must agree, with Inf / NaN sitting at masked pixels."""
+    import torch
+    from effi_mvs_plus_amd.models.module import mvs_loss, mvs_loss_static
+    torch.manual_seed(0)
+    ins = [torch.rand(2, 12, 10, requires_grad=True) for _ in range(4)]
+    gt = {"stage1": torch.rand(2, 12, 10), "stage2": torch.rand(2, 12, 10)}
+    mask = {k: (torch.rand(2, 12, 10) > 0.4).float() for k in gt}
+    with torch.no_grad():
+        ins[0][0, 0, 0], ins[1][1, 3, 4], ins[3][0, 5, 5] = float("inf"), float("nan"), -float("inf")
+    mask["stage1"][0, 0, 0] = mask["stage1"][1, 3, 4] = mask["stage2"][0, 5, 5] = 0
+    dl = (1, 1, 2, 2)
+    a, pa = mvs_loss_static(ins, gt, mask, dl)
+    b, pb = mvs_loss(ins, gt, mask, dl)
+    assert torch.isfinite(a) and abs(float(a) - float(b)) <= 1e-6 * abs(float(b))
+    assert all(abs(float(pa[k]) - float(pb[k])) <= 1e-6 for k in pb)
+    a.backward()
+    ga = [t.grad.clone() for t in ins]
+    for t in ins:
+        t.grad = None
+    b.backward()
+    for x, t in zip(ga, ins):
+        assert torch.isfinite(x).all() and torch.allclose(x, t.grad, rtol=1e-6, atol=1e-9)
+

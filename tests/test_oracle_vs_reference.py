@@ -182,3 +182,60 @@ def test_public_callables_of_the_three_mirrored_files_have_the_references_signat
                 assert g_[:len(w_)] == w_, f"{mod}.{name}: {g_} vs reference {w_}"
                 for extra in g_[len(w_):]:
                     assert extra[1] is not inspect.Parameter.empty, f"{mod}.{name}: appended parameter {extra[0]} needs a default"
+
+
+def test_fusion_and_dtu_filter_functions_have_the_references_signatures():
+    """Row n3's surface: the functions of misc/fusion.py that test_tank.py:486-509 calls and the two of test_dtu_dypcd.py:164-233,
+    by name, parameter names, order and defaults (the reference's files are read as SOURCE here: misc/fusion.py calls ``.cuda()`` at
+    import-free definition time only, but test_dtu_dypcd.py imports cv2 / plyfile, absent from this image -- its two ``def`` lines are
+    parsed with ``ast`` instead of imported)."""
+    import ast
+    import inspect
+    import os
+    import sys
+
+    from refimport import REF_ROOT, load_reference
+    if load_reference() is None:
+        pytest.skip("reference tree not present")
+    from effi_mvs_plus_amd import dtu_fusion, fusion
+
+    def ast_sigs(path, names):
+        tree = ast.parse(open(path).read())
+        out = {}
+        for node in tree.body:
+            if isinstance(node, ast.FunctionDef) and node.name in names:
+                a = node.args
+                pos = [x.arg for x in a.args]
+                defaults = [None] * (len(pos) - len(a.defaults)) + [ast.literal_eval(d) for d in a.defaults]
+                out[node.name] = list(zip(pos, defaults, [i >= len(pos) - len(a.defaults) for i in range(len(pos))]))
+        return out
+
+    def our_sig(fn):
+        return [(p_.name, None if p_.default is inspect.Parameter.empty else p_.default, p_.default is not inspect.Parameter.empty)
+                for p_ in inspect.signature(fn).parameters.values()]
+
+    tank = ["get_pixel_grids", "bin_op_reduce", "idx_img2cam", "idx_cam2world", "idx_world2cam", "idx_cam2img", "get_reproj_dynamic",
+            "vis_filter_dynamic"]
+    want = ast_sigs(os.path.join(REF_ROOT, "misc", "fusion.py"), tank)
+    assert sorted(want) == sorted(tank)
+    for name in tank:
+        got = our_sig(getattr(fusion, name))
+        assert got[:len(want[name])] == want[name], f"fusion.{name}: {got} vs reference {want[name]}"
+        assert all(has_default for _, _, has_default in got[len(want[name]):]), f"fusion.{name}: appended parameters need defaults"
+    dtu = ["reproject_with_depth", "check_geometric_consistency", "read_camera_parameters", "read_pair_file", "read_img", "save_mask"]
+    want = ast_sigs(os.path.join(REF_ROOT, "test_dtu_dypcd.py"), dtu)
+    assert sorted(want) == sorted(dtu)
+    for name in dtu:
+        got = our_sig(getattr(dtu_fusion, name))
+        w_ = want[name]
+        if name == "check_geometric_consistency":          # the reference's last parameter (confidence, unused) has no default; ours accepts its absence
+            assert [g_[0] for g_ in got[:len(w_)]] == [x[0] for x in w_], (got, w_)
+        else:
+            assert got[:len(w_)] == w_, f"dtu_fusion.{name}: {got} vs reference {w_}"
+        assert all(has_default for _, _, has_default in got[len(w_):]), f"dtu_fusion.{name}: appended parameters need defaults"
+    # the driver's call sites name no other attribute of the module (test_tank.py:455-571)
+    src = open(os.path.join(REF_ROOT, "test_tank.py")).read()
+    import re
+    used = set(re.findall(r"\bfusion\.([A-Za-z_][A-Za-z0-9_]*)", src))
+    assert used and all(hasattr(fusion, u) for u in used), sorted(u for u in used if not hasattr(fusion, u))
+
