@@ -585,7 +585,13 @@ def main():
                                   f"{max(1, args.in_flight)} independent view(s) in flight, one stream each"
                                   if graphed is not None else "eager: every kernel enqueued from Python"),
                        "parallelism": f"view-sharded x{world}, {'RCCL' if args.backend == 'nccl' else 'gloo (rehearsal)'} gather of "
-                                      f"depth+confidence to rank 0 inside the timed region" if world > 1 else "single GPU"},
+                                      f"depth+confidence to rank 0 inside the timed region" if world > 1 else "single GPU",
+                       # what 'value' is and is not: views in flight, split-precision products; the other two figures beside it
+                       "views_in_flight": (max(1, args.in_flight) if graphed is not None else 1),
+                       "single_stream_ms": (single_stream or {}).get("ms_per_view"),
+                       "single_stream_views_per_s": (single_stream or {}).get("value"),
+                       "fp32_strict_views_per_s": None, "fp32_strict_ms_per_view": None,
+                       "arithmetic": precision},
             "in_flight": (max(1, args.in_flight) if graphed is not None else 1),
             # one view after the other (a view's latency) next to the headline's views in flight; strict-fp32 figure filled in below
             "value_single_stream": (single_stream or {}).get("value"),
@@ -688,6 +694,9 @@ def main():
             torch.cuda.empty_cache()
         if other == "fp32" and other_graph and "value" in other_graph:
             result["value_fp32"] = other_graph["value"]           # exact fp32 products everywhere, one view after the other (graph replay)
+            # ... and inside ``config`` (the driver keeps config and drops extra keys): nobody should read the headline alone
+            result["config"]["fp32_strict_views_per_s"] = other_graph["value"]
+            result["config"]["fp32_strict_ms_per_view"] = other_graph["ms_per_step"]
         result["other_precision"] = {"mode": other, "dtype": DTYPE[other],
                                      "graph_replay": other_graph,        # one view after the other: like-for-like with 'single_stream' (or the headline when --in-flight 1)
                                      "eager": {"value": args.steps / dt_other, "unit": "views/s", "ms_per_step": dt_other / args.steps * 1e3},

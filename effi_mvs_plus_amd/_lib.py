@@ -111,7 +111,7 @@ SIGNATURES = {
     "effi_getcost_bwd_f32": [_vp, _vp, _i, _i, _vp, _vp, _l, _l, _i, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _vp, _vp],
     "effi_softargmin_bwd_f32": [_vp, _vp, _l, _l, _i, _i, _vp, _vp, _vp],
     "effi_view_aggregate_bwd_f32": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
-    "effi_convex_upsample2x_bwd_f32": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "effi_convex_upsample2x_bwd_f32": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "effi_warpcorr_dyn_bwd_f32": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
 }
 

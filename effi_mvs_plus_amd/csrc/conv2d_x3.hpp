@@ -14,6 +14,19 @@
 #define EFFI_FN(name) name
 #endif
 
+// Diagnostic ablation builds of the split-resident tile (tools/ablate_sr.sh; NEVER the shipped library): -DEFFI_ABL=<bits>
+//   1 no global loads of the A image   2 no K loop (no LDS fragment reads, no MFMAs)   4 LDS fragment reads but no MFMAs
+//   8 epilogue = raw accumulators stored planar (no bias / activation / auxiliary loads / split-resident store)   16 no epilogue
+#ifndef EFFI_ABL
+#define EFFI_ABL 0
+#endif
+#ifndef EFFI_PIPE_FRAGS
+// 1: the K loop requests its LDS fragments one step ahead (see PIPE in the tile function).  Measured (profiles/r04_f_pipe_ab.txt,
+// same box, per launch): -2..-4 % at 148x200, +-0 at 296x400, +10..+14 % on the 592x800 pair / encoder kernels (the second fragment
+// set costs a wave per SIMD there: 134 -> 174 registers) and -2 % on z | r: not the default.
+#define EFFI_PIPE_FRAGS 0
+#endif
+
 namespace {
 
 #ifdef EFFI_BF16_ONLY
@@ -316,7 +329,7 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
             const int cl = (c1 < 0) ? cb : (c2 < 0 ? c1 : c2);
             const f32x4* base = reinterpret_cast<const f32x4*>(src) + (long)(cl >> 2) * ((long)a.sr_hp * a.sr_wp);   // 4 planes per chunk
 #pragma unroll
-            for (int j = 0; j < NUA; ++j) pa[j] = base[goff[j]];
+            for (int j = 0; j < NUA; ++j) pa[j] = (EFFI_ABL & 1) ? f32x4{0.0f, 0.0f, 0.0f, 0.0f} : base[goff[j]];
         } else {
         int cb = ch * CCH + soct * 8;                                  // first channel of this thread's octet
         const int emax = min(cin_eff - cb, 8) - 1;                     // last real channel of the octet (< 0: none)
@@ -504,27 +517,61 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
         if (ch + 1 < nchunks) prefetch(ch + 1);
-#pragma unroll
-        for (int s_ = 0; s_ < NKS; ++s_) {
-            bf16x8 ah[MR], al[MR];
+        // SOFTWARE-PIPELINED FRAGMENT READS (PIPE).  As the compiler schedules the plain loop, every K-step opens with its 2 MR + 2 NT
+        // ds_read_b128 and waits for them in front of its first MFMA; an ablation (tools/ablate_sr.sh, profiles/r04_e_ablate_sr.txt)
+        // put 18 us of the stage-3 z | r kernel's 44 on these exposed reads and only 9 on the MFMAs -- the phases add up instead of
+        // overlapping.  Here the pixel fragments of step s + 1 are requested at the start of step s (second register set) and the
+        // weight fragments of (s + 1, n) right after the multiplies of (s, n) (into the registers those just freed); LDS returns in
+        // order, so each request sits BEHIND what the next multiplies need.  sched_barrier pins the order (the scheduler otherwise
+        // sinks every read back to its first use).  Same MFMAs on the same accumulators in the same order: bitwise the plain loop.
+        constexpr bool PIPE = SR && EFFI_PIPE_FRAGS;
+        bf16x8 ahb[PIPE ? 2 : 1][MR], alb[PIPE ? 2 : 1][MR], bhb[NT], blb[NT];
+        auto load_a = [&](int s_, int buf) {
 #pragma unroll
             for (int m = 0; m < MR; ++m) {
-                ah[m] = *reinterpret_cast<const bf16x8*>(&lds_ah[koff[s_] + m * (MROW + MCOL)]);
-                if (!kHiOnly) al[m] = *reinterpret_cast<const bf16x8*>(&lds_al_rd[koff[s_] + m * (MROW + MCOL)]);
+                ahb[buf][m] = *reinterpret_cast<const bf16x8*>(&lds_ah[koff[s_] + m * (MROW + MCOL)]);
+                if (!kHiOnly) alb[buf][m] = *reinterpret_cast<const bf16x8*>(&lds_al_rd[koff[s_] + m * (MROW + MCOL)]);
+            }
+        };
+        auto load_b = [&](int s_, int n) {
+            bhb[n] = *reinterpret_cast<const bf16x8*>(&lds_b[(((s_ * NT + n) * 2 + 0) * 64 + lane) * 8]);
+            blb[n] = bhb[n];
+            if (!kHiOnly) blb[n] = *reinterpret_cast<const bf16x8*>(&lds_b[(((s_ * NT + n) * 2 + 1) * 64 + lane) * 8]);
+        };
+        constexpr int NKS_RUN = (EFFI_ABL & 2) ? 0 : NKS;
+        if (PIPE && NKS_RUN > 0) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) load_b(0, n);
+            load_a(0, 0);
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < NKS_RUN; ++s_) {
+            const int cur = PIPE ? (s_ & 1) : 0;
+            if (PIPE) {
+                if (s_ + 1 < NKS) load_a(s_ + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                load_a(s_, 0);
             }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&lds_b[(((s_ * NT + n) * 2 + 0) * 64 + lane) * 8]);
-                bf16x8 bl = bh;
-                if (!kHiOnly) bl = *reinterpret_cast<const bf16x8*>(&lds_b[(((s_ * NT + n) * 2 + 1) * 64 + lane) * 8]);
+                if (!PIPE) load_b(s_, n);
 #pragma unroll
                 for (int m = 0; m < MR; ++m) {
-                    // weights x pixels: D[cout][pixel] (transposed fragment, see conv_epilogue_store_t)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah[m], acc[m][n], 0, 0, 0);
-                    if (!kHiOnly) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah[m], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al[m], acc[m][n], 0, 0, 0);
+                    if (EFFI_ABL & 4) {                  // keep the fragment reads alive, issue no MFMA
+                        asm volatile("" ::"v"(bhb[n]), "v"(blb[n]), "v"(ahb[cur][m]), "v"(alb[cur][m]));
+                        continue;
                     }
+                    // weights x pixels: D[cout][pixel] (transposed fragment, see conv_epilogue_store_t)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhb[n], ahb[cur][m], acc[m][n], 0, 0, 0);
+                    if (!kHiOnly) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blb[n], ahb[cur][m], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhb[n], alb[cur][m], acc[m][n], 0, 0, 0);
+                    }
+                }
+                if (PIPE) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (s_ + 1 < NKS) load_b(s_ + 1, n);
                 }
             }
         }
@@ -535,6 +582,24 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
         }
     }
 
+    if (EFFI_ABL & 24) {                                 // ablation: raw planar store of the accumulators, or (16) nothing but a sink
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const int x = x0 + li + (WIDE ? 16 * m : 0), y = y0 + (WIDE ? wv : wv * MR + m);
+            if (y >= h || x >= w) continue;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (EFFI_ABL & 16) {
+                        if (acc[m][n][r] == 1.2345e38f) a.out0[0] = 1.0f;
+                    } else if (n * 16 + 4 * lk + r < min(a.cout, a.hd > 0 ? a.hd : a.cout)) {
+                        a.out0[(long)(n * 16 + 4 * lk + r) * hw + (long)y * w + x] = acc[m][n][r];
+                    }
+                }
+        }
+        return;
+    }
     if (EPI == EFFI_EPI_K1 || EPI == EFFI_EPI_K1UP) {
         // Fused 1x1 convolution (convd -> convc of the encoder, models/update.py:78-80,93-96): the 3x3 result of a lane
         // -- channels 4*lk..4*lk+3 of pixel li, per N-tile -- is exactly the B fragment of v_mfma_f32_16x16x16_bf16 (K = 16
@@ -715,6 +780,14 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
 
 template <int NT, int MR, int EPI, bool ZB = false, bool WIDE = false, bool SR = false, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void conv2d_k3_bf16x3_kernel(const Conv2dArgs a, int tiles_x, int ntiles) {
+#ifdef EFFI_STAGGER
+    // experiment: workgroups that start together on one CU (first come first served: blocks b, b + 256, b + 512 of the first round)
+    // run their load / multiply / epilogue phases in step; delay the second and third by a fraction of a tile's time
+    if (SR && gridDim.x > 512) {
+        const int slot = (blockIdx.x >> 8) % 3;
+        for (int i = 0; i < slot * EFFI_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     conv2d_k3_bf16x3_tile<NT, MR, EPI, ZB, WIDE, SR, NW>(a, tiles_x, ntiles, blockIdx.x, gridDim.x, blockIdx.y);
 }
 

@@ -467,12 +467,14 @@ __global__ void softargmin_bwd_kernel(const float* __restrict__ logits, const fl
     for (int d = 0; d < D; ++d) m = fmaxf(m, logits[(long)d * hw + p]);
     float sum = 0.0f;
     for (int d = 0; d < D; ++d) sum += expf(logits[(long)d * hw + p] - m);
-    float dep = 0.0f;
-    for (int d = 0; d < D; ++d) dep += (expf(logits[(long)d * hw + p] - m) / sum) * hyp[d * dds + p * dps];
+    // glogits_d = g p_d (hyp_d - E[hyp]): hypotheses of 425..935 mm a few mm apart -- the difference cancels 2-3 digits, so the expectation
+    // and the difference are formed in double (the probabilities themselves are the forward's fp32 values)
+    double dep = 0.0;
+    for (int d = 0; d < D; ++d) dep += (double)(expf(logits[(long)d * hw + p] - m) / sum) * (double)hyp[d * dds + p * dps];
     const float g = gdepth[p];
     for (int d = 0; d < D; ++d) {
         const float pr = expf(logits[(long)d * hw + p] - m) / sum;
-        glogits[(long)d * hw + p] = g * pr * (hyp[d * dds + p * dps] - dep);
+        glogits[(long)d * hw + p] = (float)((double)g * (double)pr * ((double)hyp[d * dds + p * dps] - dep));
     }
 }
 
@@ -485,23 +487,35 @@ __global__ void view_aggregate_bwd_kernel(const float* __restrict__ sim_views, c
     float wsum = 0.0f;
     for (int v = 0; v < S; ++v) wsum += weights[(long)v * hw + p];
     const float den = wsum + 1e-6f;
-    for (int v = 0; v < S; ++v) gw[(long)v * hw + p] = 0.0f;
+    // g w_v = sum_d g_d (s_vd - out_d) / den is a sum of differences that mostly cancel (every view sees nearly the same similarity);
+    // the view-weight net's gradients are sums of it over all pixels.  Aggregate, difference and sum in double, one rounding at the end.
+    double gwa[EFFI_MAX_VIEWS];                  // constant trip counts below: stays in registers
+#pragma unroll
+    for (int v = 0; v < EFFI_MAX_VIEWS; ++v) gwa[v] = 0.0;
     for (int d = 0; d < D; ++d) {
-        float acc = 0.0f;
-        for (int v = 0; v < S; ++v) acc += sim_views[((long)v * D + d) * hw + p] * weights[(long)v * hw + p];
-        const float o = acc / den, g = gout[(long)d * hw + p];
-        for (int v = 0; v < S; ++v) {
-            const float s = sim_views[((long)v * D + d) * hw + p];
-            gsim[((long)v * D + d) * hw + p] = g * weights[(long)v * hw + p] / den;
-            gw[(long)v * hw + p] += g * (s - o) / den;
+        double acc = 0.0;
+        for (int v = 0; v < S; ++v) acc += (double)sim_views[((long)v * D + d) * hw + p] * (double)weights[(long)v * hw + p];
+        const double o = acc / (double)den;
+        const float g = gout[(long)d * hw + p];
+#pragma unroll
+        for (int v = 0; v < EFFI_MAX_VIEWS; ++v) {
+            if (v < S) {
+                const float s = sim_views[((long)v * D + d) * hw + p];
+                gsim[((long)v * D + d) * hw + p] = g * weights[(long)v * hw + p] / den;
+                gwa[v] += (double)g * ((double)s - o) / (double)den;
+            }
         }
     }
+#pragma unroll
+    for (int v = 0; v < EFFI_MAX_VIEWS; ++v)
+        if (v < S) gw[(long)v * hw + p] = (float)gwa[v];
 }
 
 // convex upsampling backward (models/Effi_MVS_plus.py:167-178), ratio 2: up[2y+i][2x+j] = sum_k softmax_k(mask[k][i][j]) * nb_k,
-// nb_k = inv at (y + k/3 - 1, x + k%3 - 1) (zero outside).  gmask is written; ginv receives atomic adds (zero on entry).
+// nb_k = inv at (y + k/3 - 1, x + k%3 - 1) (zero outside).  gmask is written; the contribution of pixel p to its neighbour k goes to
+// contrib[k][p], and convex_upsample2x_gather_kernel sums, for every pixel, the nine contributions addressed to it in a fixed order.
 __global__ void convex_upsample2x_bwd_kernel(const float* __restrict__ inv, const float* __restrict__ mask, int h, int w,
-                                             const float* __restrict__ gup, float* __restrict__ gmask, float* __restrict__ ginv) {
+                                             const float* __restrict__ gup, float* __restrict__ gmask, float* __restrict__ contrib) {
     const int p = blockIdx.x * TPB + threadIdx.x;
     if (p >= h * w) return;
     const int y = p / w, x = p - y * w;
@@ -538,10 +552,21 @@ __global__ void convex_upsample2x_bwd_kernel(const float* __restrict__ inv, cons
         }
     }
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-        const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
-        if (yy >= 0 && yy < h && xx >= 0 && xx < w) unsafeAtomicAdd(&ginv[(long)yy * w + xx], gn[k]);
+    for (int k = 0; k < 9; ++k) contrib[(long)k * hw + p] = gn[k];
+}
+
+__global__ void convex_upsample2x_gather_kernel(const float* __restrict__ contrib, int h, int w, float* __restrict__ ginv) {
+    const int q = blockIdx.x * TPB + threadIdx.x;
+    if (q >= h * w) return;
+    const int y = q / w, x = q - y * w;
+    const long hw = (long)h * w;
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {                       // pixel (y - dy, x - dx) names this pixel as its neighbour k = (dy + 1) * 3 + dx + 1
+        const int yy = y - (k / 3 - 1), xx = x - (k % 3 - 1);
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w) acc += contrib[(long)k * hw + (long)yy * w + xx];
     }
+    ginv[q] = acc;
 }
 
 }  // namespace
@@ -741,10 +766,12 @@ extern "C" int effi_view_aggregate_bwd_f32(const float* sim_views, const float* 
 }
 
 extern "C" int effi_convex_upsample2x_bwd_f32(const float* inv_depth, const float* mask, int h, int w, const float* gup, float* gmask,
-                                              float* ginv, effi_stream_t stream) {
-    if (!inv_depth || !mask || !gup || !gmask || !ginv || h < 1 || w < 1) return EFFI_ERR_BADARG;
-    hipLaunchKernelGGL(convex_upsample2x_bwd_kernel, dim3(effi_cdiv((long)h * w, TPB)), dim3(TPB), 0, effi_s(stream), inv_depth, mask, h,
-                       w, gup, gmask, ginv);
+                                              float* ginv, float* scratch9, effi_stream_t stream) {
+    if (!inv_depth || !mask || !gup || !gmask || !ginv || !scratch9 || h < 1 || w < 1) return EFFI_ERR_BADARG;
+    hipStream_t st = effi_s(stream);
+    hipLaunchKernelGGL(convex_upsample2x_bwd_kernel, dim3(effi_cdiv((long)h * w, TPB)), dim3(TPB), 0, st, inv_depth, mask, h,
+                       w, gup, gmask, scratch9);
+    hipLaunchKernelGGL(convex_upsample2x_gather_kernel, dim3(effi_cdiv((long)h * w, TPB)), dim3(TPB), 0, st, scratch9, h, w, ginv);
     EFFI_LAUNCH_CHECK();
     return EFFI_OK;
 }

@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_bwd_kernel(const float* __re
                                                                const float* __restrict__ interval, const float* __restrict__ view_w,
                                                                int vw_shift, int h, int w, int D, const float* __restrict__ sim,
                                                                const float* __restrict__ gsim, float* __restrict__ grad_ref,
-                                                               EffiOutList grad_srcs, float* __restrict__ grad_vw) {
+                                                               EffiOutList grad_srcs, double* __restrict__ grad_vw) {
     using G = WarpGeom<C>;
     int x, y, sub;
     if (!tile_pixel<C>(blockIdx.x, gridDim.x, h, w, x, y, sub)) return;
@@ -1073,7 +1073,10 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_bwd_kernel(const float* __re
         const float ry = rt[3] * fx + rt[4] * fy + rt[5];
         const float rz = rt[6] * fx + rt[7] * fy + rt[8];
         const float wv = view_w[(long)v * vh * vw + vpix];
-        float gwv = 0.0f;
+        // gradient of the view weight: a sum over hypotheses (here) and over the 4 / 16 fine pixels of a weight cell (atomics below) of
+        // differences (s_vd - sim_d) that mostly cancel; accumulated in DOUBLE, atomics included, so that the order of the adds does
+        // not show in fp32 (in fp32 the view-weight net's gradients moved by 3e-3 of their peak between two runs of one step)
+        double gwv = 0.0;
         for (int d = 0; d < D; ++d) {
             const float dep = 1.0f / fmaxf(smin + (float)d * step, 1e-5f);
             Taps t;
@@ -1095,7 +1098,7 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_bwd_kernel(const float* __re
             gr.y = fmaf(coef, wp.y, gr.y);
             gr.z = fmaf(coef, wp.z, gr.z);
             gr.w = fmaf(coef, wp.w, gr.w);
-            gwv = fmaf(g, (s_vd - sim[(long)d * hw + pix]) / den, gwv);
+            gwv += (double)g * ((double)s_vd - (double)sim[(long)d * hw + pix]) / (double)den;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (t.w[k] == 0.0f) continue;
@@ -1354,7 +1357,7 @@ extern "C" int effi_view_table_set(const void** table_dev, const void* const* pt
 extern "C" int effi_warpcorr_dyn_bwd_f32(const float* ref_nhwc, const float* const* src_nhwc, int S, const float* rt,
                                          const float* cur_depth, const float* interval, const float* view_w, int vw_shift, int C, int h,
                                          int w, int D, const float* sim, const float* grad_sim, float* grad_ref_nhwc,
-                                         float* const* grad_src_nhwc, float* grad_view_w, effi_stream_t stream) {
+                                         float* const* grad_src_nhwc, double* grad_view_w, effi_stream_t stream) {
     EffiPtrList l;
     if (!fill_views(src_nhwc, S, l) || !ref_nhwc || !rt || !cur_depth || !interval || !view_w || !sim || !grad_sim || !grad_ref_nhwc ||
         !grad_src_nhwc || !grad_view_w)

@@ -122,6 +122,9 @@ class Conv3d(nn.Module):
     @ops.on_tensor_device
 
     def forward(self, x):
+        if self.training:                      # BatchNorm on batch statistics, differentiable: forward AND backward on HIP kernels
+            from .. import train_path
+            return train_path.conv3d_block(self, [x])
         return _stack([self.run([x[i].contiguous()]) for i in range(x.shape[0])])
 
 
@@ -163,6 +166,9 @@ class Deconv3d(nn.Module):
     @ops.on_tensor_device
 
     def forward(self, x):
+        if self.training:
+            from .. import train_path
+            return train_path.deconv3d_block(self, x)
         return _stack([self.run(x[i].contiguous()) for i in range(x.shape[0])])
 
 
@@ -406,6 +412,9 @@ class CostRegNet_2_sample_FPN3D_Fast(nn.Module):
     @ops.on_tensor_device
 
     def forward(self, x):
+        if self.training:
+            from .. import train_path
+            return train_path.cost_regnet(self, x)
         outs = [self.run(x[i].contiguous()) for i in range(x.shape[0])]
         return _stack([o[0] for o in outs]), _stack([o[1] for o in outs])
 
@@ -468,6 +477,9 @@ class cost_up_small(nn.Module):
     @ops.on_tensor_device
 
     def forward(self, x, IGEV_cost):
+        if self.training:
+            from .. import train_path
+            return train_path.cost_up_small(self, x, IGEV_cost)
         outs = [self.run(x[i].contiguous(), IGEV_cost[i].contiguous()) for i in range(x.shape[0])]
         return _stack([o[0] for o in outs]), _stack([o[1] for o in outs])
 

@@ -1860,8 +1860,9 @@ def convex_upsample2x_bwd(inv_depth, mask, gup):
     _t(inv_depth, "inv_depth"), _t(mask, "mask"), _t(gup, "grad")
     h, w = inv_depth.shape[-2:]
     gmask = torch.empty_like(mask)
-    ginv = torch.zeros_like(inv_depth)
-    check(_lib.lib().effi_convex_upsample2x_bwd_f32(_p(inv_depth), _p(mask), h, w, _p(gup), _p(gmask), _p(ginv), _stream()),
+    ginv = torch.empty_like(inv_depth)
+    scratch = torch.empty(9, h, w, device=inv_depth.device, dtype=torch.float32)       # per-pixel contributions, gathered in a fixed order
+    check(_lib.lib().effi_convex_upsample2x_bwd_f32(_p(inv_depth), _p(mask), h, w, _p(gup), _p(gmask), _p(ginv), _p(scratch), _stream()),
           "effi_convex_upsample2x_bwd_f32")
     return gmask, ginv
 
@@ -1878,8 +1879,8 @@ def warpcorr_dyn_bwd(ref_nhwc, srcs_nhwc, rt, cur_depth, interval, view_w, D, si
         shift += 1
     g_ref = torch.empty_like(ref_nhwc)
     g_src = [torch.zeros_like(s_) for s_ in srcs_nhwc]
-    g_vw = torch.zeros_like(view_w)
+    g_vw = torch.zeros(view_w.shape, device=view_w.device, dtype=torch.float64)      # 64-bit atomics: the sum cancels (see the kernel)
     check(_lib.lib().effi_warpcorr_dyn_bwd_f32(_p(ref_nhwc), _ptr_array(srcs_nhwc), S, _p(rt), _p(cur_depth), _p(interval), _p(view_w), shift,
                                                Cc, h, w, D, _p(sim), _p(grad_sim), _p(g_ref), _ptr_array(g_src), _p(g_vw), _stream()),
           "effi_warpcorr_dyn_bwd_f32")
-    return g_ref, g_src, g_vw
+    return g_ref, g_src, g_vw.float()

@@ -579,14 +579,16 @@ int effi_softargmin_bwd_f32(const float* logits, const float* hyp, long depth_ds
 int effi_view_aggregate_bwd_f32(const float* sim_views, const float* weights, int S, int D, int hw, const float* gout, float* gsim,
                                 float* gw, effi_stream_t stream);
 /* Backward of the convex x2 upsampling (models/Effi_MVS_plus.py:167-178): gup [2h][2w] -> gmask [36][h][w] (written),
- * ginv [h][w] (atomic adds; zero on entry). */
+ * ginv [h][w] (written).  scratch9: [9][h][w] floats -- every pixel's contribution to its nine neighbours is written there and a
+ * second launch gathers them in a fixed order (no atomics: bitwise repeatable). */
 int effi_convex_upsample2x_bwd_f32(const float* inv_depth, const float* mask, int h, int w, const float* gup, float* gmask, float* ginv,
-                                   effi_stream_t stream);
+                                   float* scratch9, effi_stream_t stream);
 /* Backward of effi_warpcorr_dyn_f32 (GetCost_initvolume.forward, models/Effi_MVS_plus.py:184-251): sim = the forward's output,
- * grad_sim [D][h*w]; grad_ref_nhwc is written; grad_src_nhwc[v] and grad_view_w [S][h>>k][w>>k] must be ZERO on entry (atomics). */
+ * grad_sim [D][h*w]; grad_ref_nhwc is written; grad_src_nhwc[v] (fp32) and grad_view_w [S][h>>k][w>>k] (DOUBLE: a cancelling sum
+ * accumulated with 64-bit atomics so that the order of the adds stays below fp32 resolution) must be ZERO on entry. */
 int effi_warpcorr_dyn_bwd_f32(const float* ref_nhwc, const float* const* src_nhwc, int S, const float* rt, const float* cur_depth,
                               const float* interval, const float* view_w, int vw_shift, int C, int h, int w, int D, const float* sim,
-                              const float* grad_sim, float* grad_ref_nhwc, float* const* grad_src_nhwc, float* grad_view_w,
+                              const float* grad_sim, float* grad_ref_nhwc, float* const* grad_src_nhwc, double* grad_view_w,
                               effi_stream_t stream);
 
 /* ---- plain-bf16-operand variants of the split-precision convolution entries -------------------------------------------------
