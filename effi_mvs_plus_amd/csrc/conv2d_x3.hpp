@@ -17,6 +17,7 @@
 // Diagnostic ablation builds of the split-resident tile (tools/ablate_sr.sh; NEVER the shipped library): -DEFFI_ABL=<bits>
 //   1 no global loads of the A image   2 no K loop (no LDS fragment reads, no MFMAs)   4 LDS fragment reads but no MFMAs
 //   8 epilogue = raw accumulators stored planar (no bias / activation / auxiliary loads / split-resident store)   16 no epilogue
+//   32 generated-input kernel: no volume lookups   64 generated-input kernel: nothing generated
 #ifndef EFFI_ABL
 #define EFFI_ABL 0
 #endif
@@ -370,6 +371,14 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
     constexpr int PPT = GEN ? (APIX + NTHR - 1) / NTHR : 1;          // gmode 0: staged pixels per thread
     float gcost[PPT][6];
     bool gin[PPT];
+    if (GEN && gmode == 0 && (EFFI_ABL & 32)) {       // ablation: no lookups
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            gin[i] = true;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) gcost[i][k] = 0.25f * k;
+        }
+    } else
     if (GEN && gmode == 0) {
         const EncGenArgs& g = *gp;
         const float itv = g.interval[0];
@@ -394,6 +403,7 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
         __syncthreads();
     }
     auto generate = [&](int ch) {
+        if (EFFI_ABL & 64) return;                     // ablation: no generated image at all (LDS left as it is)
         if (GEN && gmode == 0) {
             const EncGenArgs& g = *gp;
             const int hd = g.hd;

@@ -19,6 +19,6 @@ else
   for v in $variants; do
     if [ "$v" = 0 ]; then lib=""; else lib=$PWD/abl_libs/libeffimvs_abl$v.so; fi
     echo "=== EFFI_ABL=$v"
-    EFFI_MVS_LIB=$lib python tools/bench_sr.py --stages $stages --n 40 | awk '{print $0}'
+    EFFI_MVS_LIB=$lib python tools/bench_sr.py --stages $stages --n 40 ${ROWS:+--rows "$ROWS"} | awk '{print $0}'
   done
 fi

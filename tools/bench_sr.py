@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--workload", default="cfg3")
     ap.add_argument("--n", type=int, default=50)
     ap.add_argument("--stages", default="0,1,2")
+    ap.add_argument("--rows", default="", help="substring filter of the layer names to print")
     ap.add_argument("--rotate", type=int, default=1, help="rotate over this many buffer sets (>1: working set leaves the caches)")
     args = ap.parse_args()
     from common import build_model
@@ -66,13 +67,26 @@ def main():
         wh1, bh1 = _pack(dh._c1, dh.conv1)
         wh2, bh2 = packing.pack_head_taps(dh.conv2.weight, hd)
         part = torch.empty(16, h, w, device=dev)
-        inv = torch.rand(1, h, w, generator=g).to(dev)
-        dr = torch.linspace(1 / 935.0, 1 / 425.0, 384).to(dev)
         wm, bm = _pack(blk._m0, blk.mask[0])
         c1 = blk.mask[0].out_channels
         w2m, b2m = packing.pack_mask_taps_per_lane(blk.mask[2].weight, blk.mask[2].bias, c1, scale=0.25)
+        inv = torch.rand(1, h, w, generator=g).to(dev)
+        dr = torch.linspace(1 / 935.0, 1 / 425.0, 384).to(dev)
         rows = []
         k_ = lambda i: i % R
+        # the generated-input pair (lookups + 1x1 | 7x7, then convc2 | convd2) against encoder_inputs + pair on fp32 maps
+        wc1, bc1 = e.convc1_raw()
+        w7, b7 = e.conv7_packed()
+        D = 8
+        cur = [torch.randn(D, h, w, generator=g).to(dev) for _ in range(R)]
+        reg = [torch.randn(D, h, w, generator=g).to(dev) for _ in range(R)]
+        itv = torch.full((1,), (1 / 425.0 - 1 / 935.0) / 384 * (4 >> s), device=dev)
+        dmin, dmax = (1.0 / dr[-1:]).contiguous(), (1.0 / dr[:1]).contiguous()
+        rows.append(("encgen pair (lookup|7x7 + 3x3)",
+                     timed(lambda i: (ops.encoder_inputs(inv, dr, itv, cur[k_(i)], reg[k_(i)], dmin, dmax, 3, h, w, wc1, bc1, w7, b7, hd, outs[k_(i)][2], outs[k_(i)][3]),
+                                      ops.conv2d_k3_bf16x3_pair([outs[k_(i)][2]], wc2.wx, bc2, [outs[k_(i)][3]], wd2.wx, bd2, hd, act=1, out_a=outs[k_(i)][0], out_b=outs[k_(i)][1]))),
+                     timed(lambda i: ops.encoder_pair_gen_sr(inv, dr, itv, cur[k_(i)], reg[k_(i)], dmin, dmax, 3, h, w, wc1, bc1, w7, b7, hd, wc2.wx, bc2, sets[k_(i)][4],
+                                                             wd2.wx, bd2, sets[k_(i)][5], hd))))
         rows.append(("convc2|convd2 (pair)",
                      timed(lambda i: ops.conv2d_k3_bf16x3_pair([cor1[k_(i)]], wc2.wx, bc2, [dfm1[k_(i)]], wd2.wx, bd2, hd, act=1, out_a=outs[k_(i)][0], out_b=outs[k_(i)][1])),
                      timed(lambda i: ops.conv2d_k3_pair_sr([sets[k_(i)][0]], wc2.wx, bc2, sets[k_(i)][4], [sets[k_(i)][1]], wd2.wx, bd2, sets[k_(i)][5], hd, act=1))))
@@ -93,6 +107,8 @@ def main():
                      timed(lambda i: ops.conv2d_k3_k1_up2x_sr([sets[k_(i)][2]], wm.wx, bm, c1, w2m, b2m, inv, dr))))
         print(f"stage {s + 1}: {h}x{w}, hd {hd}   (us per launch: fp32 maps / split-resident maps)")
         for name, a, b in rows:
+            if args.rows and args.rows not in name:
+                continue
             print(f"  {name:24s} {a:8.1f} {b:8.1f}   {b / a:5.2f}x")
 
 
