@@ -86,7 +86,7 @@ SIGNATURES = {
     "effi_sr_geometry": [_i, _i, _vp, _vp],
     "effi_sr_clear_border": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "effi_sr_from_planar_f32": [_vp, _i, _i, _i, _vp, _i, _i, _vp],
-    "effi_split_tanh_relu_stages_sr_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "effi_split_tanh_relu_stages_sr_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "effi_encoder_inputs_bf16x3_sr": [_vp, _vp, _i, _vp, _vp, _l, _l, _i, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp, _vp,
                                       _i, _vp, _vp, _i, _i, _vp],
     "effi_encoder_pair_gen_bf16x3_sr": [_vp, _vp, _i, _vp, _vp, _l, _l, _i, _vp, _l, _l, _i, _vp, _vp, _l, _i, _i, _i, _vp, _vp, _vp, _vp,

@@ -46,6 +46,7 @@ int fill_sr(Conv2dArgs& a, const void* const* srcs, const int* src_channels, int
     a.sr_hp = hp;
     a.sr_wp = wp;
     a.out_sr = nullptr;
+    a.aux_q4 = 0;
     return EFFI_OK;
 }
 
@@ -66,6 +67,12 @@ extern "C" int EFFI_FN(effi_conv2d_k3_bf16x3_sr)(const void* const* srcs, const 
     a.out_sr = reinterpret_cast<unsigned short*>(out_sr);
     const int nt = cout / 16;
     hipStream_t st = effi_s(stream);
+    if (epilogue & EFFI_EPI_Q4) {             // fp32 maps of a GRU epilogue in the Q4 layout (16-byte accesses)
+        epilogue &= ~EFFI_EPI_Q4;
+        if (epilogue != EFFI_EPI_GRU_ZR && epilogue != EFFI_EPI_GRU_Q) return EFFI_ERR_BADARG;
+        if ((reinterpret_cast<uintptr_t>(aux0) | reinterpret_cast<uintptr_t>(aux1) | reinterpret_cast<uintptr_t>(out0)) & 15) return EFFI_ERR_BADARG;
+        a.aux_q4 = 1;
+    }
     switch (epilogue) {
         case EFFI_EPI_PLAIN:                  // out_sr = act(conv); out0 (or NULL) = the same values as an fp32 map
             if (act < EFFI_ACT_NONE || act > EFFI_ACT_TANH) return EFFI_ERR_BADARG;

@@ -67,6 +67,7 @@ struct Conv2dArgs {
     // result in the same form.  Unused (and not initialised) by the planar kernels.
     int sr_hp, sr_wp;
     unsigned short* out_sr;
+    int aux_q4;              // SR GRU epilogues: aux0 / aux1 / out0 are [channels/4][h][w][4] fp32 maps (EFFI_EPI_Q4)
 };
 
 // GENERATED inputs of the encoder's convc2 / convd2 (models/update.py:86-91): instead of reading relu(convc1(GetCost(inv_depth))) /
@@ -153,6 +154,21 @@ __device__ __forceinline__ void conv_epilogue_store_t(const Conv2dArgs& a, const
     } else if (EPI == EFFI_EPI_GRU_ZR) {         // co0 is a multiple of 4 and hd of 16: the 4 channels are all z or all r
         if (nvalid <= 0) return;                 // cout % 16 == 0 for the GRU epilogues (checked by the host): all or nothing
         const bool is_z = co0 < a.hd;
+        if (SR && a.aux_q4) {                     // fp32 state and z in the Q4 layout: one 16-byte access per map (uniform branch)
+            const long oq = ((long)((is_z ? co0 : co0 - a.hd) >> 2) * hw + pix) * 4;
+            f32x4 g;
+            if (is_z) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[r] = effi_sigmoid_split(v[r]) * 1.0f;
+                *reinterpret_cast<f32x4*>(a.out0 + oq) = g;
+            } else {
+                const f32x4 h4 = *reinterpret_cast<const f32x4*>(a.aux0 + oq);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) g[r] = effi_sigmoid_split(v[r]) * h4[r];
+                effi_sr_store4(a.out_sr, a.sr_hp, a.sr_wp, co0 - a.hd, y, x, g);
+            }
+            return;
+        }
         const long o = (long)(is_z ? co0 : co0 - a.hd) * hw + pix;
         float* dst = (is_z ? a.out0 : a.out1) + o;
         float hv[4];
@@ -174,6 +190,16 @@ __device__ __forceinline__ void conv_epilogue_store_t(const Conv2dArgs& a, const
         for (int r = 0; r < 4; ++r) dst[(long)r * hw] = effi_sigmoid_split(v[r]) * (is_z ? 1.0f : hv[r]);
     } else if (EPI == EFFI_EPI_GRU_Q) {
         if (nvalid <= 0) return;
+        if (SR && a.aux_q4) {
+            const long oq = ((long)(co0 >> 2) * hw + pix) * 4;
+            const f32x4 h4 = *reinterpret_cast<const f32x4*>(a.aux0 + oq), z4 = *reinterpret_cast<const f32x4*>(a.aux1 + oq);
+            f32x4 g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g[r] = (1.0f - z4[r]) * h4[r] + z4[r] * effi_tanh_split(v[r]);
+            *reinterpret_cast<f32x4*>(a.out0 + oq) = g;
+            effi_sr_store4(a.out_sr, a.sr_hp, a.sr_wp, co0, y, x, g);
+            return;
+        }
         const long o = (long)co0 * hw + pix;
         float hv[4], zv[4];
 #pragma unroll

@@ -819,7 +819,7 @@ struct SplitStagesSr {
     float* hidden[4];
     float* inp[4];
     unsigned short* hidden_sr[4];
-    int hd[4], cd[4], h[4], w[4], hp[4], wp[4];
+    int hd[4], cd[4], h[4], w[4], hp[4], wp[4], q4[4];
     int first[5];
 };
 __global__ __launch_bounds__(TPB) void split_tanh_relu_stages_sr_kernel(SplitStagesSr a) {
@@ -830,12 +830,12 @@ __global__ __launch_bounds__(TPB) void split_tanh_relu_stages_sr_kernel(SplitSta
     float* __restrict__ hidden = a.hidden[0];
     float* __restrict__ inp = a.inp[0];
     unsigned short* __restrict__ hsr = a.hidden_sr[0];
-    int hd = a.hd[0], cd = a.cd[0], h = a.h[0], w = a.w[0], hp = a.hp[0], wp = a.wp[0], b0 = a.first[0];
+    int hd = a.hd[0], cd = a.cd[0], h = a.h[0], w = a.w[0], hp = a.hp[0], wp = a.wp[0], b0 = a.first[0], q4 = a.q4[0];
 #pragma unroll
     for (int j = 1; j < 4; ++j)
         if (k == j) {
             ctx = a.ctx[j]; hidden = a.hidden[j]; inp = a.inp[j]; hsr = a.hidden_sr[j];
-            hd = a.hd[j]; cd = a.cd[j]; h = a.h[j]; w = a.w[j]; hp = a.hp[j]; wp = a.wp[j]; b0 = a.first[j];
+            hd = a.hd[j]; cd = a.cd[j]; h = a.h[j]; w = a.w[j]; hp = a.hp[j]; wp = a.wp[j]; b0 = a.first[j]; q4 = a.q4[j];
         }
     // work items: (octet of hidden channels, pixel) for the hidden half [hd % 8 == 0], then (channel quad, pixel) for the input half [cd % 4 == 0]
     const long hw = (long)h * w, n_h = (long)(hd >> 3) * hw, n_i = (long)(cd >> 2) * hw;
@@ -846,9 +846,13 @@ __global__ __launch_bounds__(TPB) void split_tanh_relu_stages_sr_kernel(SplitSta
         const int y = (int)(p / w), x = (int)(p - (long)y * w);
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            v[e] = tanhf(ctx[(long)(8 * o + e) * hw + p]);
-            hidden[(long)(8 * o + e) * hw + p] = v[e];
+        for (int e = 0; e < 8; ++e) v[e] = tanhf(ctx[(long)(8 * o + e) * hw + p]);
+        if (q4) {                                  // [hd/4][h][w][4]: the octet is two 16-byte pieces (EFFI_EPI_Q4)
+            *reinterpret_cast<float4*>(hidden + ((long)(2 * o) * hw + p) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(hidden + ((long)(2 * o + 1) * hw + p) * 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hidden[(long)(8 * o + e) * hw + p] = v[e];
         }
         effi_sr_store8(hsr, hp, wp, 8 * o, y, x, v);
     } else if (i < n_h + n_i) {
@@ -901,7 +905,7 @@ extern "C" int effi_sr_from_planar_f32(const float* in, int channels, int h, int
 
 extern "C" int effi_split_tanh_relu_stages_sr_f32(const float* const* ctx, const int* hd, const int* cd, const int* h, const int* w,
                                                   float* const* hidden, void* const* hidden_sr, const int* hp, const int* wp,
-                                                  float* const* inp, int n_stages, effi_stream_t stream) {
+                                                  float* const* inp, const int* hidden_q4, int n_stages, effi_stream_t stream) {
     if (!ctx || !hd || !cd || !h || !w || !hidden || !hidden_sr || !hp || !wp || !inp || n_stages < 1 || n_stages > 4) return EFFI_ERR_BADARG;
     SplitStagesSr a;
     int blocks = 0;
@@ -912,6 +916,8 @@ extern "C" int effi_split_tanh_relu_stages_sr_f32(const float* const* ctx, const
         if (hp[j] < h[j] + 2 || wp[j] < w[j] + 2 || (reinterpret_cast<uintptr_t>(hidden_sr[j]) & 15)) return EFFI_ERR_BADARG;
         a.ctx[k] = ctx[j]; a.hidden[k] = hidden[j]; a.inp[k] = inp[j]; a.hidden_sr[k] = reinterpret_cast<unsigned short*>(hidden_sr[j]);
         a.hd[k] = hd[j]; a.cd[k] = cd[j]; a.h[k] = h[j]; a.w[k] = w[j]; a.hp[k] = hp[j]; a.wp[k] = wp[j];
+        a.q4[k] = hidden_q4 ? hidden_q4[j] : 0;
+        if (a.q4[k] && (reinterpret_cast<uintptr_t>(hidden[j]) & 15)) return EFFI_ERR_BADARG;
         a.first[k] = blocks;
         if (k < n_stages) blocks += effi_cdiv((long)h[j] * w[j] * ((hd[j] >> 3) + (cd[j] >> 2)), TPB);
     }

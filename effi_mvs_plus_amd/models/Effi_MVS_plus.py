@@ -358,16 +358,22 @@ class Effi_MVS_plus(nn.Module):
                   and all(hd in (16, 32, 48) for hd in self.hdim_stage[:self.num_stage])
                   and all(ctx[k].shape[-1] % 4 == 0 for k in keys))
 
+        # fp32 copy of each hidden state in the Q4 layout ([hd/4][h][w][4]: one 16-byte access per lane in the GRU epilogues) where
+        # the stage's block takes the split-resident path and nothing else reads that copy
+        state_q4 = [False] * self.num_stage
+
         def all_states():
-            nonlocal sr_maps
+            nonlocal sr_maps, state_q4
             cs = [ctx[k].contiguous() for k in keys]
             if use_sr:
                 nm = BasicUpdateBlock.N_SR_MAPS
                 sr_maps = [ops.sr_alloc(nm, self.hdim_stage[s], cs[s].shape[1], cs[s].shape[2], cs[s].device, clear=False)
                            for s in range(self.num_stage)]
                 ops.sr_clear_border(sr_maps)
+                state_q4 = [self.update_block[s].state_q4_ok(not want_intermediates) and ops.uses_sr(cs[s].shape[1] * cs[s].shape[2])
+                            for s in range(self.num_stage)]
                 return dict(enumerate(ops.split_tanh_relu_stages_sr(cs, self.hdim_stage[:self.num_stage], self.cdim_stage[:self.num_stage],
-                                                                    [m[-1] for m in sr_maps])))
+                                                                    [m[-1] for m in sr_maps], q4=state_q4)))
             if self.num_stage <= 4:
                 return dict(enumerate(ops.split_tanh_relu_stages(cs, self.hdim_stage[:self.num_stage], self.cdim_stage[:self.num_stage])))
             return {s: ops.split_tanh_relu(cs[s], self.hdim_stage[s], self.cdim_stage[s]) for s in range(self.num_stage)}
@@ -461,7 +467,7 @@ class Effi_MVS_plus(nn.Module):
             _, masks, invs, depths = self.update_block[s].run_fused(hidden, lookup, inv_cur, inp, self.seq_len[s],
                                                                      disp_range, fuse_upsample=not want_intermediates,
                                                                      sr_maps=None if sr_maps is None else sr_maps[s],
-                                                                     net_sr_ready=sr_maps is not None, net_owned=True)
+                                                                     net_sr_ready=sr_maps is not None, net_owned=True, net_q4=state_q4[s])
             preds.extend(d[0] for d in depths)
             if isinstance(masks[-1], tuple):      # mask head + upsampling ran as one kernel
                 up_depth, inv_next = masks[-1]

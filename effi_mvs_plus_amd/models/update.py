@@ -268,18 +268,26 @@ class BasicUpdateBlock(nn.Module):
     # and writes its result the same way; bitwise the results of ``run_fused``'s fp32-map chain --------------------------------
     N_SR_MAPS = 5          # A: cor1 -> x, B: dfm1 -> r*h, C: cor2, D: dfm2, H: hidden state
 
-    def sr_fusable(self, net, lookup):
-        hd = net.shape[0]
+    def _sr_structure_ok(self, hd):
         e = self.encoder
         cmix, cd = e.convd.out_channels, e.convc.in_channels - e.convd.out_channels
         c1m = self.mask[0].out_channels
-        return (ops.uses_sr(net.shape[-1] * net.shape[-2]) and hd in (16, 32, 48) and net.shape[-1] % 4 == 0 and getattr(lookup, "encoder_inputs_sr", None) is not None
-                and e.convd1.in_channels == 1 and cmix <= 48 and 0 <= cd <= 16 and e.convc.out_channels == hd
+        return (hd in (16, 32, 48) and e.convd1.in_channels == 1 and cmix <= 48 and 0 <= cd <= 16 and e.convc.out_channels == hd
                 and self.depth_head.conv1.out_channels == hd and self.depth_head.conv1.in_channels == hd
                 and self.depth_head.conv2.out_channels == 1 and (not self.UpMask or (c1m in (32, 64, 96) and self.mask[2].out_channels == 36)))
 
+    def sr_fusable(self, net, lookup):
+        return (ops.uses_sr(net.shape[-1] * net.shape[-2]) and net.shape[-1] % 4 == 0 and getattr(lookup, "encoder_inputs_sr", None) is not None
+                and self._sr_structure_ok(net.shape[0]))
+
+    def state_q4_ok(self, fuse_upsample):
+        """The fp32 copy of the hidden state (and z) may live in the Q4 layout [hd/4][h][w][4] (ops.EPI_Q4) when nothing outside the
+        two GRU epilogues reads it: the mask head must be the fused one (it reads the SR state), the one-launch ConvGRU off."""
+        return (bool(ops.option("state_q4")) and fuse_upsample and self.UpMask and not ops.option("gru_fused")
+                and self._sr_structure_ok(self.depth_head.conv1.in_channels))
+
     def run_fused_sr(self, net, lookup, inv_depth, context, seq_len, disp_range, fuse_upsample=False, maps=None, net_sr_ready=False,
-                     net_owned=False):
+                     net_owned=False, net_q4=False):
         """``run_fused`` with the iteration's maps split-resident.  ``maps``: the N_SR_MAPS SRMaps [A, B, C, D, H] of this block
         (borders already zero; allocated here otherwise); ``net_sr_ready``: H already holds ``net`` (written by
         ``ops.split_tanh_relu_stages_sr``), otherwise it is converted here; ``net_owned``: ``net`` is a temporary of the caller
@@ -294,6 +302,9 @@ class BasicUpdateBlock(nn.Module):
         if maps is None:
             maps = ops.sr_alloc(self.N_SR_MAPS, hd, h, w, dev)
         A, B, Cm, Dm, Hm = maps
+        if net_q4 and not (net_sr_ready and net_owned and self.state_q4_ok(fuse_upsample)):
+            raise ValueError("run_fused_sr: a Q4 state needs net_sr_ready, net_owned and the fused mask head")
+        q4 = net_q4                              # the returned ``net`` is then Q4 too (the cascade does not read it)
         if not net_sr_ready:
             ops.sr_from_planar(net, out=Hm)
         gru_fused = hd <= 16 * ops.option("gru_fused")          # option gru_fused: 0 off, 1 = hd 16, 2 = hd 16 and 32
@@ -336,12 +347,12 @@ class BasicUpdateBlock(nn.Module):
                 net, _ = ops.gru_zr_q_fused_sr(Hm, A, net, wzr.wx, bzr, wq.wx, bq, h_next, H_next)
                 Hm = H_next
             else:
-                z, _ = ops.conv2d_k3_sr([Hm, A], wzr.wx, bzr, 2 * hd, epilogue=ops.EPI_GRU_ZR, aux0=net, out0=z_buf, out_sr=B)   # r*h -> B
+                z, _ = ops.conv2d_k3_sr([Hm, A], wzr.wx, bzr, 2 * hd, epilogue=ops.EPI_GRU_ZR, aux0=net, out0=z_buf, out_sr=B, q4=q4)   # r*h -> B
                 # the new state overwrites H in place (no launch reads H between the z / r convolution and here), and so does its fp32
                 # copy once it lives in a buffer of ours
                 if h_own is None:
                     h_own = torch.empty(hd, h, w, device=dev, dtype=torch.float32)
-                net, _ = ops.conv2d_k3_sr([B, A], wq.wx, bq, hd, epilogue=ops.EPI_GRU_Q, aux0=net, aux1=z, out0=h_own, out_sr=Hm)
+                net, _ = ops.conv2d_k3_sr([B, A], wq.wx, bq, hd, epilogue=ops.EPI_GRU_Q, aux0=net, aux1=z, out0=h_own, out_sr=Hm, q4=q4)
             want_mask = self.UpMask and i == seq_len - 1
             fused_up = want_mask and fuse_upsample
             if want_mask and not fused_up:
@@ -364,13 +375,15 @@ class BasicUpdateBlock(nn.Module):
 
     # -- fused path: the cost lookup is our GetCost and scale_inv_depth is the global-range rescale ------
     def run_fused(self, net, lookup, inv_depth, context, seq_len, disp_range, fuse_upsample=False, sr_maps=None, net_sr_ready=False,
-                  net_owned=False):
+                  net_owned=False, net_q4=False):
         """Unbatched tensors; ``lookup(inv_depth, out)`` fills the [2*nq,h,w] cost for a normalised
         inverse-depth map.  Returns (net, mask_list, inv_list, depth_list).  ``fuse_upsample``: the last iteration's mask
         head and the convex upsampling it feeds run as one kernel; mask_list[-1] is then the pair (upsampled depth,
         depth_to_inv of it) instead of the mask."""
         if self.sr_fusable(net, lookup):
-            return self.run_fused_sr(net, lookup, inv_depth, context, seq_len, disp_range, fuse_upsample, sr_maps, net_sr_ready, net_owned)
+            return self.run_fused_sr(net, lookup, inv_depth, context, seq_len, disp_range, fuse_upsample, sr_maps, net_sr_ready, net_owned, net_q4)
+        if net_q4:
+            raise ValueError("run_fused: a Q4 state was passed but the block does not take the split-resident path")
         hd = net.shape[0]
         h, w = net.shape[-2:]
         dev = net.device

@@ -97,7 +97,7 @@ def _x3(name):
 # A/B switches.  Python-level ones (which fused form a module launches) live in ``_PY_OPTS``; kernel-level ones (tile rules, kernel
 # forms) in the library's own table (include/effi_mvs_hip.h: effi_set_option).  Both are initialised ONCE from the environment
 # (EFFI_<NAME>) and changed afterwards through ``set_option`` -- nothing on a per-call path reads the environment.
-_PY_OPTION_DEFAULTS = {"c1k7_mfma": 1, "k5s2_split": 1, "roll": 1, "conv3d_unaligned_split": 1, "conv3d_s2_split": 1, "fpn_conv0_fused": 1,
+_PY_OPTION_DEFAULTS = {"state_q4": 1, "c1k7_mfma": 1, "k5s2_split": 1, "roll": 1, "conv3d_unaligned_split": 1, "conv3d_s2_split": 1, "fpn_conv0_fused": 1,
                        "fpn_split_head": 1, "csp_pair": 1, "head_taps": 1, "enc_tail": 0, "enc_gen": 1, "reduce_chunk": 2048, "gru_fused": 0}
 _PY_OPTS = {k: int(os.environ.get("EFFI_" + k.upper(), v)) for k, v in _PY_OPTION_DEFAULTS.items()}
 LIB_OPTIONS = ("warp_lds_kb", "dyn_form", "dyn_setup_exact", "dyn_xchg", "pixnet_mfma", "force_mr", "mr4_min", "mr4_nt2_max", "mr2_min",
@@ -1247,8 +1247,9 @@ def sr_from_planar(x, out=None):
     return out
 
 
-def split_tanh_relu_stages_sr(ctxs, hds, cds, hidden_srs):
-    """``split_tanh_relu_stages`` that also writes each hidden state into the given SRMap -> [(hidden, inp), ...] (fp32)."""
+def split_tanh_relu_stages_sr(ctxs, hds, cds, hidden_srs, q4=None):
+    """``split_tanh_relu_stages`` that also writes each hidden state into the given SRMap -> [(hidden, inp), ...] (fp32).
+    ``q4``: per stage, write the fp32 hidden state in the Q4 layout (same shape [hd,h,w] tensor, values ordered [hd/4][h][w][4])."""
     outs = []
     for c_, hd, cd, m in zip(ctxs, hds, cds, hidden_srs):
         _t(c_, "context"), _sr(m, "hidden SR map")
@@ -1262,7 +1263,8 @@ def split_tanh_relu_stages_sr(ctxs, hds, cds, hidden_srs):
     check(_lib.lib().effi_split_tanh_relu_stages_sr_f32(
         _ptr_array(ctxs), _int_array(list(hds)), _int_array(list(cds)), _int_array([c_.shape[1] for c_ in ctxs]),
         _int_array([c_.shape[2] for c_ in ctxs]), _ptr_array([o[0] for o in outs]), _ptr_array([m.t for m in hidden_srs]),
-        _int_array([m.hp for m in hidden_srs]), _int_array([m.wp for m in hidden_srs]), _ptr_array([o[1] for o in outs]), len(ctxs),
+        _int_array([m.hp for m in hidden_srs]), _int_array([m.wp for m in hidden_srs]), _ptr_array([o[1] for o in outs]),
+        _int_array([int(bool(v)) for v in (q4 if q4 is not None else [0] * len(ctxs))]), len(ctxs),
         _stream()), "effi_split_tanh_relu_stages_sr_f32")
     return outs
 
@@ -1325,9 +1327,26 @@ def _sr_srcs(srcs):
     return g
 
 
-def conv2d_k3_sr(srcs, wpack, bias, cout, epilogue=EPI_PLAIN, act=ACT_NONE, aux0=None, aux1=None, out0=None, out_sr=None):
+EPI_Q4 = 0x100          # include/effi_mvs_hip.h: EFFI_EPI_Q4
+
+
+def q4_from_planar(x):
+    """fp32 [C,h,w] -> the same values as [C/4,h,w,4] (the "Q4" layout of EFFI_EPI_Q4; tests and callers that hold planar state)."""
+    C_, h, w = x.shape
+    return x.view(C_ // 4, 4, h, w).permute(0, 2, 3, 1).contiguous()
+
+
+def q4_to_planar(x, channels):
+    """inverse of ``q4_from_planar``: a [C/4,h,w,4] block (any view of C*h*w floats) -> planar [C,h,w]."""
+    h, w = x.shape[-3:-1] if x.dim() == 4 else (None, None)
+    q = x.reshape(channels // 4, -1, 4) if h is None else x
+    return q.permute(0, 3, 1, 2).reshape(channels, *q.shape[1:3]).contiguous()
+
+
+def conv2d_k3_sr(srcs, wpack, bias, cout, epilogue=EPI_PLAIN, act=ACT_NONE, aux0=None, aux1=None, out0=None, out_sr=None, q4=False):
     """``conv2d_k3_bf16x3`` on SR maps.  PLAIN: -> out_sr (and out0 fp32 if given); GRU_ZR: -> (z fp32, r*h SR), aux0 = h fp32;
-    GRU_Q: -> (h' fp32, h' SR), aux0 = h, aux1 = z."""
+    GRU_Q: -> (h' fp32, h' SR), aux0 = h, aux1 = z.  ``q4`` (GRU epilogues): aux0 / aux1 / out0 hold their values as
+    [C/4,h,w,4] instead of planar [C,h,w] (same number of floats; EFFI_EPI_Q4: one 16-byte access per lane and map)."""
     g = _sr_srcs(srcs)
     h, w = g.h, g.w
     dev = g.t.device
@@ -1345,7 +1364,8 @@ def conv2d_k3_sr(srcs, wpack, bias, cout, epilogue=EPI_PLAIN, act=ACT_NONE, aux0
     cin = sum(m.channels for m in srcs)
     work = lambda: {"flops": 2.0 * h * w * cin * cout * 9, "bytes": 4.0 * h * w * (cin + cout)}
     check(_call(f"conv2d_k3x3_nt{(cout + 15) // 16}_epi{epilogue}", work, _x3("effi_conv2d_k3_bf16x3_sr"), _ptr_array([m.t for m in srcs]),
-                _int_array([m.channels for m in srcs]), len(srcs), _p(wpack), _p(bias), cout, h, w, g.hp, g.wp, epilogue, act,
+                _int_array([m.channels for m in srcs]), len(srcs), _p(wpack), _p(bias), cout, h, w, g.hp, g.wp,
+                epilogue | (EPI_Q4 if (q4 and epilogue in (EPI_GRU_ZR, EPI_GRU_Q)) else 0), act,
                 _p(aux0), _p(aux1), _p(out0), _p(out_sr.t), _stream()), "effi_conv2d_k3_bf16x3_sr")
     return (out0, out_sr) if out0 is not None else out_sr
 

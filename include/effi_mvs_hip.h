@@ -42,6 +42,10 @@ typedef void* effi_stream_t;
 #define EFFI_EPI_PLAIN   0   /* out0 = act(conv + bias) */
 #define EFFI_EPI_GRU_ZR  1   /* channels [0,hd): out0 = sigmoid(.) (= z);  [hd,2hd): out1 = sigmoid(.) * aux0 (= r*h) */
 #define EFFI_EPI_GRU_Q   2   /* q = tanh(.);  out0 = (1 - aux1) * aux0 + aux1 * q   (aux0 = h, aux1 = z) */
+#define EFFI_EPI_Q4      0x100 /* flag, split-resident GRU epilogues only (effi_conv2d_k3_bf16x3_sr: EFFI_EPI_GRU_ZR | EFFI_EPI_Q4,
+                               * EFFI_EPI_GRU_Q | EFFI_EPI_Q4): the fp32 maps of the call (aux0 = h, aux1 = z, out0) are laid out
+                               * [channels/4][h][w][4] ("Q4") instead of planar [channels][h][w] -- a lane's 4 channels of a pixel are
+                               * ONE 16-byte access instead of four 4-byte ones a plane apart.  Same values. */
 #define EFFI_EPI_HEAD    3   /* 1 channel: out0 = aux0 + tanh(.) (inverse depth);  out1 = 1/clamp(lo+(hi-lo)*out0, 1e-4) */
 #define EFFI_EPI_NHWC    5   /* out0 = act(conv + bias) written channel-last [h][w][cout] (what the warp kernels read) */
 #define EFFI_EPI_ADD_SHUF2 9        /* out0 = conv + bias + pixel_shuffle(aux0): aux0 planar [4*cout][h/2][w/2], channel
@@ -680,10 +684,11 @@ int effi_sr_clear_border(void* const* maps, const int* planes, const int* h, con
 /* fp32 planar [channels][h][w] (channels % 8 == 0) -> SR map (interior only) */
 int effi_sr_from_planar_f32(const float* in, int channels, int h, int w, void* sr, int hp, int wp, effi_stream_t stream);
 /* effi_split_tanh_relu_stages_f32 (models/Effi_MVS_plus.py:442-452) that ALSO writes each hidden state as an SR map (hd % 8 == 0,
- * cd % 4 == 0): what the first ConvGRU convolution of a stage reads. */
+ * cd % 4 == 0): what the first ConvGRU convolution of a stage reads.  hidden_q4[k] != 0 (hidden_q4 == NULL: all 0): the fp32
+ * hidden state of stage k is written in the Q4 layout of EFFI_EPI_Q4. */
 int effi_split_tanh_relu_stages_sr_f32(const float* const* ctx, const int* hd, const int* cd, const int* h, const int* w,
                                        float* const* hidden, void* const* hidden_sr, const int* hp, const int* wp, float* const* inp,
-                                       int n_stages, effi_stream_t stream);
+                                       const int* hidden_q4, int n_stages, effi_stream_t stream);
 /* effi_encoder_inputs_bf16x3_f32 (models/update.py:86,90) writing both maps split-resident (sr_c1 = relu(convc1(cost)),
  * sr_d1 = relu(convd1(inv_depth)); [cout/8][2][hp][wp][8]). */
 int effi_encoder_inputs_bf16x3_sr(const float* inv_depth, const float* disp_range, int n_range, const float* interval,
@@ -704,7 +709,7 @@ int effi_encoder_pair_gen_bf16x3_sr(const float* inv_depth, const float* disp_ra
 /* effi_conv2d_k3_bf16x3_f32 on SR maps (models/update.py:36-38,43-48,75,77): srcs = SR maps of src_channels[i] channels each
  * (multiples of 16), cout % 16 == 0.  EFFI_EPI_PLAIN: out_sr = act(conv) (out0, if given, the same values as fp32 [cout][h][w]);
  * EFFI_EPI_GRU_ZR: out0 = z (fp32 [cout/2][h][w]), out_sr = r * h, aux0 = h (fp32); EFFI_EPI_GRU_Q: out0 AND out_sr =
- * (1 - z) h + z tanh(conv), aux0 = h, aux1 = z (fp32). */
+ * (1 - z) h + z tanh(conv), aux0 = h, aux1 = z (fp32).  With EFFI_EPI_Q4 or-ed into a GRU epilogue the fp32 maps are Q4 (see the flag). */
 int effi_conv2d_k3_bf16x3_sr(const void* const* srcs, const int* src_channels, int n_src, const void* wpack_bf16, const float* bias,
                              int cout, int h, int w, int hp, int wp, int epilogue, int act, const float* aux0, const float* aux1,
                              float* out0, void* out_sr, effi_stream_t stream);

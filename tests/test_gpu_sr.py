@@ -326,3 +326,40 @@ def test_sr_entries_reject_bad_geometry(split_precision):
         ops.conv2d_k3_sr([bad], wgt, torch.zeros(16, device=DEV), 16, out_sr=bad)
     with pytest.raises(ValueError):
         ops.conv2d_k3_sr([ops.SRMap(m.t[:1], 8, 20, 28)], wgt, torch.zeros(16, device=DEV), 16, out_sr=m)   # 8 channels: not a whole chunk
+
+
+
+@pytest.mark.parametrize("hd,h,w", [(16, 40, 72), (32, 24, 36), (48, 20, 28), (16, 70, 528)])
+def test_q4_state_layout_is_bitwise_the_planar_one(hd, h, w):
+    """EFFI_EPI_Q4: the GRU epilogues with the fp32 state h, the gate z and the new state laid out [hd/4][h][w][4] (one 16-byte
+    access per lane and map) against the planar maps -- same values bit for bit, both in the fp32 and the split-resident outputs;
+    and split_tanh_relu_stages_sr writing the initial state in that layout (models/update.py:40-49, models/Effi_MVS_plus.py:442-452)."""
+    from effi_mvs_plus_amd import ops, packing
+    before = ops.get_precision()
+    ops.set_precision("split")
+    g = torch.Generator().manual_seed(hd + h)
+    rnd = lambda *sh: torch.randn(*sh, generator=g).to(DEV)
+    hcur, x, rh, z = rnd(hd, h, w), rnd(hd, h, w), rnd(hd, h, w), torch.rand(hd, h, w, generator=g).to(DEV)
+    H, X, RH = (ops.sr_alloc(1, hd, h, w, DEV)[0] for _ in range(3))
+    for m, t_ in ((H, hcur), (X, x), (RH, rh)):
+        ops.sr_from_planar(t_, out=m)
+    wzr_x, bzr = packing.pack_conv2d_bf16x3(rnd(2 * hd, 2 * hd, 3, 3) * 0.05, rnd(2 * hd) * 0.1)
+    wq_x, bq = packing.pack_conv2d_bf16x3(rnd(hd, 2 * hd, 3, 3) * 0.05, rnd(hd) * 0.1)
+    # z | r
+    z_p, rh_p = ops.conv2d_k3_sr([H, X], wzr_x, bzr, 2 * hd, epilogue=ops.EPI_GRU_ZR, aux0=hcur)
+    z_q, rh_q = ops.conv2d_k3_sr([H, X], wzr_x, bzr, 2 * hd, epilogue=ops.EPI_GRU_ZR, aux0=ops.q4_from_planar(hcur).view(hd, h, w), q4=True)
+    assert torch.equal(ops.q4_to_planar(z_q.view(hd // 4, h, w, 4), hd), z_p) and torch.equal(rh_q.t, rh_p.t)
+    # q + update
+    h_p, H_p = ops.conv2d_k3_sr([RH, X], wq_x, bq, hd, epilogue=ops.EPI_GRU_Q, aux0=hcur, aux1=z)
+    h_q, H_q = ops.conv2d_k3_sr([RH, X], wq_x, bq, hd, epilogue=ops.EPI_GRU_Q, aux0=ops.q4_from_planar(hcur).view(hd, h, w),
+                                aux1=ops.q4_from_planar(z).view(hd, h, w), q4=True)
+    assert torch.equal(ops.q4_to_planar(h_q.view(hd // 4, h, w, 4), hd), h_p) and torch.equal(H_q.t, H_p.t)
+    assert torch.isfinite(h_p).all() and float(h_p.abs().max()) > 0.1
+    # initial state
+    cd = 4
+    ctx = rnd(hd + cd, h, w)
+    m1, m2 = ops.sr_alloc(1, hd, h, w, DEV)[0], ops.sr_alloc(1, hd, h, w, DEV)[0]
+    (hid_p, inp_p), = ops.split_tanh_relu_stages_sr([ctx], [hd], [cd], [m1])
+    (hid_q, inp_q), = ops.split_tanh_relu_stages_sr([ctx], [hd], [cd], [m2], q4=[True])
+    assert torch.equal(ops.q4_to_planar(hid_q.view(hd // 4, h, w, 4), hd), hid_p) and torch.equal(inp_q, inp_p) and torch.equal(m1.t, m2.t)
+    ops.set_precision(before)
