@@ -12,7 +12,12 @@
 
 namespace {
 
-constexpr int TX = 32, TY = 8;
+#ifndef EFFI_C3_TX
+#define EFFI_C3_TX 32          // tile of the vector-ALU kernels (A/B builds: -DEFFI_C3_TX=64 -DEFFI_C3_TY=4)
+#define EFFI_C3_TY 8
+#endif
+constexpr int TX = EFFI_C3_TX, TY = EFFI_C3_TY;
+static_assert(TX * TY == 256, "one thread per tile pixel");
 
 struct SrcSet {                    // channel concatenation of up to EFFI_MAX_SRC planar tensors
     const float* p[EFFI_MAX_SRC];
