@@ -560,13 +560,24 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
         // weight fragments of (s + 1, n) right after the multiplies of (s, n) (into the registers those just freed); LDS returns in
         // order, so each request sits BEHIND what the next multiplies need.  sched_barrier pins the order (the scheduler otherwise
         // sinks every read back to its first use).  Same MFMAs on the same accumulators in the same order: bitwise the plain loop.
-        constexpr bool PIPE = SR && EFFI_PIPE_FRAGS;
-        bf16x8 ahb[PIPE ? 2 : 1][MR], alb[PIPE ? 2 : 1][MR], bhb[NT], blb[NT];
-        auto load_a = [&](int s_, int buf) {
+        // EFFI_PIPE_FRAGS = 2: only the FRONT half of a wave's pixel fragments gets the second register set; the back half is requested
+        // at the start of its own step, behind the front half's multiplies (16 instead of 32 extra registers at MR = 4: the z | r kernel
+        // stays at three waves per SIMD).
+        constexpr int PIPE = SR ? EFFI_PIPE_FRAGS : 0;
+        constexpr int MF = (PIPE == 2) ? (MR + 1) / 2 : MR, MB = MR - MF;          // double-buffered / single-buffered fragments
+        bf16x8 ahf[PIPE ? 2 : 1][MF], alf[PIPE ? 2 : 1][MF], ahk[MB > 0 ? MB : 1], alk[MB > 0 ? MB : 1], bhb[NT], blb[NT];
+        auto load_front = [&](int s_, int buf) {
 #pragma unroll
-            for (int m = 0; m < MR; ++m) {
-                ahb[buf][m] = *reinterpret_cast<const bf16x8*>(&lds_ah[koff[s_] + m * (MROW + MCOL)]);
-                if (!kHiOnly) alb[buf][m] = *reinterpret_cast<const bf16x8*>(&lds_al_rd[koff[s_] + m * (MROW + MCOL)]);
+            for (int m = 0; m < MF; ++m) {
+                ahf[buf][m] = *reinterpret_cast<const bf16x8*>(&lds_ah[koff[s_] + m * (MROW + MCOL)]);
+                if (!kHiOnly) alf[buf][m] = *reinterpret_cast<const bf16x8*>(&lds_al_rd[koff[s_] + m * (MROW + MCOL)]);
+            }
+        };
+        auto load_back = [&](int s_) {
+#pragma unroll
+            for (int m = MF; m < MR; ++m) {
+                ahk[m - MF] = *reinterpret_cast<const bf16x8*>(&lds_ah[koff[s_] + m * (MROW + MCOL)]);
+                if (!kHiOnly) alk[m - MF] = *reinterpret_cast<const bf16x8*>(&lds_al_rd[koff[s_] + m * (MROW + MCOL)]);
             }
         };
         auto load_b = [&](int s_, int n) {
@@ -578,31 +589,34 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
         if (PIPE && NKS_RUN > 0) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) load_b(0, n);
-            load_a(0, 0);
+            load_front(0, 0);
         }
 #pragma unroll
         for (int s_ = 0; s_ < NKS_RUN; ++s_) {
             const int cur = PIPE ? (s_ & 1) : 0;
             if (PIPE) {
-                if (s_ + 1 < NKS) load_a(s_ + 1, cur ^ 1);
+                load_back(s_);
+                if (s_ + 1 < NKS) load_front(s_ + 1, cur ^ 1);
                 __builtin_amdgcn_sched_barrier(0);
             } else {
-                load_a(s_, 0);
+                load_front(s_, 0);
             }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 if (!PIPE) load_b(s_, n);
 #pragma unroll
                 for (int m = 0; m < MR; ++m) {
+                    const bf16x8 ah_m = (m < MF) ? ahf[cur][m < MF ? m : 0] : ahk[m >= MF ? m - MF : 0];
+                    const bf16x8 al_m = (m < MF) ? alf[cur][m < MF ? m : 0] : alk[m >= MF ? m - MF : 0];
                     if (EFFI_ABL & 4) {                  // keep the fragment reads alive, issue no MFMA
-                        asm volatile("" ::"v"(bhb[n]), "v"(blb[n]), "v"(ahb[cur][m]), "v"(alb[cur][m]));
+                        asm volatile("" ::"v"(bhb[n]), "v"(blb[n]), "v"(ah_m), "v"(al_m));
                         continue;
                     }
                     // weights x pixels: D[cout][pixel] (transposed fragment, see conv_epilogue_store_t)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhb[n], ahb[cur][m], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhb[n], ah_m, acc[m][n], 0, 0, 0);
                     if (!kHiOnly) {
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blb[n], ahb[cur][m], acc[m][n], 0, 0, 0);
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhb[n], alb[cur][m], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blb[n], ah_m, acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhb[n], al_m, acc[m][n], 0, 0, 0);
                     }
                 }
                 if (PIPE) {
