@@ -30,6 +30,7 @@ enum EffiOption {
     EFFI_OPT_DECONV_MR,          // transposed 3-D convolution: rows per wave
     EFFI_OPT_SR_WAVES,           // split-resident 3x3 convolutions: 8 = 512-thread workgroups where the rule picks 1 or 2 rows per wave
     EFFI_OPT_ENC_GEN_MR3,        // generated-input pair kernel: 0 = 4 rows per wave where the rule says so (default: 3)
+    EFFI_OPT_C3_LEAN,            // 3-D end layers (1 -> 8, 8 -> 1 channels): 0 = the general vector-ALU bodies instead of the dedicated kernels
     EFFI_OPT_COUNT
 };
 constexpr long EFFI_OPT_UNSET = -0x7fffffffL;
@@ -300,6 +301,29 @@ __device__ __forceinline__ void effi_sr_store4(unsigned short* __restrict__ base
 #endif
     const long u = ((long)((co0 >> 3) * 2 + part) * hp + (y + 1)) * wp + (x + 1);     // 16-byte unit
     *reinterpret_cast<effi_u32x4_t*>(base + u * 8) = oct;
+}
+
+// The same store with the 16-byte unit index computed by the caller (u = ((co0 >> 3) * 2 + part) * hp * wp + (y + 1) * wp + x + 1 with
+// part = (co0 >> 2) & 1): the batched epilogue of conv2d_x3.hpp derives the units of a lane's N-tiles from one base by adding a constant.
+__device__ __forceinline__ void effi_sr_store4_at(unsigned short* __restrict__ base, unsigned u, int part, const effi_f32x4_t v) {
+    typedef unsigned effi_u32x2_t __attribute__((ext_vector_type(2)));
+    typedef unsigned effi_u32x4_t __attribute__((ext_vector_type(4)));
+    const effi_bf16x4_t h4 = __builtin_convertvector(v, effi_bf16x4_t);
+    const effi_u32x2_t hu = __builtin_bit_cast(effi_u32x2_t, h4);
+#ifndef EFFI_BF16_ONLY
+    const effi_bf16x4_t l4 = __builtin_convertvector(v - __builtin_convertvector(h4, effi_f32x4_t), effi_bf16x4_t);
+    const effi_u32x2_t lu = __builtin_bit_cast(effi_u32x2_t, l4);
+#else
+    const effi_u32x2_t lu = hu;
+#endif
+    const auto s0 = __builtin_amdgcn_permlane16_swap(hu[0], lu[0], false, false);
+    const auto s1 = __builtin_amdgcn_permlane16_swap(hu[1], lu[1], false, false);
+    const effi_u32x4_t oct = {s0[0], s1[0], s0[1], s1[1]};
+#ifdef EFFI_BF16_ONLY
+    if (part) return;
+#endif
+    (void)part;
+    *reinterpret_cast<effi_u32x4_t*>(base + (size_t)u * 8) = oct;
 }
 
 // 8 consecutive channels (one octet, co0 % 8 == 0) of pixel (y, x): one 16-byte store per part

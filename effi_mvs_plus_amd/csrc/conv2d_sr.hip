@@ -28,6 +28,7 @@ int fill_sr(Conv2dArgs& a, const void* const* srcs, const int* src_channels, int
         if (i < n_src && (reinterpret_cast<uintptr_t>(srcs[i]) & 15)) return EFFI_ERR_BADARG;
         a.cin += a.ch[i];
     }
+    if ((long)cout * hp * wp >= (1L << 31)) return EFFI_ERR_UNSUPPORTED;     // the batched epilogue's 32-bit unit / Q4 offsets
     a.kgroups = (a.cin + 3) / 4;
     a.zeros = nullptr;                       // not read: padding is the maps' zero border
     a.wpack = reinterpret_cast<const float*>(wpack_bf16);

@@ -28,6 +28,22 @@
 #define EFFI_PIPE_FRAGS 0
 #endif
 
+#ifndef EFFI_EPI_BATCH
+// 1: the split-resident tile's plain / GRU epilogues issue their loads together (see "batched epilogue" in the tile function);
+// 0: the per-fragment epilogue.
+#define EFFI_EPI_BATCH 1
+#endif
+#ifndef EFFI_EPI_EARLY_MAX
+// the batched epilogue's state quads are requested AHEAD of the K loop when they take at most this many registers per lane
+// (held across the loop), else right behind it
+#define EFFI_EPI_EARLY_MAX 16
+#endif
+#ifndef EFFI_B_EARLY
+// 1: the next chunk's weight fragments are requested before the K loop of the current one (held in registers across it) instead of
+// between the two barriers that separate the chunks.
+#define EFFI_B_EARLY 0
+#endif
+
 namespace {
 
 #ifdef EFFI_BF16_ONLY
@@ -508,13 +524,17 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
     // A: split + transpose out of the prefetch registers.  B (pre-split by the host, L2-resident, identical for every
     // workgroup) is copied global -> LDS (all its loads are issued before the first use; the LDS image is padded to whole
     // 256-thread passes so the copy needs no predicate).
-    auto stash = [&](int ch) {
-        f32x4 tb[NB4];
+    f32x4 tb[NB4];
+    auto fetch_b = [&](int ch) {
 #pragma unroll
         for (int j = 0; j < NB4; ++j) {
             const int u = min(tid + j * NTHR, NBF - 1);
             tb[j] = *reinterpret_cast<const f32x4*>(wbf + ((long)ch * NBF + u) * 8);
         }
+    };
+    constexpr bool kBEarly = SR && !GEN && EFFI_B_EARLY;
+    auto stash = [&](int ch) {
+        if (!kBEarly || ch == 0) fetch_b(ch);
         if constexpr (GEN) {
             generate(ch);
         } else if constexpr (SR) {
@@ -548,11 +568,55 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
+    // BATCHED EPILOGUE (split-resident plain / GRU forms).  Written per fragment (conv_epilogue_store_t) the epilogue is a chain of
+    // dependent memory round trips -- per (m, n) fragment: the bias quad, wait, the state quad(s), wait, store -- under divergent
+    // bounds tests the compiler cannot move loads across: 8 serialised round trips per wave for the stage-3 z | r kernel, 10-24 us of
+    // the 30-44 us such a launch takes (ablation, profiles/r04_e_ablate_sr.txt: "no epilogue").  Here every load of the epilogue is
+    // issued at once from clamped addresses (out-of-map lanes read pixel 0), the bias quads before the first chunk, the state quads
+    // (Q4 layout: one 16-byte load per fragment and map) ahead of the K loop when few (EFFI_EPI_EARLY_MAX), else right behind it; the unit /
+    // offset of every store derives from ONE base per sub-tile.  Same operations on the same values: bitwise the per-fragment form.
+    constexpr bool kBatchT = SR && EFFI_EPI_BATCH != 0 && !(EFFI_ABL & 24) &&
+                             (EPI == EFFI_EPI_PLAIN || EPI == EFFI_EPI_GRU_ZR || EPI == EFFI_EPI_GRU_Q);
+    constexpr int NZ = (EPI == EFFI_EPI_GRU_ZR) ? NT / 2 : 0;                                    // a.hd = 8 NT (host): tiles [0, NZ) are z
+    constexpr int NH = !kBatchT ? 0 : (EPI == EFFI_EPI_GRU_ZR ? NT - NZ : (EPI == EFFI_EPI_GRU_Q ? NT : 0));
+    constexpr int NZQ = (kBatchT && EPI == EFFI_EPI_GRU_Q) ? NT : 0;
+    constexpr bool kStateEarly = MR * (NH + NZQ) * 4 <= EFFI_EPI_EARLY_MAX;
+    const bool ebatch = kBatchT && (EPI == EFFI_EPI_PLAIN || a.aux_q4);
+    f32x4 eb[kBatchT ? NT : 1], eh[MR][NH > 0 ? NH : 1], ez[MR][NZQ > 0 ? NZQ : 1];
+    unsigned eqb[MR];                                 // Q4 float offset of (channel group lk, the sub-tile's pixel), clamped
+    bool einside[MR];
+    auto epi_issue_bias = [&]() {
+        if (!ebatch) return;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) eb[n] = *reinterpret_cast<const f32x4*>(a.bias + n * 16 + 4 * lk);
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const int x = x0 + li + (WIDE ? 16 * m : 0), y = y0 + (WIDE ? wv : wv * MR + m);
+            einside[m] = (y < h) & (x < w);
+            eqb[m] = ((unsigned)lk * (unsigned)hw + (einside[m] ? (unsigned)(y * w + x) : 0u)) * 4u;
+        }
+    };
+    auto epi_issue_state = [&]() {
+        if (!ebatch) return;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+#pragma unroll
+            for (int j = 0; j < NH; ++j) eh[m][j] = *reinterpret_cast<const f32x4*>(a.aux0 + (size_t)(eqb[m] + (unsigned)j * 16u * (unsigned)hw));
+#pragma unroll
+            for (int j = 0; j < NZQ; ++j) ez[m][j] = *reinterpret_cast<const f32x4*>(a.aux1 + (size_t)(eqb[m] + (unsigned)j * 16u * (unsigned)hw));
+        }
+    };
+
     prefetch(0);
+    epi_issue_bias();
+    if (kStateEarly) epi_issue_state();
     stash(0);
     __syncthreads();
     for (int ch = 0; ch < nchunks; ++ch) {
-        if (ch + 1 < nchunks) prefetch(ch + 1);
+        if (ch + 1 < nchunks) {
+            prefetch(ch + 1);
+            if (kBEarly) fetch_b(ch + 1);
+        }
         // SOFTWARE-PIPELINED FRAGMENT READS (PIPE).  As the compiler schedules the plain loop, every K-step opens with its 2 MR + 2 NT
         // ds_read_b128 and waits for them in front of its first MFMA; an ablation (tools/ablate_sr.sh, profiles/r04_e_ablate_sr.txt)
         // put 18 us of the stage-3 z | r kernel's 44 on these exposed reads and only 9 on the MFMAs -- the phases add up instead of
@@ -811,6 +875,56 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
                         for (int r = 0; r < 4; ++r)
                             if (co + r < a.n_range) a.out0[(long)(co + r) * hw + pixm[m]] = vo[r];
                     }
+                }
+            }
+        }
+        return;
+    }
+    if constexpr (kBatchT) if (ebatch) {
+        if (!kStateEarly) epi_issue_state();
+        const unsigned plane = (unsigned)a.sr_hp * (unsigned)a.sr_wp;            // 16-byte units per (octet, part) plane
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            if (!einside[m]) continue;
+            const int x = x0 + li + (WIDE ? 16 * m : 0), y = y0 + (WIDE ? wv : wv * MR + m);
+            // channels 16 n + 4 lk ..: octet 2 n + (lk >> 1), part lk & 1 -> plane 4 n + lk
+            const unsigned ub = (unsigned)lk * plane + (unsigned)(y + 1) * (unsigned)a.sr_wp + (unsigned)(x + 1);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[m][n][r] + eb[n][r];
+                if constexpr (EPI == EFFI_EPI_PLAIN) {
+                    if (a.act == EFFI_ACT_RELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.0f);
+                    } else if (a.act != EFFI_ACT_NONE) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], a.act);
+                    }
+                    effi_sr_store4_at(a.out_sr, ub + (unsigned)(4 * n) * plane, lk & 1, v);
+                    if (a.out0) {
+                        float* dst = a.out0 + (long)(n * 16 + 4 * lk) * a.ostride + (long)y * w + x;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dst[(long)r * a.ostride] = v[r];
+                    }
+                } else if constexpr (EPI == EFFI_EPI_GRU_ZR) {
+                    f32x4 g;
+                    if (n < NZ) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) g[r] = effi_sigmoid_split(v[r]) * 1.0f;
+                        *reinterpret_cast<f32x4*>(a.out0 + (size_t)(eqb[m] + (unsigned)n * 16u * (unsigned)hw)) = g;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) g[r] = effi_sigmoid_split(v[r]) * eh[m][n >= NZ ? n - NZ : 0][r];
+                        effi_sr_store4_at(a.out_sr, ub + (unsigned)(4 * (n - NZ)) * plane, lk & 1, g);
+                    }
+                } else {
+                    f32x4 g;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) g[r] = (1.0f - ez[m][n][r]) * eh[m][n][r] + ez[m][n][r] * effi_tanh_split(v[r]);
+                    *reinterpret_cast<f32x4*>(a.out0 + (size_t)(eqb[m] + (unsigned)n * 16u * (unsigned)hw)) = g;
+                    effi_sr_store4_at(a.out_sr, ub + (unsigned)(4 * n) * plane, lk & 1, g);
                 }
             }
         }

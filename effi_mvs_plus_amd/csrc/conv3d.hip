@@ -207,6 +207,139 @@ __global__ __launch_bounds__(256) void conv3d_k3_pair_kernel(Conv3dCall a, Conv3
 }
 
 // ------------------------------------------------------------------------------------------------
+// cin = 1 -> cout = 8, stride (1, SXY, SXY): the first layer of the regulariser (models/module.py:439) and the two entry layers of
+// every cross-scale block (conv0 with SXY = 2, conv_cost with SXY = 1; models/module.py:505-506).
+// The general body above spends its time around the arithmetic when there is ONE input channel: it fetches and stores its 4-channel
+// chunk regardless (3 of 4 loads / LDS writes wasted), every load sits behind its own bounds branch, and the 216 weights of the channel
+// do not fit the scalar registers -- the compiler spills them through v_writelane / v_readlane (490 v_readlane for 432 packed FMAs in
+// the ISA of round 4).  Here: one plane slot per 256-thread pass (every thread always stores: no branch), all loads of the tile
+// issued together from clamped offsets, the weights (27 x 8) + bias read from LDS as broadcast 16-byte quads, ZPT = 4 or 8 output
+// planes per thread.  Same FMA order per output as the general body (ky, kx, kd): bitwise the same result.
+// blockIdx.y picks the call (two independent convolutions of one shape in a launch, as conv3d_k3_pair_kernel).
+// ------------------------------------------------------------------------------------------------
+struct C1Call {
+    const float* in;
+    const float* wgt;       // [27][8]
+    const float* bias;      // [8] or nullptr
+    float* out;
+};
+template <int SXY, int ZPT>
+__global__ __launch_bounds__(256) void conv3d_c1to8_kernel(C1Call ca, C1Call cb, int D, int h, int w, int ho, int wo, int relu) {
+    constexpr int IZ = ZPT + 2, IY = (TY - 1) * SXY + 3, IX = (TX - 1) * SXY + 3;
+    constexpr int PSZ = IY * IX, NPL = (PSZ + 255) / 256, PSZP = NPL * 256;          // plane slot padded to whole passes
+    __shared__ float tile[IZ * PSZP];
+    __shared__ __attribute__((aligned(16))) float wl[27 * 8 + 8];
+    const bool second = blockIdx.y != 0;
+    const float* __restrict__ in = second ? cb.in : ca.in;
+    const float* __restrict__ wgt = second ? cb.wgt : ca.wgt;
+    const float* __restrict__ bias = second ? cb.bias : ca.bias;
+    float* __restrict__ out = second ? cb.out : ca.out;
+
+    const int tid = threadIdx.x;
+    const int tiles_x = (wo + TX - 1) / TX, tiles_xy = tiles_x * ((ho + TY - 1) / TY);
+    int lid = effi_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_xy = lid % tiles_xy, zg = lid / tiles_xy;
+    const int by = tile_xy / tiles_x, bx = tile_xy - by * tiles_x;
+    const int tx = tid % TX, ty = tid / TX;
+    const int ox = bx * TX + tx, oy = by * TY + ty, oz0 = zg * ZPT;
+    const int iz0 = oz0 - 1, iy0 = by * TY * SXY - 1, ix0 = bx * TX * SXY - 1;
+
+    if (tid < 27 * 8) wl[tid] = wgt[tid];
+    if (tid < 8) wl[27 * 8 + tid] = bias ? bias[tid] : 0.0f;
+
+    int poff[NPL];                            // offset of this thread's fill elements inside a z-slice, -1 = padding
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int e = tid + k * 256;
+        const int ly = e / IX, lx = e - ly * IX;
+        const int gy = iy0 + ly, gx = ix0 + lx;
+        poff[k] = ((e < PSZ) & (gy >= 0) & (gy < h) & (gx >= 0) & (gx < w)) ? gy * w + gx : -1;
+    }
+    float pf[IZ][NPL];
+#pragma unroll
+    for (int lz = 0; lz < IZ; ++lz) {
+        const int gz = iz0 + lz;
+        const bool zok = (gz >= 0) & (gz < D);
+        const float* __restrict__ zp = in + (zok ? (long)gz * h * w : 0);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const float t = zp[max(poff[k], 0)];
+            pf[lz][k] = (zok & (poff[k] >= 0)) ? t : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int lz = 0; lz < IZ; ++lz)
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) tile[lz * PSZP + tid + k * 256] = pf[lz][k];
+    __syncthreads();
+
+    // channel pairs as 2-vectors: one v_pk_fma_f32 per (plane, pair) with the input value broadcast to both halves
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f2 acc[ZPT][4];
+#pragma unroll
+    for (int z = 0; z < ZPT; ++z)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[z][c] = f2{0.0f, 0.0f};
+    const float* tc = tile + (ty * SXY) * IX + tx * SXY;
+    // a REAL loop over the nine (ky, kx) columns of taps: fully unrolled, the compiler fetches all 54 weight quads up front (404 registers)
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {
+        const int ky = t / 3, kx = t - 3 * ky;
+        float col[IZ];
+#pragma unroll
+        for (int z = 0; z < IZ; ++z) col[z] = tc[z * PSZP + ky * IX + kx];
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+            const f4 w0 = *reinterpret_cast<const f4*>(&wl[(kd * 9 + t) * 8]);
+            const f4 w1 = *reinterpret_cast<const f4*>(&wl[(kd * 9 + t) * 8 + 4]);
+            const f2 wk[4] = {f2{w0[0], w0[1]}, f2{w0[2], w0[3]}, f2{w1[0], w1[1]}, f2{w1[2], w1[3]}};
+#pragma unroll
+            for (int z = 0; z < ZPT; ++z) {
+                const f2 cv = {col[z + kd], col[z + kd]};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[z][c] = __builtin_elementwise_fma(cv, wk[c], acc[z][c]);
+            }
+        }
+    }
+
+    if (ox >= wo || oy >= ho) return;
+    const long out_plane = (long)D * ho * wo;
+    float bv[8];
+#pragma unroll
+    for (int co = 0; co < 8; ++co) bv[co] = wl[27 * 8 + co];
+#pragma unroll
+    for (int z = 0; z < ZPT; ++z) {
+        const int oz = oz0 + z;
+        if (oz >= D) break;
+        const long o = ((long)oz * ho + oy) * wo + ox;
+#pragma unroll
+        for (int co = 0; co < 8; ++co) {
+            float v = acc[z][co >> 1][co & 1] + bv[co];
+            if (relu) v = fmaxf(v, 0.0f);
+            out[(long)co * out_plane + o] = v;
+        }
+    }
+}
+
+// launch rule of the cin = 1 kernel: 8 planes per thread when the grid still covers the chip twice
+int launch_c1to8(const C1Call& a, const C1Call* b, int D, int h, int w, int sxy, int relu, hipStream_t st) {
+    const int ho = (h - 1) / sxy + 1, wo = (w - 1) / sxy + 1;
+    const long tiles = (long)effi_cdiv(wo, TX) * effi_cdiv(ho, TY), ncall = b ? 2 : 1;
+    const bool z8 = tiles * effi_cdiv(D, 8) * ncall >= 512;
+    const dim3 grid((unsigned)(tiles * effi_cdiv(D, z8 ? 8 : 4)), (unsigned)ncall);
+    const C1Call& bb = b ? *b : a;
+    if (sxy == 1) {
+        if (z8) hipLaunchKernelGGL((conv3d_c1to8_kernel<1, 8>), grid, dim3(256), 0, st, a, bb, D, h, w, ho, wo, relu);
+        else hipLaunchKernelGGL((conv3d_c1to8_kernel<1, 4>), grid, dim3(256), 0, st, a, bb, D, h, w, ho, wo, relu);
+    } else {
+        if (z8) hipLaunchKernelGGL((conv3d_c1to8_kernel<2, 8>), grid, dim3(256), 0, st, a, bb, D, h, w, ho, wo, relu);
+        else hipLaunchKernelGGL((conv3d_c1to8_kernel<2, 4>), grid, dim3(256), 0, st, a, bb, D, h, w, ho, wo, relu);
+    }
+    return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------
 // transposed convolution, stride (SZ, 2, 2), padding 1, output_padding (SZ-1, 1, 1).
 // One thread per INPUT position: it produces the 2x2 (x SZ) output block that position owns, so every
 // lane does identical work (no parity divergence) and each of the 27 taps is used exactly once.
@@ -432,6 +565,10 @@ extern "C" int effi_conv3d_k3_f32(const float* const* srcs, const int* src_chann
         cin += s.ch[i];
     }
     hipStream_t st = effi_s(stream);
+    if (cin == 1 && cout == 8 && sz == 1 && (sxy == 1 || sxy == 2) && !skip && effi_option(EFFI_OPT_C3_LEAN) != 0) {
+        const C1Call c{srcs[0], weight, bias, out};
+        return launch_c1to8(c, nullptr, D, h, w, sxy, relu, st);
+    }
     const bool c8 = (cout % 8 == 0);
     if (!c8 && cout != 1) return EFFI_ERR_UNSUPPORTED;
     if (sz == 1 && sxy == 1)
@@ -491,6 +628,10 @@ extern "C" int effi_conv3d_k3_pair_f32(const float* in_a, const float* weight_a,
     a.wgt = weight_a; a.bias = bias_a; a.skip = nullptr; a.out = out_a;
     b.wgt = weight_b; b.bias = bias_b; b.skip = nullptr; b.out = out_b;
     hipStream_t st = effi_s(stream);
+    if (cin == 1 && effi_option(EFFI_OPT_C3_LEAN) != 0) {
+        const C1Call ca{in_a, weight_a, bias_a, out_a}, cb{in_b, weight_b, bias_b, out_b};
+        return launch_c1to8(ca, &cb, D, h, w, sxy, relu, st);
+    }
     const int ho = (h - 1) / sxy + 1, wo = (w - 1) / sxy + 1;
     const bool big = 2L * effi_cdiv(wo, TX) * effi_cdiv(ho, TY) * effi_cdiv(D, 4) >= 384;     // as launch_conv, for both grids
     if (sxy == 1) return big ? launch_conv_pair<1, 4>(a, b, cin, D, h, w, relu, st) : launch_conv_pair<1, 1>(a, b, cin, D, h, w, relu, st);

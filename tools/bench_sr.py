@@ -99,6 +99,16 @@ def main():
         rows.append(("convq + update",
                      timed(lambda i: ops.conv2d_k3_bf16x3([rh[k_(i)], x[k_(i)]], wq.wx, bq, hd, epilogue=ops.EPI_GRU_Q, aux0=hcur[k_(i)], aux1=z[k_(i)], out0=outs[k_(i)][0])),
                      timed(lambda i: ops.conv2d_k3_sr([sets[k_(i)][4], sets[k_(i)][3]], wq.wx, bq, hd, epilogue=ops.EPI_GRU_Q, aux0=hcur[k_(i)], aux1=z[k_(i)], out0=outs[k_(i)][0], out_sr=sets[k_(i)][5]))))
+        # the shipped form: fp32 state / gate in the Q4 layout (first column: planar fp32 aux maps, second: Q4)
+        hq = [ops.q4_from_planar(t_) for t_ in hcur]
+        zq = [ops.q4_from_planar(t_) for t_ in z]
+        oq = [torch.empty_like(t_) for t_ in hq]
+        rows.append(("convz|convr  (SR: planar aux / Q4)",
+                     timed(lambda i: ops.conv2d_k3_sr([sets[k_(i)][2], sets[k_(i)][3]], wzr.wx, bzr, 2 * hd, epilogue=ops.EPI_GRU_ZR, aux0=hcur[k_(i)], out0=outs[k_(i)][0], out_sr=sets[k_(i)][4])),
+                     timed(lambda i: ops.conv2d_k3_sr([sets[k_(i)][2], sets[k_(i)][3]], wzr.wx, bzr, 2 * hd, epilogue=ops.EPI_GRU_ZR, aux0=hq[k_(i)], out0=oq[k_(i)], out_sr=sets[k_(i)][4], q4=True))))
+        rows.append(("convq + update (SR: planar aux / Q4)",
+                     timed(lambda i: ops.conv2d_k3_sr([sets[k_(i)][4], sets[k_(i)][3]], wq.wx, bq, hd, epilogue=ops.EPI_GRU_Q, aux0=hcur[k_(i)], aux1=z[k_(i)], out0=outs[k_(i)][0], out_sr=sets[k_(i)][5])),
+                     timed(lambda i: ops.conv2d_k3_sr([sets[k_(i)][4], sets[k_(i)][3]], wq.wx, bq, hd, epilogue=ops.EPI_GRU_Q, aux0=hq[k_(i)], aux1=zq[k_(i)], out0=oq[k_(i)], out_sr=sets[k_(i)][5], q4=True))))
         rows.append(("head conv1 + taps",
                      timed(lambda i: ops.conv2d_k3_k1_x3([hcur[k_(i)]], wh1.wx, bh1, hd, None, wh2, bh2, 9, relu=False, relu1=True, out=part[:9])),
                      timed(lambda i: ops.conv2d_k3_k1_sr([sets[k_(i)][2]], wh1.wx, bh1, hd, None, wh2, bh2, 9, relu=False, relu1=True, out=part[:9]))))
@@ -109,7 +119,7 @@ def main():
         for name, a, b in rows:
             if args.rows and args.rows not in name:
                 continue
-            print(f"  {name:24s} {a:8.1f} {b:8.1f}   {b / a:5.2f}x")
+            print(f"  {name:38s} {a:8.1f} {b:8.1f}   {b / a:5.2f}x")
 
 
 if __name__ == "__main__":
