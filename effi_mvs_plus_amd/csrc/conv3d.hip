@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void conv3d_c1to8_kernel(C1Call ca, C1Call cb,
         const float* __restrict__ zp = in + (zok ? (long)gz * h * w : 0);
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
-            const float t = zp[max(poff[k], 0)];
+            const float t = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(zp) + (unsigned)max(poff[k], 0) * 4u);
             pf[lz][k] = (zok & (poff[k] >= 0)) ? t : 0.0f;
         }
     }
@@ -336,6 +336,193 @@ int launch_c1to8(const C1Call& a, const C1Call* b, int D, int h, int w, int sxy,
         if (z8) hipLaunchKernelGGL((conv3d_c1to8_kernel<2, 8>), grid, dim3(256), 0, st, a, bb, D, h, w, ho, wo, relu);
         else hipLaunchKernelGGL((conv3d_c1to8_kernel<2, 4>), grid, dim3(256), 0, st, a, bb, D, h, w, ho, wo, relu);
     }
+    return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cin = 8 -> cout = 1: the regulariser's last layer (stride 1, models/module.py:451 `prob`) and the transposed conv2 of every
+// cross-scale block (stride (1,2,2), models/module.py:508).  Same recipe as conv3d_c1to8_kernel: the tile of a 4-channel chunk is
+// fetched with all its loads in flight at once (clamped offsets, every thread stores, plane slots padded to whole half-passes), the
+// 8 x 27 weights sit in LDS and are read as broadcast quads inside a REAL loop over the chunk's channels (so that at most one
+// channel's weights are live), FMA order per output as in the general bodies (channel, then the bodies' tap order): bitwise equal.
+// ------------------------------------------------------------------------------------------------
+struct C8Call {
+    const float* in;        // [8][D][h][w]
+    const float* wgt;       // [8][27]
+    const float* bias;      // [1] or nullptr
+    float* out;
+};
+// DECONV = false: out[z][y][x] = sum_c sum_taps in[c][z+kd-1][y+ky-1][x+kx-1] w[c][kd][ky][kx]          (ZPT = 4 planes per thread)
+// DECONV = true : transposed, stride (1,2,2), output_padding (0,1,1): a thread owns input (y, x) and the 2 x 2 outputs it maps to
+template <bool DECONV, int ZPT>
+__global__ __launch_bounds__(256) void conv3d_c8to1_kernel(C8Call ca, C8Call cb, int D, int h, int w, int relu) {
+#ifndef EFFI_C8_CC
+#define EFFI_C8_CC 2
+#endif
+    constexpr int IZ = ZPT + 2, CC = (ZPT == 8) ? 1 : EFFI_C8_CC;           // channels per chunk (in flight as registers during the multiplies)
+    constexpr int IY = DECONV ? TY + 1 : TY + 2, IX = DECONV ? TX + 1 : TX + 2;
+    constexpr int PSZ = IY * IX, PSZP = (PSZ + 127) & ~127, NPL = (PSZP + 255) / 256, LASTN = PSZP - 256 * (NPL - 1);
+    __shared__ float tile[CC * IZ * PSZP];
+    __shared__ __attribute__((aligned(16))) float wl[8 * 28 + 4];          // 27 weights per channel at stride 28, then the bias
+    const bool second = blockIdx.y != 0;
+    const float* __restrict__ in = second ? cb.in : ca.in;
+    const float* __restrict__ wgt = second ? cb.wgt : ca.wgt;
+    const float* __restrict__ bias = second ? cb.bias : ca.bias;
+    float* __restrict__ out = second ? cb.out : ca.out;
+
+    const int tid = threadIdx.x;
+    const int tiles_x = (w + TX - 1) / TX, tiles_xy = tiles_x * ((h + TY - 1) / TY);
+    int lid = effi_xcd_remap(blockIdx.x, gridDim.x);
+    const int tile_xy = lid % tiles_xy, zg = lid / tiles_xy;
+    const int by = tile_xy / tiles_x, bx = tile_xy - by * tiles_x;
+    const int tx = tid % TX, ty = tid / TX;
+    const int ix = bx * TX + tx, iy = by * TY + ty, z0 = zg * ZPT;
+    const int iz0 = z0 - 1, iy0 = DECONV ? by * TY : by * TY - 1, ix0 = DECONV ? bx * TX : bx * TX - 1;
+    const long in_plane = (long)D * h * w;
+
+    if (tid < 8 * 27) wl[(tid / 27) * 28 + tid % 27] = wgt[tid];
+    if (tid == 0) wl[8 * 28] = bias ? bias[0] : 0.0f;
+
+    int poff[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int e = tid + k * 256;
+        const int ly = e / IX, lx = e - ly * IX;
+        const int gy = iy0 + ly, gx = ix0 + lx;
+        poff[k] = ((e < PSZ) & (gy >= 0) & (gy < h) & (gx >= 0) & (gx < w)) ? gy * w + gx : -1;
+    }
+    const bool last_pass = tid < LASTN;                                  // wave-uniform (LASTN is a multiple of 128)
+
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr int NACC = DECONV ? ZPT * 4 : ZPT;
+    float acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+
+    // the chunk's raw loads (converted to zero padding when stored): the second chunk is in flight while the first is multiplied
+    float pf[CC][IZ][NPL];
+    // address = the tensor's base (scalar) + a 32-bit byte offset: (channel, plane) part scalar, in-plane part per thread -- one
+    // add per load, no 64-bit address pairs held across the multiply phase (the host checks 8 D h w < 2^29)
+    unsigned pb[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) pb[k] = (unsigned)max(poff[k], 0) * 4u;
+    const unsigned plane_b = (unsigned)(h * w) * 4u, chan_b = (unsigned)in_plane * 4u;
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int c = 0; c < CC; ++c) {
+#pragma unroll
+            for (int lz = 0; lz < IZ; ++lz) {
+                const int gz = min(max(iz0 + lz, 0), D - 1);                 // planes outside the volume: any valid plane (zeroed when stored)
+                const unsigned so = (unsigned)(c0 + c) * chan_b + (unsigned)gz * plane_b;
+#pragma unroll
+                for (int k = 0; k < NPL; ++k)
+                    pf[c][lz][k] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(in) + (so + pb[k]));
+            }
+        }
+    };
+    fetch(0);
+#pragma unroll 1
+    for (int c0 = 0; c0 < 8; c0 += CC) {
+        if (c0) __syncthreads();                                         // the previous chunk's reads are done
+#pragma unroll
+        for (int c = 0; c < CC; ++c)
+#pragma unroll
+            for (int lz = 0; lz < IZ; ++lz) {
+                const int gz = iz0 + lz;
+                const bool zok = (gz >= 0) & (gz < D);
+#pragma unroll
+                for (int k = 0; k < NPL; ++k)
+                    if (k + 1 < NPL || last_pass) tile[(c * IZ + lz) * PSZP + tid + k * 256] = (zok & (poff[k] >= 0)) ? pf[c][lz][k] : 0.0f;
+            }
+        __syncthreads();
+        if (c0 + CC < 8) fetch(c0 + CC);
+#pragma unroll 1
+        for (int c = 0; c < CC; ++c) {
+            float wk[28];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                const f4 t = *reinterpret_cast<const f4*>(&wl[(c0 + c) * 28 + 4 * q]);
+                wk[4 * q] = t[0]; wk[4 * q + 1] = t[1]; wk[4 * q + 2] = t[2]; wk[4 * q + 3] = t[3];
+            }
+            const float* tc = tile + c * IZ * PSZP + ty * IX + tx;
+            if constexpr (!DECONV) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        float col[IZ];
+#pragma unroll
+                        for (int z = 0; z < IZ; ++z) col[z] = tc[z * PSZP + ky * IX + kx];
+#pragma unroll
+                        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                            for (int z = 0; z < ZPT; ++z) acc[z] = fmaf(col[z + kd], wk[kd * 9 + ky * 3 + kx], acc[z]);
+                    }
+            } else {
+#pragma unroll
+                for (int lz = 0; lz < IZ; ++lz)
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int dx = 0; dx < 2; ++dx) {
+                            const float v = tc[lz * PSZP + dy * IX + dx];
+#pragma unroll
+                            for (int ay = 0; ay < 2; ++ay) {
+                                const int ky = (dy == 0) ? (ay == 0 ? 1 : 2) : (ay == 1 ? 0 : -1);
+                                if (ky < 0) continue;
+#pragma unroll
+                                for (int ax = 0; ax < 2; ++ax) {
+                                    const int kx = (dx == 0) ? (ax == 0 ? 1 : 2) : (ax == 1 ? 0 : -1);
+                                    if (kx < 0) continue;
+#pragma unroll
+                                    for (int az = 0; az < ZPT; ++az) {
+                                        const int kd = az + 2 - lz;          // lz = az + 2 - kd
+                                        if (kd < 0 || kd > 2) continue;
+                                        acc[(az * 2 + ay) * 2 + ax] = fmaf(v, wk[kd * 9 + ky * 3 + kx], acc[(az * 2 + ay) * 2 + ax]);
+                                    }
+                                }
+                            }
+                        }
+            }
+        }
+    }
+
+    if (ix >= w || iy >= h) return;
+    const float b = wl[8 * 28];
+    if constexpr (!DECONV) {
+#pragma unroll
+        for (int z = 0; z < ZPT; ++z) {
+            const int oz = z0 + z;
+            if (oz >= D) break;
+            float v = acc[z] + b;
+            if (relu) v = fmaxf(v, 0.0f);
+            out[((long)oz * h + iy) * w + ix] = v;
+        }
+    } else {
+        const int ho = 2 * h, wo = 2 * w;
+#pragma unroll
+        for (int az = 0; az < ZPT; ++az) {
+            const int oz = z0 + az;
+            if (oz >= D) break;
+#pragma unroll
+            for (int ay = 0; ay < 2; ++ay) {
+                float v0 = acc[(az * 2 + ay) * 2] + b, v1 = acc[(az * 2 + ay) * 2 + 1] + b;
+                if (relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
+                *reinterpret_cast<float2*>(out + ((long)oz * ho + 2 * iy + ay) * wo + 2 * ix) = make_float2(v0, v1);
+            }
+        }
+    }
+}
+
+template <bool DECONV>
+int launch_c8to1(const C8Call& a, const C8Call* b, int D, int h, int w, int relu, hipStream_t st) {
+    if (8L * D * h * w >= (1L << 29)) return EFFI_ERR_UNSUPPORTED;              // 32-bit byte offsets inside the input tensor
+    const long tiles = (long)effi_cdiv(w, TX) * effi_cdiv(h, TY), ncall = b ? 2 : 1;
+    const long z8_env = effi_option(EFFI_OPT_C3_LEAN);                           // 4 / 8: force the planes per thread (A/B)
+    const bool z8 = z8_env == 8 || (z8_env != 4 && tiles * effi_cdiv(D, 8) * ncall >= 512);
+    const dim3 grid((unsigned)(tiles * effi_cdiv(D, z8 ? 8 : 4)), (unsigned)ncall);
+    if (z8) hipLaunchKernelGGL((conv3d_c8to1_kernel<DECONV, 8>), grid, dim3(256), 0, st, a, b ? *b : a, D, h, w, relu);
+    else hipLaunchKernelGGL((conv3d_c8to1_kernel<DECONV, 4>), grid, dim3(256), 0, st, a, b ? *b : a, D, h, w, relu);
     return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
 }
 
@@ -569,6 +756,10 @@ extern "C" int effi_conv3d_k3_f32(const float* const* srcs, const int* src_chann
         const C1Call c{srcs[0], weight, bias, out};
         return launch_c1to8(c, nullptr, D, h, w, sxy, relu, st);
     }
+    if (cin == 8 && n_src == 1 && cout == 1 && sz == 1 && sxy == 1 && !skip && effi_option(EFFI_OPT_C3_LEAN) != 0) {
+        const C8Call c{srcs[0], weight, bias, out};
+        return launch_c8to1<false>(c, nullptr, D, h, w, relu, st);
+    }
     const bool c8 = (cout % 8 == 0);
     if (!c8 && cout != 1) return EFFI_ERR_UNSUPPORTED;
     if (sz == 1 && sxy == 1)
@@ -593,6 +784,9 @@ extern "C" int effi_deconv3d_k3_f32(const float* in, int cin, const float* weigh
         else   // low-resolution level: split the output channels finer so the grid covers the chip
             hipLaunchKernelGGL((deconv3d_k3_kernel<4, 2>), dim3(tiles * D * (cout / 4)), dim3(256), 0, st, in, cin, weight, bias,
                                cout, D, h, w, relu, skip, out);
+    } else if (sz == 1 && cout == 1 && cin == 8 && !skip && effi_option(EFFI_OPT_C3_LEAN) != 0) {
+        const C8Call c{in, weight, bias, out};
+        return launch_c8to1<true>(c, nullptr, D, h, w, relu, st);
     } else if (sz == 1 && cout == 1) {
         hipLaunchKernelGGL((deconv3d_k3_kernel<1, 1>), dim3(tiles * effi_cdiv(D, 4)), dim3(256), 0, st, in, cin, weight,
                            bias, cout, D, h, w, relu, skip, out);
@@ -643,6 +837,10 @@ extern "C" int effi_deconv3d_k3_pair_f32(const float* in_a, const float* weight_
                                          int cout, int D, int h, int w, int sz, int relu, effi_stream_t stream) {
     if (!in_a || !weight_a || !out_a || !in_b || !weight_b || !out_b || cin < 1 || D < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
     if (sz != 1 || cout != 1) return EFFI_ERR_UNSUPPORTED;
+    if (cin == 8 && effi_option(EFFI_OPT_C3_LEAN) != 0) {
+        const C8Call ca{in_a, weight_a, bias_a, out_a}, cb{in_b, weight_b, bias_b, out_b};
+        return launch_c8to1<true>(ca, &cb, D, h, w, relu, effi_s(stream));
+    }
     const Deconv3dCall a{in_a, weight_a, bias_a, nullptr, out_a}, b{in_b, weight_b, bias_b, nullptr, out_b};
     const dim3 grid(effi_cdiv(w, TX) * effi_cdiv(h, TY) * effi_cdiv(D, 4), 2);
     hipLaunchKernelGGL((deconv3d_k3_pair_kernel<1, 1>), grid, dim3(256), 0, effi_s(stream), a, b, cin, cout, D, h, w, relu);
