@@ -54,6 +54,7 @@ SIGNATURES = {
     "effi_vol_lookup1d_pair_f32": [_vp, _vp, _l, _l, _i, _vp, _l, _l, _l, _i, _vp, _vp, _l, _i, _i, _vp, _vp, _vp],
     "effi_conv3d_k3_pair_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "effi_conv3d_k3s1_roll_bf16x3_pair_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "effi_csp_gen_roll_bf16x3_pair_f32": [_vp, _i, _i, _i] + [_vp] * 16 + [_vp],
     "effi_deconv3d_k3_pair_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "effi_homo_warp_bwd_f32": [_vp, _vp, _l, _l, _i, _i, _i, _i, _vp, _vp, _vp],
     "effi_warpcorr_views_bwd_f32": [_vp, _vp, _i, _vp, _vp, _l, _l, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
@@ -118,7 +119,7 @@ SIGNATURES = {
 # plain-bf16-operand variants (hi*hi only) of the split-precision convolution entries: same signatures, suffix _bf16
 BF16X3_ENTRIES = ("effi_conv2d_k3_bf16x3_pair_f32", "effi_conv2d_k3_bf16x3_f32", "effi_conv2d_k3_k1_bf16x3_f32",
                   "effi_conv2d_k3_k1_up2x_bf16x3_f32", "effi_conv3d_k3s1_bf16x3_f32", "effi_conv3d_k3s1_roll_bf16x3_f32",
-                  "effi_conv3d_k3s1_roll_bf16x3_pair_f32", "effi_deconv3d_k3s2_bf16x3_f32", "effi_encoder_tail_bf16x3_f32", "effi_conv2d_k3_twice_bf16x3_f32",
+                  "effi_conv3d_k3s1_roll_bf16x3_pair_f32", "effi_csp_gen_roll_bf16x3_pair_f32", "effi_deconv3d_k3s2_bf16x3_f32", "effi_encoder_tail_bf16x3_f32", "effi_conv2d_k3_twice_bf16x3_f32",
                   "effi_conv2d_k5s2_bf16x3_f32", "effi_conv3d_k3s2_bf16x3_f32",
                   "effi_conv2d_k3_bf16x3_sr", "effi_conv2d_k3_bf16x3_pair_sr", "effi_conv2d_k3_k1_bf16x3_sr", "effi_conv2d_k3_k1_up2x_bf16x3_sr",
                   "effi_encoder_pair_gen_bf16x3_sr", "effi_gru_zr_q_fused_bf16x3_sr")

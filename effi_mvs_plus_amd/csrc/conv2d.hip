@@ -1055,6 +1055,249 @@ __global__ __launch_bounds__(256) void conv3d_roll_rp_bf16x3_pair_kernel(const C
     conv3d_roll_rp_bf16x3_body<NOCT, MR>(c, tiles_x, ntiles, zt);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Cross-scale block (models/module.py:501-516), layers conv0 | conv_cost -> conv1 in ONE kernel: the 16 input channels of conv1 --
+// relu(conv0(x)) (1 -> 8 channels, stride (1,2,2)) and relu(conv_cost(prior)) (1 -> 8) -- are GENERATED plane by plane into the
+// rolling window of the row-pair kernel above instead of being written by two launches (conv3d_c1to8_kernel, conv3d.hip) and read
+// back: per block 2 x 8 channels x D x h x w x 4 B less written and read (stage 3 of cfg3: 120 MB of 180 MB per launch), two
+// launches less, and no global load inside the plane loop (the rolling kernel's plane step was bound by the latency of its fetch).
+//   * a workgroup owns a 16 x 8 tile of coarse pixels (MR = 2) and ALL D planes (D <= 14: the prior tile of every plane sits in LDS,
+//     the fine volume's tile in a ring of four planes fetched one plane step ahead);
+//   * generation: 200 work items = (row, pixel pair, octet) of the 10 x 20 slot region; per item the 27 taps in the order of
+//     conv3d_c1to8_kernel ((ky, kx) outer, kd inner, fmaf), + bias, relu, zero outside the map / the volume (conv1's padding), then
+//     the (hi, lo) split of the staging code above: the slot contents are BITWISE those of the three-launch path, and so is conv1;
+//   * the matrix part (K order, weight fragments in registers, epilogue) is that of conv3d_roll_rp_bf16x3_body<2, 2>.
+// blockIdx.z picks the block (CSP_R[s] / CSP_C[s] share x).
+// ------------------------------------------------------------------------------------------------
+struct CspGenCall {
+    const float* prior;                   // [D][h][w]
+    const float* w0; const float* b0;     // conv0:     [27][8], [8]   (BatchNorm folded)
+    const float* wc; const float* bc;     // conv_cost: [27][8], [8]
+    const float* w1; const float* b1;     // conv1: row-pair operand (packing.pack_conv3d_roll_bf16x3), bias [16]
+    float* out;                           // [8][D][h][w]
+};
+constexpr int kCspMaxD = 14;
+
+__global__ __launch_bounds__(256) void csp_gen_roll_rp_kernel(const float* __restrict__ xf, int H, int W, CspGenCall ca, CspGenCall cb,
+                                                              int D, int h, int w, int tiles_x, int ntiles) {
+    constexpr int MR = 2, NOCT = 2, TR = 4 * MR, AR = TR + 2, AW = 20, XOFF = 1;
+    constexpr int APIX = AR * AW, NIT = 36 * NOCT, NKS = NIT / 4, SLOT = NOCT * APIX * 8, MP = MR / 2;
+    constexpr int FR = 2 * AR + 1, FC = 2 * AW + 1, FPL = FR * FC, NFL = (FPL + 255) / 256;       // fine tile of a plane: 21 x 41
+    constexpr int PR = AR + 2, PC = AW + 2, PPL = PR * PC;                                       // prior tile of a plane: 12 x 22
+    constexpr int NGEN = AR * (AW / 2) * 2;                                                      // generation items
+    static_assert(NGEN <= 256, "one generation item per thread");
+    __shared__ __attribute__((aligned(16))) unsigned short lds_ah[3 * SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned short lds_al[kHiOnly ? 8 : 3 * SLOT];
+    __shared__ float s_fine[4 * FPL];
+    __shared__ float s_prior[(kCspMaxD + 2) * PPL];
+    __shared__ __attribute__((aligned(16))) float s_w[2][27 * 8 + 8];
+
+    const CspGenCall& c = blockIdx.z ? cb : ca;
+    const float* __restrict__ prior = c.prior;
+    float* __restrict__ out = c.out;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const long hw = (long)h * w;
+    const int tile = effi_xcd_remap(blockIdx.x, gridDim.x);
+    if (tile >= ntiles) return;
+    const int ty_ = tile / tiles_x;
+    const int x0 = (tile - ty_ * tiles_x) * 16, y0 = ty_ * TR;
+
+    // ---- once per workgroup: weights of the two generated layers, prior tile of every plane (zero planes in front and behind) ----
+    if (tid < 27 * 8) {
+        s_w[0][tid] = c.w0[tid];
+        s_w[1][tid] = c.wc[tid];
+    }
+    if (tid < 8) {
+        s_w[0][27 * 8 + tid] = c.b0[tid];
+        s_w[1][27 * 8 + tid] = c.bc[tid];
+    }
+    for (int e = tid; e < (D + 2) * PPL; e += 256) {
+        const int pl = e / PPL, r_ = e - pl * PPL;
+        const int py = r_ / PC, px = r_ - py * PC;
+        const int gz = pl - 1, gy = y0 - 2 + py, gx = x0 - 3 + px;
+        const bool ok = (gz >= 0) & (gz < D) & (gy >= 0) & (gy < h) & (gx >= 0) & (gx < w);
+        s_prior[e] = ok ? prior[(long)gz * hw + (long)gy * w + gx] : 0.0f;
+    }
+    // fine tile: element e of a plane -> offset inside the plane (or -1: padding)
+    int foff[NFL];
+#pragma unroll
+    for (int k = 0; k < NFL; ++k) {
+        const int e = tid + k * 256;
+        const int fy = e / FC, fx = e - fy * FC;
+        const int gy = 2 * (y0 - 1) - 1 + fy, gx = 2 * (x0 - 2) - 1 + fx;
+        foff[k] = ((e < FPL) & (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W)) ? gy * W + gx : -1;
+    }
+    const long HW = (long)H * W;
+    float ff[NFL];
+    auto fine_fetch = [&](int p) {                    // plane p of the fine volume -> registers (any valid address when outside)
+        const float* __restrict__ zp = xf + (long)min(max(p, 0), D - 1) * HW;
+#pragma unroll
+        for (int k = 0; k < NFL; ++k) ff[k] = zp[max(foff[k], 0)];
+    };
+    auto fine_stash = [&](int p) {                    // registers -> ring slot p & 3, zero where padding
+        const bool zok = (p >= 0) & (p < D);
+        float* dst = s_fine + (p & 3) * FPL;
+#pragma unroll
+        for (int k = 0; k < NFL; ++k) {
+            const int e = tid + k * 256;
+            if (e < FPL) dst[e] = (zok & (foff[k] >= 0)) ? ff[k] : 0.0f;
+        }
+    };
+
+    // weight fragments of conv1 in registers (see conv3d_roll_rp_bf16x3_body)
+    bf16x8 breg_h[NKS], breg_l[NKS];
+    {
+        const unsigned short* wbf = reinterpret_cast<const unsigned short*>(c.w1);
+#pragma unroll
+        for (int s_ = 0; s_ < NKS; ++s_) {
+            breg_h[s_] = *reinterpret_cast<const bf16x8*>(wbf + ((long)(s_ * 2 + 0) * 64 + lane) * 8);
+            if (!kHiOnly) breg_l[s_] = *reinterpret_cast<const bf16x8*>(wbf + ((long)(s_ * 2 + 1) * 64 + lane) * 8);
+        }
+    }
+    int kconst[NKS];
+#pragma unroll
+    for (int s_ = 0; s_ < NKS; ++s_) {
+        const int item = 4 * s_ + lk;
+        const int oct = item % NOCT, dt = item / NOCT;
+        const int dz = dt / 12, rem = dt - dz * 12;
+        kconst[s_] = ((oct * APIX + (rem / 3) * AW + rem % 3) * 8) * 4 + dz;
+    }
+    const int lane_base = ((wv * MR) * AW + li + XOFF) * 8;
+
+    // generation item of this thread: slot row gr, columns 2 gcp / 2 gcp + 1, octet goct (0: conv0 over the fine ring, 1: conv_cost)
+    const bool gen = tid < NGEN;
+    const int goct = (tid >= NGEN / 2) ? 1 : 0, git = gen ? tid - goct * (NGEN / 2) : 0;
+    const int gr = git / (AW / 2), gcp = git - gr * (AW / 2);
+    const int ggy = y0 - 1 + gr, ggx = x0 - 2 + 2 * gcp;
+    const bool gin0 = gen & (ggy >= 0) & (ggy < h) & (ggx >= 0) & (ggx < w);
+    const bool gin1 = gen & (ggy >= 0) & (ggy < h) & (ggx + 1 >= 0) & (ggx + 1 < w);
+    // element (ky, kx) of pixel 0 sits at base + ky * rstride + kx; pixel 1 is pstride further
+    const int g_rs = goct ? PC : FC, g_ps = goct ? 1 : 2;
+    const int g_base = goct ? gr * PC + 2 * gcp : (2 * gr) * FC + 4 * gcp;
+    const int g_lds = (goct * APIX + gr * AW + 2 * gcp) * 8;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    auto generate = [&](int p) {                      // plane p of the 16 channels -> slot (p + 3) % 3
+        const int slot = (p + 3) % 3;
+        if (!gen) return;
+        unsigned short* dh = lds_ah + slot * SLOT + g_lds;
+        unsigned short* dl = lds_al + (kHiOnly ? 0 : slot * SLOT + g_lds);
+        if (p < 0 || p >= D) {                        // outside the volume: conv1's zero padding
+            const f4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            *reinterpret_cast<f4*>(dh) = z4;
+            *reinterpret_cast<f4*>(dh + 8) = z4;
+            if (!kHiOnly) {
+                *reinterpret_cast<f4*>(dl) = z4;
+                *reinterpret_cast<f4*>(dl + 8) = z4;
+            }
+            return;
+        }
+        // plane p + kd - 1 of the input: fine ring slot (p + kd - 1) & 3, or prior plane index p + kd (index 0 is the zero plane)
+        const float* pl[3];
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) pl[kd] = (goct ? s_prior + (p + kd) * PPL : s_fine + ((p + kd - 1) & 3) * FPL) + g_base;
+        f2 acc[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[j][q] = f2{0.0f, 0.0f};
+        const float* wl = s_w[goct];
+#ifndef CSP_ABL
+#define CSP_ABL 0
+#endif
+#pragma unroll 1
+        for (int t = 0; t < ((CSP_ABL & 1) ? 1 : 9); ++t) {
+            const int ky = t / 3, kx = t - 3 * ky;
+            const int o = ky * g_rs + kx;
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) {
+                const float v0 = pl[kd][o], v1 = pl[kd][o + g_ps];
+                const f4 w0 = *reinterpret_cast<const f4*>(&wl[(kd * 9 + t) * 8]);
+                const f4 w1 = *reinterpret_cast<const f4*>(&wl[(kd * 9 + t) * 8 + 4]);
+                const f2 wk[4] = {f2{w0[0], w0[1]}, f2{w0[2], w0[3]}, f2{w1[0], w1[1]}, f2{w1[2], w1[3]}};
+                const f2 c0 = {v0, v0}, c1 = {v1, v1};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[0][q] = __builtin_elementwise_fma(c0, wk[q], acc[0][q]);
+                    acc[1][q] = __builtin_elementwise_fma(c1, wk[q], acc[1][q]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool in = j ? gin1 : gin0;
+            float v[8];
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+                const float t_ = fmaxf(acc[j][ch >> 1][ch & 1] + wl[27 * 8 + ch], 0.0f);
+                v[ch] = in ? t_ : 0.0f;
+            }
+            effi_bf16x8_t hi, lo;
+            effi_split8(v, hi, lo);
+            *reinterpret_cast<effi_bf16x8_t*>(dh + j * 8) = hi;
+            if (!kHiOnly) *reinterpret_cast<effi_bf16x8_t*>(dl + j * 8) = lo;
+        }
+    };
+
+    // ---- prologue: fine planes -1 .. 2 in the ring, generated planes -1 and 0 in their slots ----
+    fine_fetch(0);
+    fine_stash(-1);                                   // zeros (the values of plane 0 are in flight)
+    fine_stash(0);
+    fine_fetch(1);
+    fine_stash(1);
+    fine_fetch(2);
+    __syncthreads();                                  // weights, prior tile, fine planes -1 .. 1
+    generate(-1);
+    generate(0);
+    fine_stash(2);
+    fine_fetch(3);
+    __syncthreads();
+
+    f32x4 acc[MP];
+    float bias4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias4[r] = c.b1[4 * (lk & 1) + r];
+    for (int z = 0; z < D; ++z) {
+        generate(z + 1);                              // reads fine planes z .. z + 2 / prior planes; writes the slot plane z - 2 used
+        __syncthreads();
+        const int rb0 = ((z + 2) % 3) * SLOT, rb1 = (z % 3) * SLOT, rb2 = ((z + 1) % 3) * SLOT;      // planes z - 1, z, z + 1
+#pragma unroll
+        for (int m = 0; m < MP; ++m) acc[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s_ = 0; s_ < ((CSP_ABL & 2) ? 1 : NKS); ++s_) {
+            const int dz = kconst[s_] & 3;
+            const int off = lane_base + (kconst[s_] >> 2) + (dz == 0 ? rb0 : (dz == 1 ? rb1 : rb2));
+            const bf16x8 bh = breg_h[s_];
+            const bf16x8 bl = kHiOnly ? bh : breg_l[s_];
+#pragma unroll
+            for (int m = 0; m < MP; ++m) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&lds_ah[off + m * 2 * AW * 8]);
+                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, ah, acc[m], 0, 0, 0);
+                if (!kHiOnly) {
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&lds_al[off + m * 2 * AW * 8]);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl, ah, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh, al, acc[m], 0, 0, 0);
+                }
+            }
+        }
+        // lane (li, lk): lk < 2 -> row y, channels 4 lk ..; lk >= 2 -> row y + 1, channels 4 (lk - 2) ..
+        const int x = x0 + li;
+#pragma unroll
+        for (int m = 0; m < MP; ++m) {
+            const int y = y0 + wv * MR + 2 * m + (lk >> 1);
+            if (y >= h || x >= w) continue;
+            if ((CSP_ABL & 4) && acc[m][0] != 1.2345e30f) continue;
+            float* dst = out + (long)(4 * (lk & 1)) * ((long)D * hw) + (long)z * hw + (long)y * w + x;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[(long)r * ((long)D * hw)] = fmaxf(acc[m][r] + bias4[r], 0.0f);
+        }
+        fine_stash(z + 3);                            // ring slot of plane z - 1, last read by generate(z)
+        if (z + 4 < D + 2) fine_fetch(z + 4);
+        __syncthreads();                              // slot reads of plane z - 1 done; fine plane z + 3 visible
+    }
+}
+
 template <int NOCT, int NT, int MR>
 __global__ __launch_bounds__(256) void conv3d_roll_bf16x3_kernel(const Conv2dArgs a, int tiles_x, int ntiles, int zt) {
     conv3d_roll_bf16x3_body<NOCT, NT, MR>(a, tiles_x, ntiles, zt);
@@ -2521,6 +2764,27 @@ extern "C" int EFFI_FN(effi_conv3d_k3s1_roll_bf16x3_pair_f32)(const float* const
     if (cout > 16) return EFFI_ERR_UNSUPPORTED;
     hipStream_t st = effi_s(stream);
     return a.cin == 8 ? launch_roll<1, 1>(a, st, &b) : launch_roll<2, 1>(a, st, &b);
+}
+
+// conv0 | conv_cost -> conv1 of two cross-scale blocks over one fine volume x [D][H][W] (csp_gen_roll_rp_kernel): priors [D][h][w],
+// h = (H - 1) / 2 + 1, w = (W - 1) / 2 + 1, outputs [8][D][h][w].  Bitwise the result of effi_conv3d_k3_pair_f32 (sxy 2 / sxy 1) +
+// effi_conv3d_k3s1_roll_bf16x3_pair_f32 on the same weights.
+extern "C" int EFFI_FN(effi_csp_gen_roll_bf16x3_pair_f32)(const float* x, int D, int H, int W, const float* prior_a, const float* w0_a,
+                                                          const float* b0_a, const float* wc_a, const float* bc_a, const void* w1_a,
+                                                          const float* b1_a, float* out_a, const float* prior_b, const float* w0_b,
+                                                          const float* b0_b, const float* wc_b, const float* bc_b, const void* w1_b,
+                                                          const float* b1_b, float* out_b, effi_stream_t stream) {
+    if (!x || !prior_a || !w0_a || !b0_a || !wc_a || !bc_a || !w1_a || !b1_a || !out_a) return EFFI_ERR_BADARG;
+    if (!prior_b || !w0_b || !b0_b || !wc_b || !bc_b || !w1_b || !b1_b || !out_b) return EFFI_ERR_BADARG;
+    if (D < 1 || H < 1 || W < 1) return EFFI_ERR_BADARG;
+    if (D > kCspMaxD || (long)D * H * W >= (1L << 30)) return EFFI_ERR_UNSUPPORTED;
+    const int h = (H - 1) / 2 + 1, w = (W - 1) / 2 + 1;
+    const CspGenCall ca{prior_a, w0_a, b0_a, wc_a, bc_a, reinterpret_cast<const float*>(w1_a), b1_a, out_a};
+    const CspGenCall cb{prior_b, w0_b, b0_b, wc_b, bc_b, reinterpret_cast<const float*>(w1_b), b1_b, out_b};
+    const int cols = effi_cdiv(w, 16), tiles = cols * effi_cdiv(h, 8);
+    hipLaunchKernelGGL(csp_gen_roll_rp_kernel, dim3((unsigned)tiles, 1, 2), dim3(256), 0, effi_s(stream), x, H, W, ca, cb, D, h, w, cols, tiles);
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
 }
 
 extern "C" int EFFI_FN(effi_deconv3d_k3s2_bf16x3_f32)(const float* in, int cin, const void* wpack_bf16, const float* bias, int cout, int D,

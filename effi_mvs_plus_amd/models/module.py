@@ -465,11 +465,15 @@ class cost_up_small(nn.Module):
         """``a.run(x, prior_a)`` and ``b.run(x, prior_b)`` with every layer of the two blocks in ONE launch (the blocks are
         independent: CSP_R[s] and CSP_C[s] of a stage, reference models/Effi_MVS_plus.py:520-531) -> ((out_a, c1_a), (out_b, c1_b))."""
         (w0a, b0a), (w0b, b0b) = a.conv0._packed(), b.conv0._packed()
-        fa, fb = ops.conv3d_k3_pair(x, w0a, b0a, x, w0b, b0b, 8, sxy=2, relu=True)
         (wca, bca), (wcb, bcb) = a.conv_cost._packed(), b.conv_cost._packed()
-        ga, gb = ops.conv3d_k3_pair(prior_a, wca, bca, prior_b, wcb, bcb, 8, sxy=1, relu=True)
         (w1a, b1a), (w1b, b1b) = a._roll_packed(), b._roll_packed()
-        c1a, c1b = ops.conv3d_k3s1_roll_pair([fa, ga], w1a, b1a, [fb, gb], w1b, b1b, 8, relu=True)
+        if ops.option("csp_gen") and x.shape[1] <= 14 and ops.get_option("roll_rp") != 0:
+            # conv0 | conv_cost generated inside conv1's rolling window (csrc/conv2d.hip: csp_gen_roll_rp_kernel): one launch, bitwise
+            c1a, c1b = ops.csp_gen_roll_pair(x, prior_a, w0a, b0a, wca, bca, w1a, b1a, prior_b, w0b, b0b, wcb, bcb, w1b, b1b)
+        else:
+            fa, fb = ops.conv3d_k3_pair(x, w0a, b0a, x, w0b, b0b, 8, sxy=2, relu=True)
+            ga, gb = ops.conv3d_k3_pair(prior_a, wca, bca, prior_b, wcb, bcb, 8, sxy=1, relu=True)
+            c1a, c1b = ops.conv3d_k3s1_roll_pair([fa, ga], w1a, b1a, [fb, gb], w1b, b1b, 8, relu=True)
         (w2a, b2a), (w2b, b2b) = a.conv2._packed(), b.conv2._packed()
         oa, ob = ops.deconv3d_k3_pair(c1a, w2a, b2a, c1b, w2b, b2b, 1, sz=1, relu=True)
         return (oa, c1a), (ob, c1b)

@@ -98,7 +98,7 @@ def _x3(name):
 # forms) in the library's own table (include/effi_mvs_hip.h: effi_set_option).  Both are initialised ONCE from the environment
 # (EFFI_<NAME>) and changed afterwards through ``set_option`` -- nothing on a per-call path reads the environment.
 _PY_OPTION_DEFAULTS = {"state_q4": 1, "c1k7_mfma": 1, "k5s2_split": 1, "roll": 1, "conv3d_unaligned_split": 1, "conv3d_s2_split": 1, "fpn_conv0_fused": 1,
-                       "fpn_split_head": 1, "csp_pair": 1, "head_taps": 1, "enc_tail": 0, "enc_gen": 1, "reduce_chunk": 2048, "gru_fused": 0}
+                       "fpn_split_head": 1, "csp_pair": 1, "head_taps": 1, "enc_tail": 0, "enc_gen": 1, "reduce_chunk": 2048, "gru_fused": 0, "csp_gen": 0}
 _PY_OPTS = {k: int(os.environ.get("EFFI_" + k.upper(), v)) for k, v in _PY_OPTION_DEFAULTS.items()}
 LIB_OPTIONS = ("warp_lds_kb", "dyn_form", "dyn_setup_exact", "dyn_xchg", "pixnet_mfma", "force_mr", "mr4_min", "mr4_nt2_max", "mr2_min",
                "wide_tiles", "roll_mr", "roll_zt", "roll_rp", "deconv_mr", "sr_waves", "enc_gen_mr3", "c3_lean")
@@ -968,6 +968,29 @@ def conv3d_k3_pair(x_a, weight_a, bias_a, x_b, weight_b, bias_b, cout, sxy=1, re
     work = lambda: {"flops": 2.0 * 2 * 27 * cin * cout * D * ho * wo, "bytes": 2 * 4.0 * (cin * D * h * w + cout * D * ho * wo)}
     check(_call(f"conv3d_pair_c8_s1{sxy}", work, _lib.lib().effi_conv3d_k3_pair_f32, _p(x_a), _p(weight_a), _p(bias_a), _p(out_a),
                 _p(x_b), _p(weight_b), _p(bias_b), _p(out_b), cin, cout, D, h, w, sxy, int(relu), _stream()), "effi_conv3d_k3_pair_f32")
+    return out_a, out_b
+
+
+def csp_gen_roll_pair(x, prior_a, w0_a, b0_a, wc_a, bc_a, w1_a, b1_a, prior_b, w0_b, b0_b, wc_b, bc_b, w1_b, b1_b):
+    """conv0 | conv_cost -> conv1 of two cross-scale blocks over one fine volume in ONE launch (``effi_csp_gen_roll_bf16x3_pair_f32``):
+    x [1,D,H,W]; priors [1,D,h,w]; w0 / wc [1,27,8] packed (``Conv3d._packed``), w1 the rolling operand -> (c1_a, c1_b) [8,D,h,w].
+    Bitwise ``conv3d_k3_pair`` (sxy 2 / sxy 1) + ``conv3d_k3s1_roll_pair``."""
+    _t(x, "fine volume"), _t(prior_a, "prior"), _t(prior_b, "prior")
+    _, D, H, W = x.shape
+    h, w = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    if tuple(prior_a.shape) != (1, D, h, w) or tuple(prior_b.shape) != (1, D, h, w):
+        raise ValueError(f"csp_gen_roll_pair: priors must be [1,{D},{h},{w}], got {tuple(prior_a.shape)} / {tuple(prior_b.shape)}")
+    for t_, n_ in ((w0_a, 216), (wc_a, 216), (w0_b, 216), (wc_b, 216), (b0_a, 8), (bc_a, 8), (b0_b, 8), (bc_b, 8)):
+        _t(t_, "generated layer's parameters")
+        if t_.numel() != n_:
+            raise ValueError("csp_gen_roll_pair: the generated layers are 1 -> 8 channels (27 x 8 weights, 8 biases)")
+    out_a = torch.empty(8, D, h, w, device=x.device, dtype=torch.float32)
+    out_b = torch.empty_like(out_a)
+    V = D * h * w
+    work = lambda: {"flops": 2 * 2.0 * 27 * (8 * 2 + 16 * 8) * V, "bytes": 4.0 * (D * H * W + 2 * V + 2 * 8 * V)}
+    check(_call("csp_gen_roll_pair", work, _x3("effi_csp_gen_roll_bf16x3_pair_f32"), _p(x), D, H, W, _p(prior_a), _p(w0_a), _p(b0_a),
+                _p(wc_a), _p(bc_a), _p(w1_a), _p(b1_a), _p(out_a), _p(prior_b), _p(w0_b), _p(b0_b), _p(wc_b), _p(bc_b), _p(w1_b),
+                _p(b1_b), _p(out_b), _stream()), "effi_csp_gen_roll_bf16x3_pair_f32")
     return out_a, out_b
 
 

@@ -471,6 +471,16 @@ int effi_conv3d_k3s1_roll_bf16x3_pair_f32(const float* const* srcs_a, const void
                                           const float* const* srcs_b, const void* wpack_b, const float* bias_b, float* out_b,
                                           const int* src_channels, int n_src, int cout, int D, int h, int w, int relu,
                                           effi_stream_t stream);
+/* Cross-scale block, conv0 | conv_cost -> conv1 of TWO blocks over one fine volume in one launch (reference models/module.py:501-516,
+ * caller models/Effi_MVS_plus.py:520-531): x [D][H][W]; per block prior [D][h][w] (h = (H-1)/2+1, w = (W-1)/2+1), w0 / wc [27][8] and
+ * b0 / bc [8] (conv0 stride (1,2,2) and conv_cost, BatchNorm folded, ReLU), w1 / b1 = conv1 as effi_conv3d_k3s1_roll_bf16x3_f32 takes
+ * it (row-pair operand, cin 16, cout 8, ReLU) -> out [8][D][h][w].  The 16 channels between the layers are generated inside the
+ * rolling-window kernel and never reach memory; bitwise the result of effi_conv3d_k3_pair_f32 (sxy 2, sxy 1) +
+ * effi_conv3d_k3s1_roll_bf16x3_pair_f32.  D <= 14. */
+int effi_csp_gen_roll_bf16x3_pair_f32(const float* x, int D, int H, int W, const float* prior_a, const float* w0_a, const float* b0_a,
+                                      const float* wc_a, const float* bc_a, const void* w1_a, const float* b1_a, float* out_a,
+                                      const float* prior_b, const float* w0_b, const float* b0_b, const float* wc_b, const float* bc_b,
+                                      const void* w1_b, const float* b1_b, float* out_b, effi_stream_t stream);
 /* effi_deconv3d_k3_f32 twice: stride (1,2,2), cout == 1, no skip. */
 int effi_deconv3d_k3_pair_f32(const float* in_a, const float* weight_a, const float* bias_a, float* out_a, const float* in_b,
                               const float* weight_b, const float* bias_b, float* out_b, int cin, int cout, int D, int h, int w,
@@ -636,6 +646,10 @@ int effi_conv3d_k3s1_roll_bf16x3_pair_f32_bf16(const float* const* srcs_a, const
                                           const float* const* srcs_b, const void* wpack_b, const float* bias_b, float* out_b,
                                           const int* src_channels, int n_src, int cout, int D, int h, int w, int relu,
                                           effi_stream_t stream);
+int effi_csp_gen_roll_bf16x3_pair_f32_bf16(const float* x, int D, int H, int W, const float* prior_a, const float* w0_a, const float* b0_a,
+                                      const float* wc_a, const float* bc_a, const void* w1_a, const float* b1_a, float* out_a,
+                                      const float* prior_b, const float* w0_b, const float* b0_b, const float* wc_b, const float* bc_b,
+                                      const void* w1_b, const float* b1_b, float* out_b, effi_stream_t stream);
 int effi_deconv3d_k3s2_bf16x3_f32_bf16(const float* in, int cin, const void* wpack_bf16, const float* bias, int cout,
                                   int D, int h, int w, int relu, const float* skip, float* out, effi_stream_t stream);
 

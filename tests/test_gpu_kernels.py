@@ -473,6 +473,52 @@ def test_cost_up_small_pair_equals_two_single_runs(dims):
             assert torch.equal(oa, ra[0]) and torch.equal(ca, ra[1]) and torch.equal(ob, rb[0]) and torch.equal(cb, rb[1])
     finally:
         ops.set_precision(before)
+
+
+@pytest.mark.parametrize("dims,odd", [((8, 36, 48), False), ((8, 37, 52), True), ((8, 74, 100), False), ((3, 9, 20), True), ((14, 16, 16), False)])
+@pytest.mark.parametrize("precision_", ["split", "bf16"])
+def test_cost_up_small_generated_inputs_are_bitwise_the_three_launches(dims, odd, precision_):
+    """conv0 | conv_cost generated inside conv1's rolling window (effi_csp_gen_roll_bf16x3_pair_f32, option csp_gen) against the
+    three launches it replaces (effi_conv3d_k3_pair_f32 with stride (1,2,2) and (1,1,1), effi_conv3d_k3s1_roll_bf16x3_pair_f32):
+    the same bits, ragged tiles, odd fine sizes (H = 2h - 1) and the largest supported depth included."""
+    import contextlib
+    import io
+    from effi_mvs_plus_amd import ops
+    from effi_mvs_plus_amd.models.module import cost_up_small
+    D, h, w = dims
+    g = torch.Generator().manual_seed(D * 1000 + h * 10 + int(odd))
+    blocks = []
+    for seed in (5, 6):
+        with contextlib.redirect_stdout(io.StringIO()):
+            m = cost_up_small(in_channels=1, base_channels=8).eval()
+        m.load_state_dict(synth.randomize_state_dict(m.state_dict(), seed=seed))
+        blocks.append(m.to(DEV))
+    a, b = blocks
+    H, W = (2 * h - 1, 2 * w - 1) if odd else (2 * h, 2 * w)
+    x = torch.randn(1, D, H, W, generator=g).to(DEV)
+    pa, pb = torch.randn(1, D, h, w, generator=g).to(DEV), torch.randn(1, D, h, w, generator=g).to(DEV)
+    before, gen0 = ops.get_precision(), ops.option("csp_gen")
+    ops.set_precision(precision_)
+    try:
+        (w0a, b0a), (w0b, b0b) = a.conv0._packed(), b.conv0._packed()
+        (wca, bca), (wcb, bcb) = a.conv_cost._packed(), b.conv_cost._packed()
+        (w1a, b1a), (w1b, b1b) = a._roll_packed(), b._roll_packed()
+        fa, fb = ops.conv3d_k3_pair(x, w0a, b0a, x, w0b, b0b, 8, sxy=2, relu=True)
+        ga, gb = ops.conv3d_k3_pair(pa, wca, bca, pb, wcb, bcb, 8, sxy=1, relu=True)
+        want_a, want_b = ops.conv3d_k3s1_roll_pair([fa, ga], w1a, b1a, [fb, gb], w1b, b1b, 8, relu=True)
+        got_a, got_b = ops.csp_gen_roll_pair(x, pa, w0a, b0a, wca, bca, w1a, b1a, pb, w0b, b0b, wcb, bcb, w1b, b1b)
+        torch.cuda.synchronize()
+        assert torch.isfinite(got_a).all() and want_a.abs().max() > 0
+        assert torch.equal(got_a, want_a), f"block a: {(got_a - want_a).abs().max().item():.3e}"
+        assert torch.equal(got_b, want_b), f"block b: {(got_b - want_b).abs().max().item():.3e}"
+        if not odd:                                   # the module path picks the fused form by default and the launches with csp_gen = 0
+            (o1, c1), _ = cost_up_small.run_pair(a, b, x, pa, pb)
+            ops.set_option("csp_gen", 0)
+            (o0, c0), _ = cost_up_small.run_pair(a, b, x, pa, pb)
+            assert torch.equal(c1, c0) and torch.equal(o1, o0) and torch.equal(c1, want_a)
+    finally:
+        ops.set_option("csp_gen", gen0)
+        ops.set_precision(before)
     # paired lookup: same queries into two volumes
     Dp = 11
     va, vb = torch.rand(Dp, h, w, generator=g).to(DEV), torch.rand(Dp, h, w, generator=g).to(DEV)
