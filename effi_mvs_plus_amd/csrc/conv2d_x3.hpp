@@ -607,6 +607,32 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
         }
     };
 
+    // Fused-1x1 epilogues (EPI_K1 / EPI_K1UP): the 3x3 bias quads and (K1) the extra-channel values of the wave's pixels are requested
+    // here, unconditionally from clamped addresses, instead of element by element behind bounds branches after the K loop (as the
+    // compiler laid that out: 16 single-dword loads in 8 dependent round trips per wave, profiles/r04_e_ablate_sr.txt: 10-13 us of a
+    // 21-32 us launch).  Same values: bitwise.
+    constexpr bool kK1 = (EPI == EFFI_EPI_K1 || EPI == EFFI_EPI_K1UP) && !(EFFI_ABL & 24) && EFFI_EPI_BATCH != 0;
+    f32x4 kb[kK1 ? NT : 1], kex[kK1 ? MR : 1];
+    if constexpr (kK1) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) kb[n] = *reinterpret_cast<const f32x4*>(a.bias + n * 16 + 4 * lk);
+#pragma unroll
+        for (int m = 0; m < MR; ++m) kex[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (EPI == EFFI_EPI_K1 && a.hd > 0) {                     // uniform: the layer has extra (context) channels
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                const int x = x0 + li + (WIDE ? 16 * m : 0), y = y0 + (WIDE ? wv : wv * MR + m);
+                const unsigned pix = ((y < h) & (x < w)) ? (unsigned)(y * w + x) : 0u;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 4 * lk + r;
+                    const float t_ = a.aux0[(size_t)((unsigned)min(c, a.hd - 1) * (unsigned)hw + pix)];
+                    kex[m][r] = (c < a.hd) ? t_ : 0.0f;
+                }
+            }
+        }
+    }
+
     prefetch(0);
     epi_issue_bias();
     if (kStateEarly) epi_issue_state();
@@ -737,10 +763,14 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
             const int y = y0 + (WIDE ? wv : wv * MR + m);
             inside[m] = (y < h) & (x < w);
             pixm[m] = inside[m] ? (long)y * w + x : 0;
+            if constexpr (kK1) {
+                ex[m] = kex[m];
+            } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = 4 * lk + r;
-                ex[m][r] = (c < a.hd) ? a.aux0[(long)c * hw + pixm[m]] : 0.0f;   // a.hd == 0: aux0 is a valid dummy, never read
+                for (int r = 0; r < 4; ++r) {
+                    const int c = 4 * lk + r;
+                    ex[m][r] = (c < a.hd) ? a.aux0[(long)c * hw + pixm[m]] : 0.0f;   // a.hd == 0: aux0 is a valid dummy, never read
+                }
             }
         }
 #pragma unroll
@@ -750,7 +780,7 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
                 f32x4 vf;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    vf[r] = (n < NT) ? acc[m][n][r] + a.bias[n * 16 + 4 * lk + r] : (inside[m] ? ex[m][r] : 0.0f);
+                    vf[r] = (n < NT) ? acc[m][n][r] + (kK1 ? kb[n < NT ? n : 0][r] : a.bias[n * 16 + 4 * lk + r]) : (inside[m] ? ex[m][r] : 0.0f);
                 if (relu1 && n < NT) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) vf[r] = fmaxf(vf[r], 0.0f);
