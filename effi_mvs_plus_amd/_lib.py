@@ -55,6 +55,8 @@ SIGNATURES = {
     "effi_conv3d_k3_pair_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "effi_conv3d_k3s1_roll_bf16x3_pair_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "effi_csp_gen_roll_bf16x3_pair_f32": [_vp, _i, _i, _i] + [_vp] * 16 + [_vp],
+    "effi_debug_poison_lds": [C.c_uint, _vp, _vp],
+    "effi_debug_pk_war_probe": [_vp, _i, _i, _i, _vp],
     "effi_deconv3d_k3_pair_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "effi_homo_warp_bwd_f32": [_vp, _vp, _l, _l, _i, _i, _i, _i, _vp, _vp, _vp],
     "effi_warpcorr_views_bwd_f32": [_vp, _vp, _i, _vp, _vp, _l, _l, _i, _i, _i, _i, _vp, _vp, _vp, _vp],

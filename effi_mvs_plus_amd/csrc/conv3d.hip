@@ -322,6 +322,12 @@ __global__ __launch_bounds__(256) void conv3d_c1to8_kernel(C1Call ca, C1Call cb,
     }
 }
 
+// option c3_lean: unset = both dedicated kernels; otherwise a mask, bit 0 = the 1 -> 8 kernel, bit 1 = the 8 -> 1 kernel (A/B, bisection)
+static bool c3_lean(int bit) {
+    const long v = effi_option(EFFI_OPT_C3_LEAN);
+    return v == EFFI_OPT_UNSET || ((v >> bit) & 1);
+}
+
 // launch rule of the cin = 1 kernel: 8 planes per thread when the grid still covers the chip twice
 int launch_c1to8(const C1Call& a, const C1Call* b, int D, int h, int w, int sxy, int relu, hipStream_t st) {
     const int ho = (h - 1) / sxy + 1, wo = (w - 1) / sxy + 1;
@@ -361,7 +367,10 @@ __global__ __launch_bounds__(256) void conv3d_c8to1_kernel(C8Call ca, C8Call cb,
 #endif
     constexpr int IZ = ZPT + 2, CC = (ZPT == 8) ? 1 : EFFI_C8_CC;           // channels per chunk (in flight as registers during the multiplies)
     constexpr int IY = DECONV ? TY + 1 : TY + 2, IX = DECONV ? TX + 1 : TX + 2;
-    constexpr int PSZ = IY * IX, PSZP = (PSZ + 127) & ~127, NPL = (PSZP + 255) / 256, LASTN = PSZP - 256 * (NPL - 1);
+#ifndef EFFI_C8_PADMASK
+#define EFFI_C8_PADMASK 127
+#endif
+    constexpr int PSZ = IY * IX, PSZP = (PSZ + EFFI_C8_PADMASK) & ~EFFI_C8_PADMASK, NPL = (PSZP + 255) / 256, LASTN = PSZP - 256 * (NPL - 1);
     __shared__ float tile[CC * IZ * PSZP];
     __shared__ __attribute__((aligned(16))) float wl[8 * 28 + 4];          // 27 weights per channel at stride 28, then the bias
     const bool second = blockIdx.y != 0;
@@ -381,6 +390,7 @@ __global__ __launch_bounds__(256) void conv3d_c8to1_kernel(C8Call ca, C8Call cb,
     const long in_plane = (long)D * h * w;
 
     if (tid < 8 * 27) wl[(tid / 27) * 28 + tid % 27] = wgt[tid];
+    if (tid < 8) wl[tid * 28 + 27] = 0.0f;                                // the pad entry of a channel's seven quads
     if (tid == 0) wl[8 * 28] = bias ? bias[0] : 0.0f;
 
     int poff[NPL];
@@ -420,9 +430,17 @@ __global__ __launch_bounds__(256) void conv3d_c8to1_kernel(C8Call ca, C8Call cb,
             }
         }
     };
-    fetch(0);
+#ifndef EFFI_C8_PREFETCH
+#define EFFI_C8_PREFETCH 1
+#endif
+    if (EFFI_C8_PREFETCH) fetch(0);
+#ifdef EFFI_C8_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
     for (int c0 = 0; c0 < 8; c0 += CC) {
+        if (!EFFI_C8_PREFETCH) fetch(c0);
         if (c0) __syncthreads();                                         // the previous chunk's reads are done
 #pragma unroll
         for (int c = 0; c < CC; ++c)
@@ -435,7 +453,7 @@ __global__ __launch_bounds__(256) void conv3d_c8to1_kernel(C8Call ca, C8Call cb,
                     if (k + 1 < NPL || last_pass) tile[(c * IZ + lz) * PSZP + tid + k * 256] = (zok & (poff[k] >= 0)) ? pf[c][lz][k] : 0.0f;
             }
         __syncthreads();
-        if (c0 + CC < 8) fetch(c0 + CC);
+        if (EFFI_C8_PREFETCH && c0 + CC < 8) fetch(c0 + CC);
 #pragma unroll 1
         for (int c = 0; c < CC; ++c) {
             float wk[28];
@@ -445,6 +463,9 @@ __global__ __launch_bounds__(256) void conv3d_c8to1_kernel(C8Call ca, C8Call cb,
                 wk[4 * q] = t[0]; wk[4 * q + 1] = t[1]; wk[4 * q + 2] = t[2]; wk[4 * q + 3] = t[3];
             }
             const float* tc = tile + c * IZ * PSZP + ty * IX + tx;
+#ifdef EFFI_C8_NO_B96
+            acc[0] = fmaf(wk[27], 0.0f, acc[0]);                         // keeps the seventh quad a whole 16-byte read
+#endif
             if constexpr (!DECONV) {
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
@@ -518,8 +539,7 @@ template <bool DECONV>
 int launch_c8to1(const C8Call& a, const C8Call* b, int D, int h, int w, int relu, hipStream_t st) {
     if (8L * D * h * w >= (1L << 29)) return EFFI_ERR_UNSUPPORTED;              // 32-bit byte offsets inside the input tensor
     const long tiles = (long)effi_cdiv(w, TX) * effi_cdiv(h, TY), ncall = b ? 2 : 1;
-    const long z8_env = effi_option(EFFI_OPT_C3_LEAN);                           // 4 / 8: force the planes per thread (A/B)
-    const bool z8 = z8_env == 8 || (z8_env != 4 && tiles * effi_cdiv(D, 8) * ncall >= 512);
+    const bool z8 = tiles * effi_cdiv(D, 8) * ncall >= 512;
     const dim3 grid((unsigned)(tiles * effi_cdiv(D, z8 ? 8 : 4)), (unsigned)ncall);
     if (z8) hipLaunchKernelGGL((conv3d_c8to1_kernel<DECONV, 8>), grid, dim3(256), 0, st, a, b ? *b : a, D, h, w, relu);
     else hipLaunchKernelGGL((conv3d_c8to1_kernel<DECONV, 4>), grid, dim3(256), 0, st, a, b ? *b : a, D, h, w, relu);
@@ -752,11 +772,11 @@ extern "C" int effi_conv3d_k3_f32(const float* const* srcs, const int* src_chann
         cin += s.ch[i];
     }
     hipStream_t st = effi_s(stream);
-    if (cin == 1 && cout == 8 && sz == 1 && (sxy == 1 || sxy == 2) && !skip && effi_option(EFFI_OPT_C3_LEAN) != 0) {
+    if (cin == 1 && cout == 8 && sz == 1 && (sxy == 1 || sxy == 2) && !skip && c3_lean(0)) {
         const C1Call c{srcs[0], weight, bias, out};
         return launch_c1to8(c, nullptr, D, h, w, sxy, relu, st);
     }
-    if (cin == 8 && n_src == 1 && cout == 1 && sz == 1 && sxy == 1 && !skip && effi_option(EFFI_OPT_C3_LEAN) != 0) {
+    if (cin == 8 && n_src == 1 && cout == 1 && sz == 1 && sxy == 1 && !skip && c3_lean(1)) {
         const C8Call c{srcs[0], weight, bias, out};
         return launch_c8to1<false>(c, nullptr, D, h, w, relu, st);
     }
@@ -784,7 +804,7 @@ extern "C" int effi_deconv3d_k3_f32(const float* in, int cin, const float* weigh
         else   // low-resolution level: split the output channels finer so the grid covers the chip
             hipLaunchKernelGGL((deconv3d_k3_kernel<4, 2>), dim3(tiles * D * (cout / 4)), dim3(256), 0, st, in, cin, weight, bias,
                                cout, D, h, w, relu, skip, out);
-    } else if (sz == 1 && cout == 1 && cin == 8 && !skip && effi_option(EFFI_OPT_C3_LEAN) != 0) {
+    } else if (sz == 1 && cout == 1 && cin == 8 && !skip && c3_lean(1)) {
         const C8Call c{in, weight, bias, out};
         return launch_c8to1<true>(c, nullptr, D, h, w, relu, st);
     } else if (sz == 1 && cout == 1) {
@@ -822,7 +842,7 @@ extern "C" int effi_conv3d_k3_pair_f32(const float* in_a, const float* weight_a,
     a.wgt = weight_a; a.bias = bias_a; a.skip = nullptr; a.out = out_a;
     b.wgt = weight_b; b.bias = bias_b; b.skip = nullptr; b.out = out_b;
     hipStream_t st = effi_s(stream);
-    if (cin == 1 && effi_option(EFFI_OPT_C3_LEAN) != 0) {
+    if (cin == 1 && c3_lean(0)) {
         const C1Call ca{in_a, weight_a, bias_a, out_a}, cb{in_b, weight_b, bias_b, out_b};
         return launch_c1to8(ca, &cb, D, h, w, sxy, relu, st);
     }
@@ -837,7 +857,7 @@ extern "C" int effi_deconv3d_k3_pair_f32(const float* in_a, const float* weight_
                                          int cout, int D, int h, int w, int sz, int relu, effi_stream_t stream) {
     if (!in_a || !weight_a || !out_a || !in_b || !weight_b || !out_b || cin < 1 || D < 1 || h < 1 || w < 1) return EFFI_ERR_BADARG;
     if (sz != 1 || cout != 1) return EFFI_ERR_UNSUPPORTED;
-    if (cin == 8 && effi_option(EFFI_OPT_C3_LEAN) != 0) {
+    if (cin == 8 && c3_lean(1)) {
         const C8Call ca{in_a, weight_a, bias_a, out_a}, cb{in_b, weight_b, bias_b, out_b};
         return launch_c8to1<true>(ca, &cb, D, h, w, relu, effi_s(stream));
     }

@@ -481,6 +481,13 @@ int effi_csp_gen_roll_bf16x3_pair_f32(const float* x, int D, int H, int W, const
                                       const float* wc_a, const float* bc_a, const void* w1_a, const float* b1_a, float* out_a,
                                       const float* prior_b, const float* w0_b, const float* b0_b, const float* wc_b, const float* bc_b,
                                       const void* w1_b, const float* b1_b, float* out_b, effi_stream_t stream);
+/* Diagnostics (tools/stress_c8_corun.py, tests): every CU's LDS is overwritten with `pattern` by a throw-away kernel, so that a later
+ * kernel reading LDS it has not written sees that pattern instead of a previous workgroup's data.  sink4: 4 writable bytes. */
+int effi_debug_poison_lds(unsigned pattern, void* sink4, effi_stream_t stream);
+/* Diagnostics (tools/probe_pk_war.py): repeats `acc += (x, y) * w` as one v_pk_fma_f32 whose low source register is overwritten by the
+ * very next instruction (and restored) -- variant 0: back to back, 1: an s_nop between, 3: two v_fma_f32 instead -- and returns the
+ * accumulators of every lane in out[2 * 256 * blocks]; expected (16 reps x, 16 reps y) with x = 1 + (tid & 15) / 16, y = 2. */
+int effi_debug_pk_war_probe(float* out, int blocks, int reps, int variant, effi_stream_t stream);
 /* effi_deconv3d_k3_f32 twice: stride (1,2,2), cout == 1, no skip. */
 int effi_deconv3d_k3_pair_f32(const float* in_a, const float* weight_a, const float* bias_a, float* out_a, const float* in_b,
                               const float* weight_b, const float* bias_b, float* out_b, int cin, int cout, int D, int h, int w,

@@ -1118,3 +1118,38 @@ def test_stage1_hypotheses_and_intervals():
         assert misc[3].item() == (1.0 / dv[0, -1]).item() and misc[4].item() == (1.0 / dv[0, 0]).item()
     with pytest.raises(Exception):
         ops.stage1_hypotheses(torch.zeros(1, device=DEV), 8)          # n_range < 2
+
+
+def test_3d_end_kernels_do_not_depend_on_what_shares_their_cu():
+    """Round 4: the compiler's packed (z-pair) form of the dedicated 8 -> 1 channel kernel returned wrong low halves in lanes 48-63 --
+    only while another queue ran matrix-core GEMMs on the same CUs (10-60 % of the launches; never alone, never next to element-wise
+    kernels; tools/stress_c8_corun.py).  conv3d.hip is compiled without the SLP vectoriser since (csrc/Makefile).  Here: the three
+    dedicated kernels next to hipBLASLt GEMMs on two more streams, every result against a quiet run, bit for bit."""
+    from effi_mvs_plus_amd import ops
+    g = torch.Generator().manual_seed(0)
+    rnd = lambda *s_: torch.randn(*s_, generator=g).to(DEV)
+    D, h, w = 8, 24, 32
+    x8, w81, b1 = rnd(8, D, h, w), rnd(8, 27, 1) * 0.1, rnd(1)
+    x1, w18, b8 = rnd(1, D, 2 * h, 2 * w), rnd(1, 27, 8) * 0.2, rnd(8)
+
+    def run():
+        return (ops.conv3d_k3([x8], w81, None, 1, relu=False), *ops.conv3d_k3_pair(x1, w18, b8, x1, w18, b8, 8, sxy=2),
+                *ops.deconv3d_k3_pair(x8, w81, b1, x8, w81, b1, 1, sz=1))
+
+    want = [o.clone() for o in run()]
+    A, B = rnd(2048, 2048).bfloat16(), rnd(2048, 2048).bfloat16()
+    torch.cuda.synchronize()
+    s0, s1, s2 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    bad = 0
+    for _ in range(80):
+        outs = []
+        for _ in range(6):
+            with torch.cuda.stream(s1):
+                A @ B
+            with torch.cuda.stream(s2):
+                B @ A
+            with torch.cuda.stream(s0):
+                outs.append(run())
+        torch.cuda.synchronize()
+        bad += sum(int(not all(torch.equal(a, b) for a, b in zip(o, want))) for o in outs)
+    assert bad == 0, f"{bad} of 480 runs next to GEMMs differ from the quiet run"
