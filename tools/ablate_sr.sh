@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/.."
 mode=$1; variants=$2; stages=${3:-2}
 CS=effi_mvs_plus_amd/csrc
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wno-unused-function"
 if [ "$mode" = build ]; then
   mkdir -p abl_libs
   for v in $variants; do

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 name=$1; flags=$2
 CS=effi_mvs_plus_amd/csrc
 mkdir -p abl_libs
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function $flags -c $CS/conv2d_sr.hip -o /tmp/conv2d_sr_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wno-unused-function $flags -c $CS/conv2d_sr.hip -o /tmp/conv2d_sr_$name.o
 objs=$(ls $CS/*.o | grep -v "conv2d_sr.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o abl_libs/libeffimvs_$name.so $objs /tmp/conv2d_sr_$name.o
 echo built abl_libs/libeffimvs_$name.so
