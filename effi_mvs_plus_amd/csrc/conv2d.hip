@@ -827,7 +827,9 @@ __device__ __forceinline__ void conv3d_roll_bf16x3_body(const Conv2dArgs a, int 
     }
     const int lane_base = ((wv * MR) * AW + li + XOFF) * 8;
 
-    f32x4 acc[MR][NT];
+    f32x4 acc[MR][NT], rbias[NT];                                      // bias quads of the lane's N-tiles: once per workgroup, not per plane
+#pragma unroll
+    for (int n = 0; n < NT; ++n) rbias[n] = *reinterpret_cast<const f32x4*>(a.bias + n * 16 + 4 * lk);
     prefetch(B0{}, z0 - 1);
     prefetch(B1{}, z0);
     stash(B0{}, 0);
@@ -882,7 +884,7 @@ __device__ __forceinline__ void conv3d_roll_bf16x3_body(const Conv2dArgs a, int 
             if (y >= h || x >= w) continue;
             const long pix = (long)y * w + x;
 #pragma unroll
-            for (int n = 0; n < NT; ++n) conv_epilogue_store_t<EFFI_EPI_PLAIN>(a, acc[m][n], n * 16 + 4 * lk, pix, hw, z);
+            for (int n = 0; n < NT; ++n) conv_epilogue_store_t<EFFI_EPI_PLAIN>(a, acc[m][n], n * 16 + 4 * lk, pix, hw, z, 0, 0, &rbias[n]);
         }
         __syncthreads();                                               // all reads of slot `rot` done before it is refilled
         rot = s1;
@@ -983,6 +985,7 @@ __device__ __forceinline__ void conv3d_roll_rp_bf16x3_body(const Conv2dArgs a, i
     const int lane_base = ((wv * MR) * AW + li + XOFF) * 8;
 
     f32x4 acc[MP];
+    const f32x4 rbias = *reinterpret_cast<const f32x4*>(a.bias + 4 * (lk & 1));   // once per workgroup, not per plane
     using BL = std::integral_constant<int, NBUF - 1>;                  // the second buffer, or the only one
     prefetch(B0{}, z0 - 1);
     if (NBUF == 2) prefetch(BL{}, z0);
@@ -1025,7 +1028,7 @@ __device__ __forceinline__ void conv3d_roll_rp_bf16x3_body(const Conv2dArgs a, i
         for (int m = 0; m < MP; ++m) {
             const int y = y0 + wv * MR + 2 * m + (lk >> 1);
             if (y >= h || x >= w) continue;
-            conv_epilogue_store_t<EFFI_EPI_PLAIN>(a, acc[m], 4 * (lk & 1), (long)y * w + x, hw, z);
+            conv_epilogue_store_t<EFFI_EPI_PLAIN>(a, acc[m], 4 * (lk & 1), (long)y * w + x, hw, z, 0, 0, &rbias);
         }
         __syncthreads();
         rot = s1;

@@ -119,13 +119,15 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // largest single cost of the memory-bound layers.  Channel-last output becomes one float4 per lane, 1 KB contiguous per wave.
 template <int EPI, bool SR = false>
 __device__ __forceinline__ void conv_epilogue_store_t(const Conv2dArgs& a, const f32x4& acc, int co0, long pix, long hw,
-                                                      int zpl, int y = 0, int x = 0) {
+                                                      int zpl, int y = 0, int x = 0, const f32x4* biasq = nullptr) {
     constexpr bool kShuf = (EPI == EFFI_EPI_ADD_SHUF2 || EPI == EFFI_EPI_NHWC_ADD_SHUF2);
     constexpr bool kNhwc = (EPI == EFFI_EPI_NHWC || EPI == EFFI_EPI_NHWC_ADD_SHUF2);
     constexpr bool kPlain = (EPI == EFFI_EPI_PLAIN || EPI == EFFI_EPI_ADD_SHUF2);
     float v[4];
+    // biasq: the caller's copy of bias[co0 .. co0 + 3], fetched ahead of the multiplies (the rolling 3-D kernels: once per workgroup
+    // instead of a dependent load per plane); same values
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = acc[r] + a.bias[co0 + r];       // bias is padded to 16*NT entries
+    for (int r = 0; r < 4; ++r) v[r] = acc[r] + (biasq ? (*biasq)[r] : a.bias[co0 + r]);       // bias is padded to 16*NT entries
     if (kNhwc || kPlain) {                                             // activation: one uniform branch for the 4 values
         if (a.act == EFFI_ACT_RELU) {
 #pragma unroll
@@ -633,6 +635,14 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
         }
     }
 
+    // every other epilogue (planar maps, channel-last heads, z-batched 3-D): the bias quads of the lane's N-tiles, fetched here
+    constexpr bool kBiasQ = !kBatchT && !kK1 && !(EFFI_ABL & 24) && EFFI_EPI_BATCH != 0;
+    f32x4 gb[kBiasQ ? NT : 1];
+    if constexpr (kBiasQ) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) gb[n] = *reinterpret_cast<const f32x4*>(a.bias + n * 16 + 4 * lk);
+    }
+
     prefetch(0);
     epi_issue_bias();
     if (kStateEarly) epi_issue_state();
@@ -968,7 +978,8 @@ __device__ __forceinline__ void conv2d_k3_bf16x3_tile(const Conv2dArgs a, int ti
         const long pix = (long)y * w + x;
 #pragma unroll
         for (int n = 0; n < NT; ++n)
-            conv_epilogue_store_t<((EPI == EFFI_EPI_K1 || EPI == EFFI_EPI_K1UP) ? EFFI_EPI_PLAIN : EPI), SR>(a, acc[m][n], n * 16 + 4 * lk, pix, hw, zpl, y, x);
+            conv_epilogue_store_t<((EPI == EFFI_EPI_K1 || EPI == EFFI_EPI_K1UP) ? EFFI_EPI_PLAIN : EPI), SR>(a, acc[m][n], n * 16 + 4 * lk, pix, hw, zpl, y, x,
+                                                                                                          kBiasQ ? &gb[n] : nullptr);
     }
 }
 
