@@ -1491,10 +1491,19 @@ __global__ __launch_bounds__(256) void deconv3d_s2_bf16x3_kernel(const DeconvArg
         float bv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[r] = a.bias[cb + r];
+        // the skip values of a row's 16 outputs are fetched together BEFORE its stores: load -> add -> store per element is a chain of
+        // 16 dependent round trips per row (skip and out may alias as far as the compiler knows, so it keeps that order)
 #pragma unroll
         for (int m = 0; m < MR; ++m) {
             const int y = y0 + wv * MR + m;
             if (y >= h || x >= w) continue;
+            float sk[4][4];
+#pragma unroll
+            for (int pzy = 0; pzy < 4; ++pzy) {
+                const long o = ((long)(2 * z + (pzy >> 1)) * Ho + (2 * y + (pzy & 1))) * Wo + 2 * x + px;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sk[pzy][r] = (a.skip && cb + r < a.cout) ? a.skip[(long)(cb + r) * ostride + o] : 0.0f;
+            }
 #pragma unroll
             for (int pzy = 0; pzy < 4; ++pzy) {
                 const long o = ((long)(2 * z + (pzy >> 1)) * Ho + (2 * y + (pzy & 1))) * Wo + 2 * x + px;
@@ -1505,7 +1514,7 @@ __global__ __launch_bounds__(256) void deconv3d_s2_bf16x3_kernel(const DeconvArg
                     float v = acc[m][pzy][r] + bv[r];
                     if (a.relu) v = fmaxf(v, 0.0f);
                     const long oo = (long)co * ostride + o;
-                    if (a.skip) v += a.skip[oo];
+                    if (a.skip) v += sk[pzy][r];
                     a.out[oo] = v;
                 }
             }
@@ -1520,6 +1529,14 @@ __global__ __launch_bounds__(256) void deconv3d_s2_bf16x3_kernel(const DeconvArg
     for (int m = 0; m < MR; ++m) {
         const int y = y0 + wv * MR + m;
         if (y >= h || x >= w) continue;
+        float2 sk[4][4];                                               // fetched together before the row's stores (see above)
+#pragma unroll
+        for (int pzy = 0; pzy < 4; ++pzy) {
+            const long o = ((long)(2 * z + (pzy >> 1)) * Ho + (2 * y + (pzy & 1))) * Wo + 2 * x;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                sk[pzy][r] = (a.skip && 4 * lk + r < a.cout) ? *reinterpret_cast<const float2*>(a.skip + (long)(4 * lk + r) * ostride + o) : make_float2(0.0f, 0.0f);
+        }
 #pragma unroll
         for (int pzy = 0; pzy < 4; ++pzy) {
             const long o = ((long)(2 * z + (pzy >> 1)) * Ho + (2 * y + (pzy & 1))) * Wo + 2 * x;
@@ -1531,9 +1548,8 @@ __global__ __launch_bounds__(256) void deconv3d_s2_bf16x3_kernel(const DeconvArg
                 if (a.relu) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
                 const long oo = (long)co * ostride + o;
                 if (a.skip) {
-                    const float2 sk = *reinterpret_cast<const float2*>(a.skip + oo);
-                    v0 += sk.x;
-                    v1 += sk.y;
+                    v0 += sk[pzy][r].x;
+                    v1 += sk[pzy][r].y;
                 }
                 *reinterpret_cast<float2*>(a.out + oo) = make_float2(v0, v1);
             }

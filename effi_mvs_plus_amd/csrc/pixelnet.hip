@@ -113,7 +113,9 @@ __global__ __launch_bounds__(256) void pixelwise_net_mfma_kernel(const float* __
     __shared__ float s_a1[16 * A1_W * A1_W];
     __shared__ float s_a2[16 * A2_W * A2_W];
     __shared__ float s_part[T * T];
+    __shared__ __attribute__((aligned(16))) float s_w0[160];              // layer 1: w0[9][16] | b0[16]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, n = lane & 15, kq = lane >> 4;
+    if (tid < 160) s_w0[tid] = prm[tid];                                  // OFF_W0 = 0, OFF_B0 = 144
     const int x0 = blockIdx.x * T, y0 = blockIdx.y * T;
     const float* __restrict__ ent = entropy + (long)blockIdx.z * h * w;
 
@@ -132,22 +134,29 @@ __global__ __launch_bounds__(256) void pixelwise_net_mfma_kernel(const float* __
     for (int s_ = 0; s_ < 36; ++s_) wa[s_] = prm[OFF_W1 + (kq * 36 + s_) * 16 + n];
     __syncthreads();
 
-    // layer 1: 1 -> 16 on the 20x20 patch (144 FMAs per pixel: vector ALU, as above)
+    // layer 1: 1 -> 16 on the 20x20 patch (144 FMAs per pixel: vector ALU, as above).  Its 160 parameters are read from LDS as
+    // broadcast quads (s_w0, filled before the barrier above): as scalar operands they did not fit the scalar registers next to
+    // the rest of the kernel and were spilled through v_writelane / v_readlane (397 of them in the ISA of round 4)
     for (int e = tid; e < A1_W * A1_W; e += 256) {
         const int py = e / A1_W, px = e - py * A1_W;
         const int gy = y0 - 2 + py, gx = x0 - 2 + px;
         const bool inside = (gy >= 0 && gy < h && gx >= 0 && gx < w);
-        float acc[16];
+        pn_f32x4 acc[4];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) acc[c] = prm[OFF_B0 + c];
-#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = *reinterpret_cast<const pn_f32x4*>(&s_w0[144 + 4 * q]);
+#pragma unroll 1
         for (int k = 0; k < 9; ++k) {
-            const float v = s_in[(py + k / 3) * IN_W + px + k % 3];
+            const int ky = k / 3;
+            const float v = s_in[(py + ky) * IN_W + px + k - 3 * ky];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) acc[c] = fmaf(v, prm[OFF_W0 + k * 16 + c], acc[c]);
+            for (int q = 0; q < 4; ++q) {
+                const pn_f32x4 wq = *reinterpret_cast<const pn_f32x4*>(&s_w0[k * 16 + 4 * q]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[q][r] = fmaf(v, wq[r], acc[q][r]);
+            }
         }
 #pragma unroll
-        for (int c = 0; c < 16; ++c) s_a1[c * (A1_W * A1_W) + e] = inside ? fmaxf(acc[c], 0.0f) : 0.0f;
+        for (int c = 0; c < 16; ++c) s_a1[c * (A1_W * A1_W) + e] = inside ? fmaxf(acc[c >> 2][c & 3], 0.0f) : 0.0f;
     }
     __syncthreads();
 
