@@ -256,14 +256,18 @@ __global__ __launch_bounds__(256) void conv3d_c1to8_kernel(C1Call ca, C1Call cb,
         poff[k] = ((e < PSZ) & (gy >= 0) & (gy < h) & (gx >= 0) & (gx < w)) ? gy * w + gx : -1;
     }
     float pf[IZ][NPL];
+    unsigned pb[NPL];                                  // in-plane byte offsets; the plane part of an address is a 32-bit scalar (host: D h w < 2^29)
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) pb[k] = (unsigned)max(poff[k], 0) * 4u;
+    const unsigned plane_b = (unsigned)(h * w) * 4u;
 #pragma unroll
     for (int lz = 0; lz < IZ; ++lz) {
         const int gz = iz0 + lz;
         const bool zok = (gz >= 0) & (gz < D);
-        const float* __restrict__ zp = in + (zok ? (long)gz * h * w : 0);
+        const unsigned so = (unsigned)min(max(gz, 0), D - 1) * plane_b;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
-            const float t = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(zp) + (unsigned)max(poff[k], 0) * 4u);
+            const float t = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(in) + (so + pb[k]));
             pf[lz][k] = (zok & (poff[k] >= 0)) ? t : 0.0f;
         }
     }
@@ -330,6 +334,7 @@ static bool c3_lean(int bit) {
 
 // launch rule of the cin = 1 kernel: 8 planes per thread when the grid still covers the chip twice
 int launch_c1to8(const C1Call& a, const C1Call* b, int D, int h, int w, int sxy, int relu, hipStream_t st) {
+    if ((long)D * h * w >= (1L << 29)) return EFFI_ERR_UNSUPPORTED;              // 32-bit byte offsets inside the input volume
     const int ho = (h - 1) / sxy + 1, wo = (w - 1) / sxy + 1;
     const long tiles = (long)effi_cdiv(wo, TX) * effi_cdiv(ho, TY), ncall = b ? 2 : 1;
     const bool z8 = tiles * effi_cdiv(D, 8) * ncall >= 512;
