@@ -240,6 +240,9 @@ def main():
                          "captured with the pass's two internal streams (throughput metric: while one view is in its low-resolution "
                          "stages, which cannot fill 256 CUs, the others use them); 1 = strictly one view after the other on a linear "
                          "graph.  With more than one the single-stream figure is measured right after and reported as 'single_stream'")
+    ap.add_argument("--graph-branches", default="auto", choices=["auto", "0", "1"],
+                    help="views in flight: capture each view's graph with the pass's side stream (1) or as a linear one-stream graph (0); "
+                         "auto = the measured better form (see DESIGN.md section 6)")
     ap.add_argument("--no-other-precision", action="store_true", help="skip the secondary run in the other conv arithmetic (profiling runs)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1: nccl (= RCCL over xGMI, the real path) or gloo (rehearsal of the "
@@ -322,7 +325,7 @@ def main():
         # into the slots before the timed region -- "inputs resident in HBM" -- and a step replays the slot's graph
         n_slots = max(n_scenes, args.in_flight)
         try:
-            if args.in_flight > 1:                # each view's graph keeps the pass's side stream: more to overlap across views
+            if args.in_flight > 1 and args.graph_branches != "0":    # each view's graph keeps the pass's side stream (auto: measured better)
                 ops.set_branches(True)
             graphed = HotPathGraph(net, *inputs[0], slots=n_slots)
             for i in range(n_slots):
@@ -368,6 +371,20 @@ def main():
         key = args.profile_key or max(fam_ms, key=lambda k: fam_ms[k])      # the kernel TEMPLATE with the largest share of a view
         fam_keys = sorted(k_ for k_ in disc if family_of(k_) == key or k_ == key)
         step(1)                                   # last warm-up step, no instrumentation
+        if graphed is not None and args.in_flight > 1:
+            # ... and W warm-up steps launched exactly as the timed ones are: slot i's graph on lane i.  A stream's hardware queue
+            # is created at its first use and a graph's first launch into a stream uploads it there; with the warm-up on the
+            # current stream only, both fell into the timed region (20 steps: 590 views/s; the same steps after this warm-up:
+            # see DESIGN.md section 6)
+            cur = torch.cuda.current_stream()
+            for st_ in lanes:
+                st_.wait_stream(cur)
+            for i in range(max(args.warmup, len(lanes))):
+                with torch.cuda.stream(lanes[i % len(lanes)]):
+                    step(i)
+            for st_ in lanes:
+                cur.wait_stream(st_)
+            torch.cuda.synchronize()
 
         # ---- timed region: exactly K steps + the final gather ---------------------------------------
         # eager launches: the dominant kernel's launches are bracketed with HIP events inside the timed region;

@@ -44,7 +44,7 @@ const float* effi_zero_page() {
 // ---- tuning / A-B options (common.hpp: EffiOption) ------------------------------------------------------------------------
 namespace {
 const char* const kOptName[EFFI_OPT_COUNT] = {"warp_lds_kb", "dyn_form", "dyn_setup_exact", "dyn_xchg", "pixnet_mfma", "force_mr", "mr4_min",
-                                              "mr4_nt2_max", "mr2_min", "wide_tiles", "roll_mr", "roll_zt", "roll_rp", "deconv_mr", "sr_waves", "enc_gen_mr3", "c3_lean"};
+                                              "mr4_nt2_max", "mr2_min", "wide_tiles", "roll_mr", "roll_zt", "roll_rp", "deconv_mr", "sr_waves", "enc_gen_mr3", "c3_lean", "dyn_win"};
 long g_opt[EFFI_OPT_COUNT];
 std::once_flag g_opt_once;
 void load_options() {

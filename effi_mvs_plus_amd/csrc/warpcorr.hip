@@ -833,11 +833,26 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* ref_arg,
     }
 }
 
+// sum_c tap[c] * ref[c] over C channels as TWO interleaved chains (even / odd channels) of packed FMAs (v_pk_fma_f32: C/2 instructions
+// + one add instead of C); used by the hypothesis-per-lane gather kernel and by the LDS-window kernel, which therefore agree bit for bit
+typedef float effi_f4 __attribute__((ext_vector_type(4)));
+template <int Q>
+__device__ __forceinline__ float dyn_dot(const effi_f4 (&tv)[Q], const float4 (&r)[Q]) {
+    f32x2 a = f32x2{tv[0].x, tv[0].y} * f32x2{r[0].x, r[0].y};
+    a = __builtin_elementwise_fma(f32x2{tv[0].z, tv[0].w}, f32x2{r[0].z, r[0].w}, a);
+#pragma unroll
+    for (int q = 1; q < Q; ++q) {
+        a = __builtin_elementwise_fma(f32x2{tv[q].x, tv[q].y}, f32x2{r[q].x, r[q].y}, a);
+        a = __builtin_elementwise_fma(f32x2{tv[q].z, tv[q].w}, f32x2{r[q].z, r[q].w}, a);
+    }
+    return a.x + a.y;
+}
+
 // Hypothesis-per-lane form of the same operator (the default for C = 8 / 16): the C/4 lanes of a pixel no longer split the channels of every
 // hypothesis -- which makes every lane set up every hypothesis once the set-up cannot be exchanged between lanes -- but the
 // hypotheses: lane `sub` owns d = sub, sub + C/4, ... with ALL C channels of the pixel (the reference features sit in C registers),
 // so a pixel's D x S set-ups are computed exactly once, and nothing crosses lanes (no exchange, no reduction).  Same FAST set-up
-// arithmetic as above; the channel sum runs over C in one lane (a different association than 4 + butterfly: ~1e-7 relative).
+// arithmetic as above; the channel sum runs over C in one lane, as two chains of packed FMAs (dyn_dot; a different association than 4 + butterfly: ~1e-7 relative).
 template <int C>
 __global__ __launch_bounds__(256) void warpcorr_dyn_hyp_kernel(const float* ref_arg, EffiPtrList srcs, int S,
                                                                const float* __restrict__ rt_all,
@@ -882,29 +897,330 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_hyp_kernel(const float* ref_
             project_xy(rx * dep + rt[9], ry * dep + rt[10], rz * dep + rt[11], hw2, rhw2, hh2, rhh2, wm1, hm1, ix, iy);
             WinTaps tw;
             make_taps_win<false>(ix, iy, w, h, 0, 0, w, h, tw);
-            float4 tv[4][C / 4];
+            effi_f4 tv[4][C / 4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const char* tp = sb + (unsigned)(tw.a[k] * (C * 4));
 #pragma unroll
-                for (int q = 0; q < C / 4; ++q) tv[k][q] = *reinterpret_cast<const float4*>(tp + 16 * q);
+                for (int q = 0; q < C / 4; ++q) tv[k][q] = *reinterpret_cast<const effi_f4*>(tp + 16 * q);
             }
             float sd = 0.0f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                float dk = tv[k][0].x * r[0].x;
-                dk = fmaf(tv[k][0].y, r[0].y, dk); dk = fmaf(tv[k][0].z, r[0].z, dk); dk = fmaf(tv[k][0].w, r[0].w, dk);
-#pragma unroll
-                for (int q = 1; q < C / 4; ++q) {
-                    dk = fmaf(tv[k][q].x, r[q].x, dk); dk = fmaf(tv[k][q].y, r[q].y, dk);
-                    dk = fmaf(tv[k][q].z, r[q].z, dk); dk = fmaf(tv[k][q].w, r[q].w, dk);
-                }
+                const float dk = dyn_dot<C / 4>(tv[k], r);
                 sd = (k == 0) ? tw.w[0] * dk : fmaf(tw.w[k], dk, sd);
             }
             acc = fmaf(wv, sd, acc);
         }
         sim[(long)d * hw + pix] = (acc / (float)C) / den;
         samples[(long)d * hw + pix] = dep;
+    }
+}
+
+// LDS-WINDOW form of the hypothesis-per-lane kernel (round 4; the default for C = 8 / 16, D <= 8).  The kernel above is bound by the
+// texture path: 1.9 M wave-level 16-byte gathers at 592x800 (tools/microbench/ta_gather.hip: 80 us for the access shape alone),
+// although the source positions of a tile of reference pixels are confined to a small box -- median 24 x 10 source pixels for the
+// 16 x 8 tile's 128 pixels x 8 hypotheses (tools/probe_dyn_windows.py on the benchmark rig, whose depth maps are noisy).  Here, per
+// source view:
+//   * every lane sets up its hypotheses (projection as above) and the workgroup reduces the bounding box of the tap pixels: per-lane
+//     min / max, packed as two 16-bit pairs, a wave butterfly (RESULTS cross lanes, never set-ups), one LDS store per wave; every
+//     thread combines the four waves' boxes after the barrier (no atomics);
+//   * the box (clipped to the image; channel-last rows are contiguous runs) is copied into LDS by global_load_lds_dwordx4 -- an image
+//     of 16 / 12 rows with a fixed pitch of 32 pixels (C = 8: 1 KB = one wave-instruction per row; tap addresses are shifts) -- and
+//     the taps are read with ds_read_b128 (128 B/clk/CU, no tag look-ups) instead of through the L1;
+//   * a view whose box exceeds the image (wider than 32 pixels or taller than the image's rows: a depth discontinuity inside the tile,
+//     extreme geometry) is sampled from global memory by the same code: identical arithmetic, bit for bit (option dyn_win = 0 forces
+//     it for every view: the cross-check of the tests).
+// Software pipeline over the views, ONE barrier per view: set-ups + box of view v + 1, barrier, the window of v + 1 requested (LDS-DMA:
+// no registers), view v sampled from its image.  Same operations in the same order as warpcorr_dyn_hyp_kernel: bitwise the same
+// similarities.  Instruction count per wave and view (C = 8): ~600 as the gather kernel, which it replaces the L1 path of.
+struct DynTaps {
+    float w[4];
+    unsigned a[4];     // byte offset of the tap pixel's C channels: inside the LDS image / inside the source map
+};
+constexpr int DYN_WIN_PX = 32;         // pixels per image row (C = 8: 64 float4 = one wave-instruction of the copy; C = 16: 128 = two)
+
+// MODE 0: taps in the source map; 1: in the LDS image of a window that was clipped at the image border; 2: in the LDS image of an
+// INTERIOR window (the view's whole box lies inside the image: every tap is inside the image and inside the window -- no validity
+// tests, no clamps, and the four tap addresses are ONE register + immediate offsets).  Same weights in every mode, bit for bit.
+template <int MODE, int C>
+__device__ __forceinline__ void make_taps_dyn(float ix, float iy, int W, int H, int x_lo, int y_lo, int ww, int wh, DynTaps& t) {
+    // ix, iy: already clamped to [-2, W + 1] x [-2, H + 1] (make_taps_win's neutral clamp, applied by the caller)
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    if (MODE == 2) {
+        const float wx0 = (x0f + 1.0f) - ix, wx1 = ix - x0f, wy0 = (y0f + 1.0f) - iy, wy1 = iy - y0f;
+        t.w[0] = wx0 * wy0;
+        t.w[1] = wx1 * wy0;
+        t.w[2] = wx0 * wy1;
+        t.w[3] = wx1 * wy1;
+        t.a[0] = (unsigned)(y0 - y_lo) * (DYN_WIN_PX * C * 4) + (unsigned)(x0 - x_lo) * (C * 4);
+        t.a[1] = t.a[0] + C * 4;
+        t.a[2] = t.a[0] + DYN_WIN_PX * C * 4;
+        t.a[3] = t.a[0] + DYN_WIN_PX * C * 4 + C * 4;
+        return;
+    }
+    const float wx0 = ((unsigned)x0 < (unsigned)W) ? (x0f + 1.0f) - ix : 0.0f;
+    const float wx1 = ((unsigned)(x0 + 1) < (unsigned)W) ? ix - x0f : 0.0f;
+    const float wy0 = ((unsigned)y0 < (unsigned)H) ? (y0f + 1.0f) - iy : 0.0f;
+    const float wy1 = ((unsigned)(y0 + 1) < (unsigned)H) ? iy - y0f : 0.0f;
+    t.w[0] = wx0 * wy0;
+    t.w[1] = wx1 * wy0;
+    t.w[2] = wx0 * wy1;
+    t.w[3] = wx1 * wy1;
+    // window-relative and clamped INTO the window (MODE 1: x_lo, y_lo, ww, wh describe it; MODE 0: the whole map): a no-op for every
+    // tap that carries weight, and zero-weight taps read finite staged data
+    const int xa = min(max(x0 - x_lo, 0), ww - 1), xb = min(max(x0 + 1 - x_lo, 0), ww - 1);
+    const int ra = min(max(y0 - y_lo, 0), wh - 1), rb = min(max(y0 + 1 - y_lo, 0), wh - 1);
+    if (MODE == 1) {
+        const unsigned ya = (unsigned)ra * (DYN_WIN_PX * C * 4), yb = (unsigned)rb * (DYN_WIN_PX * C * 4);
+        t.a[0] = ya + (unsigned)xa * (C * 4);
+        t.a[1] = ya + (unsigned)xb * (C * 4);
+        t.a[2] = yb + (unsigned)xa * (C * 4);
+        t.a[3] = yb + (unsigned)xb * (C * 4);
+    } else {
+        const int ya = __mul24(ra, ww), yb = __mul24(rb, ww);
+        t.a[0] = (unsigned)(ya + xa) * (C * 4);
+        t.a[1] = (unsigned)(ya + xb) * (C * 4);
+        t.a[2] = (unsigned)(yb + xa) * (C * 4);
+        t.a[3] = (unsigned)(yb + xb) * (C * 4);
+    }
+}
+
+typedef const __attribute__((address_space(1))) effi_f4* effi_gptr4;      // a pointer KNOWN to be global memory (global_load, not flat_load)
+typedef short effi_s16x2 __attribute__((ext_vector_type(2)));
+
+// one hypothesis of one view: sum_c ref[c] * bilinear(src[c]) with the taps from the LDS window (LDSWIN) or from the source map
+template <int MODE, int C>
+__device__ __forceinline__ float dyn_sample_hyp(const char* __restrict__ wb, effi_gptr4 sb, float ix, float iy, int w, int h,
+                                                int x_lo, int y_lo, int ww, int wh, const float4 (&r)[C / 4]) {
+    constexpr int Q = C / 4;
+    DynTaps t;
+    constexpr bool LDSWIN = MODE != 0;
+    make_taps_dyn<MODE, C>(ix, iy, w, h, x_lo, y_lo, ww, wh, t);
+    // taps in groups of KG (C = 16: two at a time -- 32 instead of 64 registers of tap data in flight; the other waves hide the latency)
+    constexpr int KG = (Q > 2) ? 2 : 4;
+    float sd = 0.0f;
+#pragma unroll
+    for (int k0 = 0; k0 < 4; k0 += KG) {
+        effi_f4 tv[KG][Q];
+#pragma unroll
+        for (int k = 0; k < KG; ++k)
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                tv[k][q] = LDSWIN ? *reinterpret_cast<const effi_f4*>(wb + t.a[k0 + k] + 16 * q) : sb[(t.a[k0 + k] >> 4) + q];
+#pragma unroll
+        for (int k = 0; k < KG; ++k) {
+            const float dk = dyn_dot<Q>(tv[k], r);
+            sd = (k0 + k == 0) ? t.w[0] * dk : fmaf(t.w[k0 + k], dk, sd);
+        }
+        if (KG < 4) __builtin_amdgcn_sched_barrier(0);
+    }
+    return sd;
+}
+
+template <int C, int HPL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 8 ? 4 : 3, C == 8 ? 4 : 3))) void warpcorr_dyn_win_kernel(
+    const float* ref_arg, EffiPtrList srcs, int S, const float* __restrict__ rt_all, const float* __restrict__ cur_depth,
+    const float* __restrict__ interval, const float* __restrict__ view_w, int vw_shift, int h, int w, int D, float* __restrict__ sim,
+    float* __restrict__ samples, int lds_px) {
+    using G = WarpGeom<C>;
+    constexpr int LPP = G::LPP, Q = C / 4;
+    constexpr int PITCH = DYN_WIN_PX * Q, PARTS = PITCH / 64;   // float4 per image row; wave-instructions of the copy per row
+    constexpr int ROWS = (C == 8) ? 16 : 12;                     // 16 / 24 KB per image, two images: four / three workgroups per CU (as the registers allow)
+    constexpr int MAXW = DYN_WIN_PX;
+    __shared__ effi_f4 win[2][ROWS * PITCH];
+    __shared__ int bbw[EFFI_MAX_VIEWS][4][2];                // per view and wave: packed (min x, min y), (max x, max y) of the tap pixels
+    const float* __restrict__ ref = effi_resolve_views(ref_arg, srcs);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wvi = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave index as a SCALAR: window rows / LDS bases of the copy are then scalar arithmetic
+    const int tiles_x = (w + G::TW - 1) / G::TW;
+    const int tl = effi_xcd_remap(blockIdx.x, gridDim.x);
+    const int tyi = tl / tiles_x, txi = tl - tyi * tiles_x;
+    const int g = tid / LPP, sub = tid % LPP;
+    const int x = txi * G::TW + (g % G::TW), y = tyi * G::TH + (g / G::TW);
+    const bool valid = (x < w) & (y < h);
+    const int xs = min(x, w - 1), ys = min(y, h - 1);          // out-of-image lanes shadow the border pixel (no stores)
+    const int hw = h * w, pix = ys * w + xs;
+    float4 r[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) r[q] = *reinterpret_cast<const float4*>(ref + (long)pix * C + 4 * q);
+    const float fx = (float)xs, fy = (float)ys;
+    const float inv = 1.0f / cur_depth[pix];
+    const float half = (float)(D / 2) * interval[0];
+    const float smin = fmaxf(inv - half, 1e-4f);
+    const float smax = fminf(fmaxf(inv + half, 1e-4f), 1e4f);
+    const float step = (smax - smin) / (float)(D - 1);
+    const int vh = h >> vw_shift, vw = w >> vw_shift;
+    const int vpix = (ys >> vw_shift) * vw + (xs >> vw_shift);
+    float wsum = 0.0f;
+    for (int v = 0; v < S; ++v) wsum = wsum + view_w[(long)v * vh * vw + vpix];
+    const float den = wsum + 1e-6f;
+    const float wm1 = (float)(w - 1), hm1 = (float)(h - 1);
+    const float hw2 = wm1 / 2.0f, hh2 = hm1 / 2.0f;
+    const float rhw2 = 1.0f / hw2, rhh2 = 1.0f / hh2;
+    float dep[HPL], acc[HPL];
+#pragma unroll
+    for (int j = 0; j < HPL; ++j) {                             // lane `sub` owns d = sub, sub + LPP, ... (beyond D: a shadow of D - 1)
+        dep[j] = 1.0f / fmaxf(smin + (float)min(sub + j * LPP, D - 1) * step, 1e-5f);
+        acc[j] = 0.0f;
+    }
+
+    // set-ups of one view for this lane's hypotheses + the wave's share of the view's bounding box
+    auto setup = [&](int v, float (&ix)[HPL], float (&iy)[HPL]) {
+        const float* __restrict__ rt = rt_all + v * 12;
+        const float rx = rt[0] * fx + rt[1] * fy + rt[2];
+        const float ry = rt[3] * fx + rt[4] * fy + rt[5];
+        const float rz = rt[6] * fx + rt[7] * fy + rt[8];
+        float mnx = 0.0f, mxx = 0.0f, mny = 0.0f, mxy = 0.0f;
+#pragma unroll
+        for (int j = 0; j < HPL; ++j) {
+            project_xy(rx * dep[j] + rt[9], ry * dep[j] + rt[10], rz * dep[j] + rt[11], hw2, rhw2, hh2, rhh2, wm1, hm1, ix[j], iy[j]);
+            ix[j] = fminf(fmaxf(ix[j], -2.0f), (float)w + 1.0f);       // make_taps_win's neutral clamp; NaN -> outside
+            iy[j] = fminf(fmaxf(iy[j], -2.0f), (float)h + 1.0f);
+            mnx = j ? fminf(mnx, ix[j]) : ix[j]; mxx = j ? fmaxf(mxx, ix[j]) : ix[j];
+            mny = j ? fminf(mny, iy[j]) : iy[j]; mxy = j ? fmaxf(mxy, iy[j]) : iy[j];
+        }
+        // tap pixels are floor(.) and floor(.) + 1; coordinates lie in [-2, 32767) (the launch checks the map size): 16-bit pairs
+        effi_s16x2 lo = {(short)(int)floorf(mnx), (short)(int)floorf(mny)};
+        effi_s16x2 hi = {(short)((int)floorf(mxx) + 1), (short)((int)floorf(mxy) + 1)};
+        // inside a row of 16 lanes: four DPP moves (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: full-rate, no LDS round
+        // trip); across the four rows: two shuffles
+#define EFFI_BOX_STEP(MOVE)                                                                                              \
+        {                                                                                                                \
+            const int lo_i = __builtin_bit_cast(int, lo), hi_i = __builtin_bit_cast(int, hi);                           \
+            const int lo_o = MOVE(lo_i), hi_o = MOVE(hi_i);                                                              \
+            lo = __builtin_elementwise_min(lo, __builtin_bit_cast(effi_s16x2, lo_o));                                    \
+            hi = __builtin_elementwise_max(hi, __builtin_bit_cast(effi_s16x2, hi_o));                                    \
+        }
+#define EFFI_DPP_B1(v) __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true)
+#define EFFI_DPP_4E(v) __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true)
+#define EFFI_DPP_141(v) __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true)
+#define EFFI_DPP_140(v) __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true)
+#define EFFI_SHFL_16(v) __shfl_xor(v, 16)
+#define EFFI_SHFL_32(v) __shfl_xor(v, 32)
+        EFFI_BOX_STEP(EFFI_DPP_B1)
+        EFFI_BOX_STEP(EFFI_DPP_4E)
+        EFFI_BOX_STEP(EFFI_DPP_141)
+        EFFI_BOX_STEP(EFFI_DPP_140)
+        EFFI_BOX_STEP(EFFI_SHFL_16)
+        EFFI_BOX_STEP(EFFI_SHFL_32)
+#undef EFFI_BOX_STEP
+#undef EFFI_DPP_B1
+#undef EFFI_DPP_4E
+#undef EFFI_DPP_141
+#undef EFFI_DPP_140
+#undef EFFI_SHFL_16
+#undef EFFI_SHFL_32
+        if (lane == 0) {
+            bbw[v][wvi][0] = __builtin_bit_cast(int, lo);
+            bbw[v][wvi][1] = __builtin_bit_cast(int, hi);
+        }
+    };
+    // the window of a view (uniform): the box clipped to the image, or ww = 0 when it does not fit the LDS image
+    struct Win { int x_lo, y_lo, ww, wh, interior; };
+    auto window_of = [&](int v) {
+        effi_s16x2 lo = __builtin_bit_cast(effi_s16x2, bbw[v][0][0]), hi = __builtin_bit_cast(effi_s16x2, bbw[v][0][1]);
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            lo = __builtin_elementwise_min(lo, __builtin_bit_cast(effi_s16x2, bbw[v][k][0]));
+            hi = __builtin_elementwise_max(hi, __builtin_bit_cast(effi_s16x2, bbw[v][k][1]));
+        }
+        const int lo_u = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lo));
+        const int hi_u = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, hi));
+        Win W_;
+        const int x_lo = min(max((int)(short)(lo_u & 0xffff), 0), w - 1);
+        const int x_hi = max(min((int)(short)(hi_u & 0xffff), w - 1), x_lo);
+        const int y_lo = min(max(lo_u >> 16, 0), h - 1);
+        const int y_hi = max(min(hi_u >> 16, h - 1), y_lo);
+        W_.x_lo = x_lo; W_.y_lo = y_lo; W_.ww = x_hi - x_lo + 1; W_.wh = y_hi - y_lo + 1;
+        // interior: the unclipped box of the tap pixels lies inside the image (every tap is a real pixel of the window)
+        W_.interior = ((int)(short)(lo_u & 0xffff) >= 0) & ((lo_u >> 16) >= 0) & ((int)(short)(hi_u & 0xffff) <= w - 1) & ((hi_u >> 16) <= h - 1);
+        if (W_.ww > MAXW || W_.wh > ROWS || W_.ww * W_.wh > lds_px) W_.ww = 0;
+        return W_;
+    };
+    // window copy: global -> LDS directly (global_load_lds_dwordx4: no registers, no ds_write pass).  Wave k copies rows k, k + 4, ...:
+    // one wave-instruction per row -- lane i reads float4 min(i, ww Q - 1) of the row and lands in slot i of the row's 64.  The copy
+    // is drained by the next barrier (vmcnt(0)); no ordinary vector load is consumed while it is in flight (the view's weight and base
+    // pointer are fetched with the set-ups).
+    auto stage = [&](const float* __restrict__ src, int buf, const Win& W_) {
+        if (W_.ww == 0) return;
+        const effi_gptr4 gsrc = (effi_gptr4)(src + ((long)W_.y_lo * w + W_.x_lo) * C);
+        const int n4 = W_.ww * Q;
+#pragma unroll
+        for (int j = 0; j < (ROWS * PARTS + 3) / 4; ++j) {
+            const int item = wvi + 4 * j, row = item / PARTS, part = item % PARTS;     // (scalar arithmetic)
+            if (row >= W_.wh) break;                             // wave-uniform
+            if (part * 64 >= n4) continue;
+            __builtin_amdgcn_global_load_lds(gsrc + ((long)row * w * Q + min(part * 64 + lane, n4 - 1)),
+                                             (__attribute__((address_space(3))) effi_f4*)(&win[buf][row * PITCH + part * 64]), 16, 0, 0);
+        }
+    };
+    auto sample = [&](const float* __restrict__ src, float wv, int buf, const Win& W_, const float (&ix)[HPL], const float (&iy)[HPL]) {
+        const char* __restrict__ wb = reinterpret_cast<const char*>(win[buf]);
+        const effi_gptr4 sb = (effi_gptr4)src;
+        // one hypothesis at a time (sched_barrier: the scheduler otherwise hoists the tap reads of all HPL hypotheses to the top --
+        // 128 registers of tap data at C = 8); the uniform window / global choice is the OUTER branch
+        if (W_.ww != 0 && W_.interior) {
+#pragma unroll
+            for (int j = 0; j < HPL; ++j) {
+                acc[j] = fmaf(wv, dyn_sample_hyp<2, C>(wb, sb, ix[j], iy[j], w, h, W_.x_lo, W_.y_lo, W_.ww, W_.wh, r), acc[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if (W_.ww != 0) {
+#pragma unroll
+            for (int j = 0; j < HPL; ++j) {
+                acc[j] = fmaf(wv, dyn_sample_hyp<1, C>(wb, sb, ix[j], iy[j], w, h, W_.x_lo, W_.y_lo, W_.ww, W_.wh, r), acc[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < HPL; ++j) {
+                acc[j] = fmaf(wv, dyn_sample_hyp<0, C>(wb, sb, ix[j], iy[j], w, h, 0, 0, w, h, r), acc[j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    float ixc[HPL], iyc[HPL], ixn[HPL], iyn[HPL];
+    setup(0, ixc, iyc);
+    const float* srcc = pick_view(srcs, 0);
+    const float* srcn = srcc;
+    float wvc = view_w[vpix], wvn = wvc;
+    __syncthreads();                                             // the waves' boxes of view 0
+    Win wc = window_of(0), wn = wc;
+    stage(srcc, 0, wc);
+    for (int v = 0; v < S; ++v) {
+        const bool more = v + 1 < S;
+        if (more) {
+            setup(v + 1, ixn, iyn);
+            srcn = pick_view(srcs, v + 1);
+            wvn = view_w[(long)(v + 1) * vh * vw + vpix];
+        }
+        // This wave's share of window v must have LANDED before the barrier lets other waves read it.  The compiler's fence in front
+        // of the barrier does not wait for the LDS-DMA by itself (seen in the ISA: lgkmcnt(0) only, when no ordinary load happened to
+        // be outstanding): explicit vmcnt(0).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();             // window v has landed, the boxes of v + 1 are stored, nobody samples image (v + 1) & 1 any more
+        if (more) {
+            wn = window_of(v + 1);
+            stage(srcn, (v + 1) & 1, wn);
+        }
+        sample(srcc, wvc, v & 1, wc, ixc, iyc);
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < HPL; ++j) { ixc[j] = ixn[j]; iyc[j] = iyn[j]; }
+            wc = wn; srcc = srcn; wvc = wvn;
+        }
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int j = 0; j < HPL; ++j) {
+        const int d = sub + j * LPP;
+        if (d < D) {
+            sim[(long)d * hw + pix] = (acc[j] / (float)C) / den;
+            samples[(long)d * hw + pix] = dep[j];
+        }
     }
 }
 
@@ -1288,6 +1604,21 @@ static int launch_warpcorr_dyn(const float* ref_nhwc, const EffiPtrList& l, int 
     const bool lanes = effi_option(EFFI_OPT_DYN_FORM) == 1;
     const bool exact = effi_option(EFFI_OPT_DYN_SETUP_EXACT) == 1;
     if (!exact && !lanes && (C == 8 || C == 16) && (long)h * w * C * 4 < (1L << 31)) {
+        // LDS-window form (warpcorr_dyn_win_kernel): D <= 8 (a lane holds the set-ups of its 4 / 2 hypotheses for two views);
+        // option dyn_win: -1 = the gather kernel below, 0 = the window kernel with every view sampled from global memory
+        const long dw = effi_option(EFFI_OPT_DYN_WIN);
+        if (dw != -1 && D <= 8 && S <= EFFI_MAX_VIEWS && h < 32000 && w < 32000) {
+            // option value n > 0: windows of at most n pixels (tests: most boxes then overflow and mix with LDS-served views)
+            const int lds_px = dw == EFFI_OPT_UNSET ? (1 << 20) : (int)max(dw, 0L);
+            if (C == 8)
+                hipLaunchKernelGGL((warpcorr_dyn_win_kernel<8, 4>), dim3(grid_blocks<8>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth,
+                                   interval, view_w, vw_shift, h, w, D, sim, samples, lds_px);
+            else
+                hipLaunchKernelGGL((warpcorr_dyn_win_kernel<16, 2>), dim3(grid_blocks<16>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt,
+                                   cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples, lds_px);
+            EFFI_LAUNCH_CHECK();
+            return EFFI_OK;
+        }
         if (C == 8) hipLaunchKernelGGL(warpcorr_dyn_hyp_kernel<8>, dim3(grid_blocks<8>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples);
         else hipLaunchKernelGGL(warpcorr_dyn_hyp_kernel<16>, dim3(grid_blocks<16>(h, w)), dim3(256), 0, s, ref_nhwc, l, S, rt, cur_depth, interval, view_w, vw_shift, h, w, D, sim, samples);
         EFFI_LAUNCH_CHECK();

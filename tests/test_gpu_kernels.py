@@ -642,6 +642,48 @@ def test_getcost_initvolume_kernel_forms_agree(model):
         assert diff <= 2e-5 * max(peak, 1.0), (name, diff, peak)
 
 
+@pytest.mark.parametrize("C,h,w,S,D", [(8, 74, 100, 4, 8), (16, 37, 50, 4, 8), (8, 64, 96, 1, 8), (16, 70, 90, 6, 8), (8, 33, 47, 10, 6),
+                                        (16, 24, 40, 3, 4)])
+def test_warpcorr_dyn_window_form_is_bitwise_the_gather_form(C, h, w, S, D):
+    """Round 4: the stage-2/3 warp + correlation serves its taps from an LDS window per (tile, view) (warpcorr_dyn_win_kernel, the
+    default for C = 8 / 16, D <= 8) instead of gathering them through the L1.  Same arithmetic in the same order: the similarities
+    are BITWISE those of the gather kernel (option dyn_win = -1) -- with the full window, with a window too small for most tiles
+    (dyn_win = 48: views of one tile mix LDS and global sampling), with none (dyn_win = 0), on smooth depth (every window fits) and
+    on noisy depth with jumps (boxes overflow), on maps that are not multiples of the tile, from 1 to 10 source views."""
+    from effi_mvs_plus_amd import ops
+    N = S + 1
+    pm = synth.synth_cameras(8 * h, 8 * w, N)["stage3"][0]      # the ring of cameras; intrinsics set for THIS map below
+    feats = synth.smooth_features(N, C, h, w, seed=11)
+    nhwc = ops.to_nhwc([f[0].to(DEV).contiguous() for f in feats])
+    pmd = pm.clone()
+    pmd[:, 1, 0, 0] = pmd[:, 1, 1, 1] = 1.1 * w
+    pmd[:, 1, 0, 2], pmd[:, 1, 1, 2] = w / 2.0, h / 2.0
+    rt = ops.compose_rel_proj(pmd.to(DEV).contiguous())
+    g = torch.Generator().manual_seed(5)
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    smooth = 600.0 + 40.0 * torch.sin(xs / 17.0) + 30.0 * torch.cos(ys / 11.0)
+    noisy = smooth + 25.0 * torch.randn(h, w, generator=g)
+    noisy[h // 3: h // 3 + 5, :] = 430.0                        # a depth jump through tiles
+    noisy[:, w // 2] = 930.0
+    vh, vw = (h // 2, w // 2) if h % 2 == 0 and w % 2 == 0 else (h, w)
+    vweights = (0.2 + torch.rand(S, vh, vw, generator=g)).to(DEV)
+    itv = torch.tensor([2.0e-5], device=DEV)
+    for name, cur in (("smooth", smooth), ("noisy", noisy)):
+        cur = cur.to(DEV).contiguous()
+        out = {}
+        for tag, val in (("gather", -1), ("window", None), ("window48", 48), ("window0", 0)):
+            with ops.options(dyn_win=val):
+                sim, smp = ops.warpcorr_dyn(nhwc[0], nhwc[1:], rt, cur, itv, vweights, D)
+                torch.cuda.synchronize()
+            out[tag] = (sim.clone(), smp.clone())
+            assert torch.isfinite(sim).all()
+        assert float(out["gather"][0].abs().max()) > 1e-3
+        for tag in ("window", "window48", "window0"):
+            nd = int((out[tag][0] != out["gather"][0]).sum())
+            assert nd == 0, f"{name}: {tag} differs from the gather kernel in {nd} similarities"
+            assert torch.equal(out[tag][1], out["gather"][1]), f"{name}: {tag} hypotheses differ"
+
+
 # ---------------------------------------------------------------------------------------------
 # GRU update block
 # ---------------------------------------------------------------------------------------------
