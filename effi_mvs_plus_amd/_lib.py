@@ -32,6 +32,8 @@ SIGNATURES = {
     "effi_homo_warp_f32": [_vp, _vp, _vp, _l, _l, _i, _i, _i, _i, _vp, _vp],
     "effi_warpcorr_views_f32": [_vp, _vp, _i, _vp, _vp, _l, _l, _i, _i, _i, _i, _vp, _vp, _vp],
     "effi_warpcorr_views_tbl_f32": [_vp, _i, _vp, _vp, _l, _l, _i, _i, _i, _i, _vp, _vp, _vp],
+    "effi_warpcorr_views_x3_f32": [_vp, _vp, _i, _vp, _vp, _l, _l, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    "effi_warpcorr_views_x3_tbl_f32": [_vp, _i, _vp, _vp, _l, _l, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "effi_warpcorr_dyn_tbl_f32": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "effi_view_table_set": [_vp, _vp, _i, _vp],
     "effi_pixelwise_net_f32": [_vp, _vp, _i, _i, _i, _vp, _vp],

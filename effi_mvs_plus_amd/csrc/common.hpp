@@ -146,15 +146,40 @@ __device__ __forceinline__ float effi_depth_to_inv(float depth, float lo, float 
     return (s_ - min_disp) / den;
 }
 
+// Divisions of the volume look-ups (lookup1d_index, effi_getcost_pixel): a refined reciprocal (v_rcp_f32 + one Newton step, <= 1 ulp) and,
+// for a quotient, one residual step on top -- 3 / 6 instructions instead of the ~11 of the IEEE sequence, correctly rounded except for
+// rare 1-ulp cases of CONTINUOUS functions of the query depth (linear interpolation has no jumps), as the warp kernels' projection
+// (warpcorr.hip, project_xy).  The generated-input convolution spends 660 instructions per staged pixel in this prologue, 23 IEEE
+// divisions among them.  -DEFFI_EXACT_LOOKUP restores the IEEE divisions (A/B builds).  The maps the path RETURNS
+// (effi_inv_to_depth / effi_depth_to_inv) keep their IEEE divisions.
+__device__ __forceinline__ float effi_lk_rcp(float b) {
+#ifdef EFFI_EXACT_LOOKUP
+    return 1.0f / b;
+#else
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    return fmaf(fmaf(-b, r0, 1.0f), r0, r0);
+#endif
+}
+__device__ __forceinline__ float effi_lk_div(float a, float b, float rb) {      // a / b given rb = effi_lk_rcp(b)
+#ifdef EFFI_EXACT_LOOKUP
+    (void)rb;
+    return a / b;
+#else
+    const float q = a * rb;
+    return fmaf(fmaf(-q, b, a), rb, q);
+#endif
+}
+
 // the sampling position of a query in a Dp-long vector: first tap x0 and the two weights (the arithmetic depends on Dp, not on the volume)
 __device__ __forceinline__ void lookup1d_index(int Dp, float q_depth, float dmin, float dmax, int& x0, float& w0, float& w1) {
-    const float scaled = 1.0f / q_depth;                               // depth_to_disp, :156-164
-    const float min_disp = 1.0f / dmax, max_disp = 1.0f / dmin;
-    const float disp = (scaled - min_disp) / ((max_disp - min_disp) + 1e-10f);
+    const float scaled = effi_lk_rcp(q_depth);                          // depth_to_disp, :156-164
+    const float min_disp = effi_lk_rcp(dmax), max_disp = effi_lk_rcp(dmin);
+    const float den = (max_disp - min_disp) + 1e-10f;
+    const float disp = effi_lk_div(scaled - min_disp, den, effi_lk_rcp(den));
     const float dm1 = (float)(Dp - 1);
     const float t = disp * dm1;                                        // :123
-    const float g = 2.0f * t / dm1 - 1.0f;                             // :107
-    float ix = ((g + 1.0f) / 2.0f) * dm1;                              // grid_sample, align_corners=True
+    const float g = effi_lk_div(2.0f * t, dm1, effi_lk_rcp(dm1)) - 1.0f;   // :107
+    float ix = ((g + 1.0f) * 0.5f) * dm1;                              // grid_sample, align_corners=True (x / 2 = x * 0.5 exactly)
     ix = fminf(fmaxf(ix, -2.0f), dm1 + 2.0f);                          // neutral: both taps stay out of range
     const float x0f = floorf(ix);
     x0 = (int)x0f;
@@ -177,7 +202,7 @@ __device__ __forceinline__ void effi_getcost_pixel(float inv_or_depth, int input
                                                    const float* __restrict__ reg, long rds, int Dreg, float rlo, float rhi, float (&cost)[2 * NQ]) {
     float depth = inv_or_depth;
     if (!input_is_depth) depth = effi_inv_to_depth(depth, disp_range[0], disp_range[n_range - 1]);
-    const float dv = 1.0f / depth;
+    const float dv = effi_lk_rcp(depth);
     const float half = (float)(NQ / 2) * itv;
     const float smin = fmaxf(dv - half, 1e-4f);
     const float smax = fminf(fmaxf(dv + half, 1e-4f), 1e4f);
@@ -185,7 +210,7 @@ __device__ __forceinline__ void effi_getcost_pixel(float inv_or_depth, int input
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {
         const float s = fmaxf(smin + (float)k * step, 1e-5f);
-        const float qd = 1.0f / s;
+        const float qd = effi_lk_rcp(s);
         // both volumes of a stage are equally long on the path: one position per query serves both (bitwise the same values)
         int x0;
         float w0, w1;

@@ -406,17 +406,10 @@ __global__ __launch_bounds__(TPB) void pointwise_kernel(int op, PwArgs p) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void lookup1d_bwd(float* __restrict__ gvol, long dstride, int Dp, float q_depth, float dmin, float dmax,
                                              float g) {
-    const float scaled = 1.0f / q_depth;
-    const float min_disp = 1.0f / dmax, max_disp = 1.0f / dmin;
-    const float disp = (scaled - min_disp) / ((max_disp - min_disp) + 1e-10f);
-    const float dm1 = (float)(Dp - 1);
-    const float t = disp * dm1;
-    const float gg = 2.0f * t / dm1 - 1.0f;
-    float ix = ((gg + 1.0f) / 2.0f) * dm1;
-    ix = fminf(fmaxf(ix, -2.0f), dm1 + 2.0f);
-    const float x0f = floorf(ix);
-    const int x0 = (int)x0f;
-    const float w1 = ix - x0f, w0 = (x0f + 1.0f) - ix;
+    // the forward's position and weights (common.hpp: one arithmetic for both passes)
+    int x0;
+    float w0, w1;
+    lookup1d_index(Dp, q_depth, dmin, dmax, x0, w0, w1);
     if (x0 >= 0 && x0 <= Dp - 1) gvol[x0 * dstride] += g * w0;
     if (x0 + 1 >= 0 && x0 + 1 <= Dp - 1) gvol[(x0 + 1) * dstride] += g * w1;
 }
@@ -443,7 +436,7 @@ __global__ void getcost_bwd_kernel(const float* __restrict__ inv_depth, const fl
     const float itv = interval[0];
     float depth = inv_depth[p];
     if (!input_is_depth) depth = effi_inv_to_depth(depth, disp_range[0], disp_range[n_range - 1]);
-    const float dv = 1.0f / depth;
+    const float dv = effi_lk_rcp(depth);                      // as effi_getcost_pixel (common.hpp)
     const float half = (float)(nq / 2) * itv;
     const float smin = fmaxf(dv - half, 1e-4f);
     const float smax = fminf(fmaxf(dv + half, 1e-4f), 1e4f);
@@ -451,7 +444,7 @@ __global__ void getcost_bwd_kernel(const float* __restrict__ inv_depth, const fl
     const float rlo = dmin[p * range_ps], rhi = dmax[p * range_ps];
     for (int k = 0; k < nq; ++k) {
         const float s = fmaxf(smin + (float)k * step, 1e-5f);
-        const float qd = 1.0f / s;
+        const float qd = effi_lk_rcp(s);
         lookup1d_bwd(gcur + p * cps, cds, Dcur, qd, rlo, rhi, gcost[(long)k * hw + p]);
         lookup1d_bwd(greg + p * rps_, rds, Dreg, qd, rlo, rhi, gcost[(long)(nq + k) * hw + p]);
     }

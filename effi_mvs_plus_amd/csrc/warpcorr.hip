@@ -225,6 +225,9 @@ __global__ __launch_bounds__(256) void warpcorr_views_kernel(const float* ref_ar
 // the coordinate (bilinear sampling with zeros padding has no jumps), far inside the kernel tolerance.
 // ------------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float effi_f4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) effi_f4* effi_gptr4;      // a pointer KNOWN to be global memory (global_load, not flat_load)
+typedef short effi_s16x2 __attribute__((ext_vector_type(2)));
 
 struct WinTaps {
     float w[4];
@@ -543,6 +546,262 @@ __global__ __launch_bounds__(WIN_THREADS) __attribute__((amdgpu_waves_per_eu(4, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// stage 1 in SPLIT precision, CORRELATE FIRST (round 4; C = 32, hypotheses shared by all pixels, precision "split" / "bf16" only --
+// the exact-fp32 mode and training keep the kernel above).  BUILT, CORRECT (tests/test_gpu_kernels.py::test_warpcorr_views_matrix_core_form),
+// AND SLOWER THAN THE WINDOW KERNEL: 147 vs 93 us at 148x200, D = 48, S = 4 -- NOT the default (Python option warp_x3 = 1 selects it).
+// Why: the box of a chunk is dominated by the 16-pixel width of the row segment, not by the chunk's disparity
+// spread, so every chunk re-reads and re-splits almost the same source pixels (36-96 blocks of 16 x 16 per row segment and view
+// instead of the ~10 one box over all hypotheses would need -- which does not fit the LDS region once the epipolar line is slanted);
+// the per-block split (24 instructions) then costs as much per hypothesis as the window kernel's blend.  What it would take: source
+// features split to bf16 hi / lo once per image, and a sheared box that follows the epipolar line.  Correlation is linear in the warped feature:
+//     sum_c ref[c] * (sum_k w_k src[tap_k][c])  =  sum_k w_k * (sum_c ref[c] * src[tap_k][c])  =  sum_k w_k G[p][tap_k],
+// and the 192 taps of a pixel's 48 hypotheses in one view lie on one short epipolar segment whose ~100 distinct source pixels are
+// shared with the pixel's neighbours.  So a wave takes a row segment of 16 reference pixels and, per chunk of 16 hypotheses:
+//   A. every lane (pixel p = lane & 15, hypothesis slot lane >> 4) projects its four hypotheses (the arithmetic of the kernel above);
+//      the wave reduces the bounding box of the tap pixels (packed 16-bit min / max: DPP inside a row of lanes, shuffles across);
+//   B. G[16 reference pixels][box pixels] on the matrix cores: per 16 box pixels of one source row ONE coalesced 2-KB read (a lane
+//      fetches 8 consecutive channels of one pixel: 16 pixels x 128 B contiguous in the channel-last map), split into bf16 hi + lo
+//      in registers, and three v_mfma_f32_16x16x32_bf16 (hi*hi + lo*hi + hi*lo, K = 32 = all channels, fp32 accumulation: the
+//      precision of the path's convolutions); the 16 x 16 block goes to the wave's own LDS region -- no source window in LDS at all;
+//   C. a hypothesis is then 4 LDS dwords and 4 FMAs.
+// Per (pixel, hypothesis, view) this is ~75 vector instructions and 16 LDS bytes against ~366 instructions and 512 LDS bytes of the
+// window kernel.  A chunk whose box does not fit the wave's LDS region (a steep epipolar line: extreme geometry) is evaluated
+// directly from global memory (blend of the four taps, then the product -- fp32).  No workgroup barrier inside the chunk loop: the
+// four waves of a workgroup only share the hypothesis table.
+// ------------------------------------------------------------------------------------------------
+constexpr int MM_NQ = 144;             // box pixels per wave and chunk (16 x 145 floats = 9.3 KB per wave: four workgroups per CU)
+constexpr int MM_CH = 16;              // hypotheses per full chunk (four per lane); a chunk shrinks to 8 / 4 when its box does not fit
+
+__device__ __forceinline__ int mm_dpp_min16(int v, int o) { effi_s16x2 a = __builtin_bit_cast(effi_s16x2, v), b = __builtin_bit_cast(effi_s16x2, o); return __builtin_bit_cast(int, __builtin_elementwise_min(a, b)); }
+__device__ __forceinline__ int mm_dpp_max16(int v, int o) { effi_s16x2 a = __builtin_bit_cast(effi_s16x2, v), b = __builtin_bit_cast(effi_s16x2, o); return __builtin_bit_cast(int, __builtin_elementwise_max(a, b)); }
+// wave-wide minimum / maximum of two packed 16-bit pairs (every lane receives the result)
+__device__ __forceinline__ void mm_wave_box(int& lo, int& hi) {
+#define EFFI_MM_STEP(MOVE) { const int lo_o = MOVE(lo), hi_o = MOVE(hi); lo = mm_dpp_min16(lo, lo_o); hi = mm_dpp_max16(hi, hi_o); }
+#define EFFI_MM_B1(v) __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true)
+#define EFFI_MM_4E(v) __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true)
+#define EFFI_MM_141(v) __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true)
+#define EFFI_MM_140(v) __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true)
+#define EFFI_MM_S16(v) __shfl_xor(v, 16)
+#define EFFI_MM_S32(v) __shfl_xor(v, 32)
+    EFFI_MM_STEP(EFFI_MM_B1) EFFI_MM_STEP(EFFI_MM_4E) EFFI_MM_STEP(EFFI_MM_141) EFFI_MM_STEP(EFFI_MM_140) EFFI_MM_STEP(EFFI_MM_S16) EFFI_MM_STEP(EFFI_MM_S32)
+#undef EFFI_MM_STEP
+#undef EFFI_MM_B1
+#undef EFFI_MM_4E
+#undef EFFI_MM_141
+#undef EFFI_MM_140
+#undef EFFI_MM_S16
+#undef EFFI_MM_S32
+}
+
+typedef __bf16 mm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 mm_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mm_split8(const effi_f4& a, const effi_f4& b, mm_bf16x8& hi, mm_bf16x8& lo) {
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        const f32x2 v = {x[e], x[e + 1]};
+        const mm_bf16x2 h2 = __builtin_convertvector(v, mm_bf16x2);
+        const mm_bf16x2 l2 = __builtin_convertvector(v - __builtin_convertvector(h2, f32x2), mm_bf16x2);
+        hi[e] = h2[0]; hi[e + 1] = h2[1];
+        lo[e] = l2[0]; lo[e + 1] = l2[1];
+    }
+}
+
+template <bool HI_ONLY>
+__device__ __forceinline__ void warpcorr_views_mm_body(const float* __restrict__ ref, const float* __restrict__ src,
+                                                       const float* __restrict__ rt_all, const float* __restrict__ depth, long dds,
+                                                       int h, int w, int D, float* sim_views, float* __restrict__ entropy) {
+    constexpr int C = 32, MAXD = 256, GS = MM_NQ + 1;                // G row stride per reference pixel (odd: bank spread)
+    __shared__ float gbuf[4][16 * GS];
+    __shared__ float hyp[MAXD + MM_CH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wvi = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int tiles_x = (w + 15) / 16;
+    const int tl = effi_xcd_remap(blockIdx.x, gridDim.x);
+    const int tyi = tl / tiles_x, txi = tl - tyi * tiles_x;
+    const int x = txi * 16 + li, y = tyi * 4 + wvi;
+    const bool valid = (x < w) & (y < h);
+    const int xs = min(x, w - 1), ys = min(y, h - 1);          // out-of-image lanes shadow the border pixel (no stores)
+    const int view = blockIdx.y;
+    const float* __restrict__ rt = rt_all + view * 12;
+    const int hw = h * w, pix = ys * w + xs;
+    for (int d = tid; d < ((D + MM_CH - 1) / MM_CH) * MM_CH; d += 256) hyp[d] = depth[(long)min(d, D - 1) * dds];
+    WinProj P;
+    {
+        const float fx = (float)xs, fy = (float)ys;
+        P.rx = rt[0] * fx + rt[1] * fy + rt[2];
+        P.ry = rt[3] * fx + rt[4] * fy + rt[5];
+        P.rz = rt[6] * fx + rt[7] * fy + rt[8];
+        P.tx = rt[9]; P.ty = rt[10]; P.tz = rt[11];
+        P.wm1 = (float)(w - 1); P.hm1 = (float)(h - 1);
+        P.hw2 = P.wm1 / 2.0f; P.hh2 = P.hm1 / 2.0f;
+        P.rhw2 = 1.0f / P.hw2; P.rhh2 = 1.0f / P.hh2;
+    }
+    // A operand: this lane's reference pixel li, channels 8 lk .. 8 lk + 7, as bf16 hi + lo
+    mm_bf16x8 rh, rl;
+    {
+        const effi_f4* rp = reinterpret_cast<const effi_f4*>(ref + (long)pix * C + 8 * lk);
+        mm_split8(rp[0], rp[1], rh, rl);
+    }
+    float* simv = sim_views + (long)view * D * hw + pix;
+    float* G = gbuf[wvi];
+    const effi_gptr4 sb4 = (effi_gptr4)src;
+    float m = -INFINITY;
+    __syncthreads();                                             // hyp[] visible (the only workgroup barrier)
+    constexpr int NG = MM_CH / 4, MAXB = MM_NQ / 16;              // hypothesis groups of a full chunk; 16 x 16 blocks of a full box
+    for (int d0 = 0; d0 < D;) {
+        // ---- A: positions of this lane's hypotheses d0 + 4 g + lk; the LONGEST prefix of groups whose box fits the wave's region
+        float ix[NG], iy[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const float dep = hyp[d0 + 4 * g + lk];                  // padded with the last hypothesis to a whole chunk
+            project_xy(P.rx * dep + P.tx, P.ry * dep + P.ty, P.rz * dep + P.tz, P.hw2, P.rhw2, P.hh2, P.rhh2, P.wm1, P.hm1, ix[g], iy[g]);
+            ix[g] = fminf(fmaxf(ix[g], -2.0f), (float)w + 1.0f);       // neutral clamp (make_taps); NaN -> outside
+            iy[g] = fminf(fmaxf(iy[g], -2.0f), (float)h + 1.0f);
+        }
+        int ng = min(NG, (D - d0 + 3) >> 2), x_lo = 0, y_lo = 0, nrows = 1, nb = 1;
+        bool fits = false;
+        for (;;) {
+            float mnx = ix[0], mxx = ix[0], mny = iy[0], mxy = iy[0];
+#pragma unroll
+            for (int g = 1; g < NG; ++g)
+                if (g < ng) { mnx = fminf(mnx, ix[g]); mxx = fmaxf(mxx, ix[g]); mny = fminf(mny, iy[g]); mxy = fmaxf(mxy, iy[g]); }
+            const effi_s16x2 lo2 = {(short)(int)floorf(mnx), (short)(int)floorf(mny)};
+            const effi_s16x2 hi2 = {(short)((int)floorf(mxx) + 1), (short)((int)floorf(mxy) + 1)};
+            int lo_i = __builtin_bit_cast(int, lo2), hi_i = __builtin_bit_cast(int, hi2);
+            mm_wave_box(lo_i, hi_i);
+            const int lo_u = __builtin_amdgcn_readfirstlane(lo_i), hi_u = __builtin_amdgcn_readfirstlane(hi_i);
+            x_lo = min(max((int)(short)(lo_u & 0xffff), 0), w - 1);
+            const int x_hi = max(min((int)(short)(hi_u & 0xffff), w - 1), x_lo);
+            y_lo = min(max(lo_u >> 16, 0), h - 1);
+            const int y_hi = max(min(hi_u >> 16, h - 1), y_lo);
+            nrows = y_hi - y_lo + 1;
+            nb = (x_hi - x_lo + 16) >> 4;
+            fits = nrows * nb <= MAXB;
+            if (fits || ng == 1) break;
+            ng >>= 1;                                                // (the positions of the dropped groups are set up again next round)
+        }
+        const int pitch = nb * 16;
+        if (fits) {
+            // ---- B: G[reference pixel][box pixel] = sum_c ref * src, 16 x 16 blocks on the matrix cores; ALL reads of the box first
+            effi_f4 s0[MAXB], s1[MAXB];
+            const int nblk = nrows * nb;
+            {
+                int r = 0, b = 0;
+#pragma unroll
+                for (int k = 0; k < MAXB; ++k) {
+                    if (k < nblk) {
+                        const int qx = min(x_lo + 16 * b + li, w - 1);   // beyond the box / the image: a finite value nobody weights
+                        const effi_gptr4 q = sb4 + ((long)(y_lo + r) * w + qx) * (C / 4) + 2 * lk;
+                        s0[k] = q[0];
+                        s1[k] = q[1];
+                    }
+                    if (++b == nb) { b = 0; ++r; }
+                }
+            }
+            {
+                int r = 0, b = 0;
+#pragma unroll
+                for (int k = 0; k < MAXB; ++k) {
+                    if (k < nblk) {
+                        mm_bf16x8 sh, sl;
+                        mm_split8(s0[k], s1[k], sh, sl);
+                        effi_f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh, sh, acc, 0, 0, 0);
+                        if (!HI_ONLY) {
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rl, sh, acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rh, sl, acc, 0, 0, 0);
+                        }
+                        float* gp = G + (4 * lk) * GS + r * pitch + 16 * b + li;       // D[reference pixel 4 lk + i][box pixel li]
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) gp[i * GS] = acc[i];
+                    }
+                    if (++b == nb) { b = 0; ++r; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        // ---- C: this lane's hypotheses of the accepted groups
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g >= ng) break;
+            const int d = d0 + 4 * g + lk;
+            const float x0f = floorf(ix[g]), y0f = floorf(iy[g]);
+            const int x0 = (int)x0f, y0 = (int)y0f;
+            const float wx0 = ((unsigned)x0 < (unsigned)w) ? (x0f + 1.0f) - ix[g] : 0.0f;
+            const float wx1 = ((unsigned)(x0 + 1) < (unsigned)w) ? ix[g] - x0f : 0.0f;
+            const float wy0 = ((unsigned)y0 < (unsigned)h) ? (y0f + 1.0f) - iy[g] : 0.0f;
+            const float wy1 = ((unsigned)(y0 + 1) < (unsigned)h) ? iy[g] - y0f : 0.0f;
+            const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
+            float sv;
+            if (fits) {
+                // clamped INTO the box: a no-op for every tap that carries weight
+                const int xa = min(max(x0 - x_lo, 0), pitch - 1), xb = min(max(x0 + 1 - x_lo, 0), pitch - 1);
+                const int ra = min(max(y0 - y_lo, 0), nrows - 1) * pitch, rb = min(max(y0 + 1 - y_lo, 0), nrows - 1) * pitch;
+                const float* gq = G + li * GS;
+                float a = w00 * gq[ra + xa];
+                a = fmaf(w01, gq[ra + xb], a);
+                a = fmaf(w10, gq[rb + xa], a);
+                a = fmaf(w11, gq[rb + xb], a);
+                sv = a * (1.0f / 32.0f);
+            } else {
+                // direct form (rare): blend the four taps, then the product with the reference features, all channels in this lane
+                const int xa = min(max(x0, 0), w - 1), xb = min(max(x0 + 1, 0), w - 1);
+                const int ya = min(max(y0, 0), h - 1) * w, yb = min(max(y0 + 1, 0), h - 1) * w;
+                const effi_gptr4 t0 = sb4 + (long)(ya + xa) * (C / 4), t1 = sb4 + (long)(ya + xb) * (C / 4);
+                const effi_gptr4 t2 = sb4 + (long)(yb + xa) * (C / 4), t3 = sb4 + (long)(yb + xb) * (C / 4);
+                const effi_f4* rq = reinterpret_cast<const effi_f4*>(ref + (long)pix * C);
+                float a = 0.0f;
+#pragma unroll 2
+                for (int q = 0; q < C / 4; ++q) {
+                    const effi_f4 v = w00 * t0[q] + w01 * t1[q] + w10 * t2[q] + w11 * t3[q];
+                    const effi_f4 rr = rq[q];
+                    a = fmaf(v.x, rr.x, a); a = fmaf(v.y, rr.y, a); a = fmaf(v.z, rr.z, a); a = fmaf(v.w, rr.w, a);
+                }
+                sv = a * (1.0f / 32.0f);
+            }
+            if (d < D) {
+                if (valid) simv[(long)d * hw] = sv;
+                m = fmaxf(m, sv);
+            }
+        }
+        if (fits) {                                              // G is rewritten by the next chunk
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        d0 += 4 * ng;
+    }
+    // ---- softmax over D and entropy (models/Effi_MVS_plus.py:43-44); lane slot lk owns (and wrote) d = lk, lk + 4, ...
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float z = 0.0f;
+    for (int d = lk; d < D; d += 4) z = z + expf((valid ? simv[(long)d * hw] : 0.0f) - m);
+    z = z + __shfl_xor(z, 16);
+    z = z + __shfl_xor(z, 32);
+    float e = 0.0f;
+    for (int d = lk; d < D; d += 4) {
+        const float p = expf((valid ? simv[(long)d * hw] : 0.0f) - m) / z;
+        e = e + (-p) * logf(p + 1e-7f);
+    }
+    e = e + __shfl_xor(e, 16);
+    e = e + __shfl_xor(e, 32);
+    if (valid && lk == 0) entropy[(long)view * hw + pix] = e;
+}
+
+template <bool TBL, bool HI_ONLY>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void warpcorr_views_mm_kernel(const float* __restrict__ ref_arg, EffiPtrList srcs,
+                                                                const float* __restrict__ rt_all, const float* __restrict__ depth,
+                                                                long dds, int h, int w, int D, float* sim_views,
+                                                                float* __restrict__ entropy) {
+    const int view = blockIdx.y;
+    warpcorr_views_mm_body<HI_ONLY>(TBL ? srcs.tbl[0] : ref_arg, TBL ? srcs.tbl[1 + view] : pick_view_list(srcs, view), rt_all, depth, dds,
+                                    h, w, D, sim_views, entropy);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Backward of the stage-1 warp + correlation with the scatter PRIVATISED in LDS (scope row n2): same tiles, chunks and windows as
 // warpcorr_views_win_kernel.  grad_src[tap][c] += g * w_tap * ref[c] is accumulated with LDS atomics (ds_add_f32) into a window of
 // the source-gradient map and flushed to global memory ONCE per (tile, chunk) -- 576 x 32 global atomics instead of
@@ -835,7 +1094,6 @@ __global__ __launch_bounds__(256) void warpcorr_dyn_kernel(const float* ref_arg,
 
 // sum_c tap[c] * ref[c] over C channels as TWO interleaved chains (even / odd channels) of packed FMAs (v_pk_fma_f32: C/2 instructions
 // + one add instead of C); used by the hypothesis-per-lane gather kernel and by the LDS-window kernel, which therefore agree bit for bit
-typedef float effi_f4 __attribute__((ext_vector_type(4)));
 template <int Q>
 __device__ __forceinline__ float dyn_dot(const effi_f4 (&tv)[Q], const float4 (&r)[Q]) {
     f32x2 a = f32x2{tv[0].x, tv[0].y} * f32x2{r[0].x, r[0].y};
@@ -987,8 +1245,6 @@ __device__ __forceinline__ void make_taps_dyn(float ix, float iy, int W, int H, 
     }
 }
 
-typedef const __attribute__((address_space(1))) effi_f4* effi_gptr4;      // a pointer KNOWN to be global memory (global_load, not flat_load)
-typedef short effi_s16x2 __attribute__((ext_vector_type(2)));
 
 // one hypothesis of one view: sum_c ref[c] * bilinear(src[c]) with the taps from the LDS window (LDSWIN) or from the source map
 template <int MODE, int C>
@@ -1532,6 +1788,41 @@ extern "C" int effi_warpcorr_views_f32(const float* ref_nhwc, const float* const
     EffiPtrList l;
     if (!fill_views(src_nhwc, S, l) || !ref_nhwc) return EFFI_ERR_BADARG;
     return launch_warpcorr_views(ref_nhwc, l, S, rt, depth, dds, dps, C, h, w, D, sim_views, entropy, stream);
+}
+
+// Split-precision stage-1 form (warpcorr_views_mm_kernel): C = 32 and hypotheses shared by all pixels, else the exact kernels above.
+// hi_only: bf16 operands (precision "bf16").
+static int launch_warpcorr_views_x3(const float* ref_nhwc, const EffiPtrList& l, int S, const float* rt, const float* depth, long dds,
+                                    long dps, int C, int h, int w, int D, float* sim_views, float* entropy, int hi_only,
+                                    effi_stream_t stream) {
+    if (!rt || !depth || !sim_views || !entropy) return EFFI_ERR_BADARG;
+    if (h < 2 || w < 2 || D < 1) return EFFI_ERR_BADARG;
+    if (!(C == 32 && dps == 0 && D <= 256 && h < 32000 && w < 32000))
+        return launch_warpcorr_views(ref_nhwc, l, S, rt, depth, dds, dps, C, h, w, D, sim_views, entropy, stream);
+    hipStream_t s = effi_s(stream);
+    const dim3 grid(((w + 15) / 16) * ((h + 3) / 4), S);
+#define EFFI_MM(TBL, HO) hipLaunchKernelGGL((warpcorr_views_mm_kernel<TBL, HO>), grid, dim3(256), 0, s, ref_nhwc, l, rt, depth, dds, h, w, D, sim_views, entropy)
+    if (l.tbl) { if (hi_only) EFFI_MM(true, true); else EFFI_MM(true, false); }
+    else { if (hi_only) EFFI_MM(false, true); else EFFI_MM(false, false); }
+#undef EFFI_MM
+    EFFI_LAUNCH_CHECK();
+    return EFFI_OK;
+}
+
+extern "C" int effi_warpcorr_views_x3_f32(const float* ref_nhwc, const float* const* src_nhwc, int S, const float* rt,
+                                          const float* depth, long dds, long dps, int C, int h, int w, int D,
+                                          float* sim_views, float* entropy, int hi_only, effi_stream_t stream) {
+    EffiPtrList l;
+    if (!fill_views(src_nhwc, S, l) || !ref_nhwc) return EFFI_ERR_BADARG;
+    return launch_warpcorr_views_x3(ref_nhwc, l, S, rt, depth, dds, dps, C, h, w, D, sim_views, entropy, hi_only, stream);
+}
+
+extern "C" int effi_warpcorr_views_x3_tbl_f32(const float* const* view_table_dev, int S, const float* rt, const float* depth, long dds,
+                                              long dps, int C, int h, int w, int D, float* sim_views, float* entropy, int hi_only,
+                                              effi_stream_t stream) {
+    EffiPtrList l;
+    if (!fill_table(view_table_dev, S, l)) return EFFI_ERR_BADARG;
+    return launch_warpcorr_views_x3(nullptr, l, S, rt, depth, dds, dps, C, h, w, D, sim_views, entropy, hi_only, stream);
 }
 
 extern "C" int effi_warpcorr_views_tbl_f32(const float* const* view_table_dev, int S, const float* rt, const float* depth, long dds,

@@ -392,9 +392,9 @@ class Effi_MVS_plus(nn.Module):
             nhwc, rt, (_, h, w) = geo[s]
             if s == 0:
                 if table is not None:
-                    sim_views, entropy = ops.warpcorr_views_tbl(table, 0, rt, hyp, D1)
+                    sim_views, entropy = ops.warpcorr_views_tbl(table, 0, rt, hyp, D1, x3=bool(ops.option("warp_x3")))
                 else:
-                    sim_views, entropy = ops.warpcorr_views(nhwc[0], nhwc[1:], rt, hyp, D1)
+                    sim_views, entropy = ops.warpcorr_views(nhwc[0], nhwc[1:], rt, hyp, D1, x3=bool(ops.option("warp_x3")))
                 weights = self.PixelwiseNet.run(entropy)
                 cur_vol = ops.view_aggregate(sim_views, weights)
                 reg_vol = self.cost_regularization.run(cur_vol.unsqueeze(0))[0][0]

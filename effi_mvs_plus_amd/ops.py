@@ -97,7 +97,7 @@ def _x3(name):
 # A/B switches.  Python-level ones (which fused form a module launches) live in ``_PY_OPTS``; kernel-level ones (tile rules, kernel
 # forms) in the library's own table (include/effi_mvs_hip.h: effi_set_option).  Both are initialised ONCE from the environment
 # (EFFI_<NAME>) and changed afterwards through ``set_option`` -- nothing on a per-call path reads the environment.
-_PY_OPTION_DEFAULTS = {"state_q4": 1, "c1k7_mfma": 1, "k5s2_split": 1, "roll": 1, "conv3d_unaligned_split": 1, "conv3d_s2_split": 1, "fpn_conv0_fused": 1,
+_PY_OPTION_DEFAULTS = {"warp_x3": 0, "state_q4": 1, "c1k7_mfma": 1, "k5s2_split": 1, "roll": 1, "conv3d_unaligned_split": 1, "conv3d_s2_split": 1, "fpn_conv0_fused": 1,
                        "fpn_split_head": 1, "csp_pair": 1, "head_taps": 1, "enc_tail": 0, "enc_gen": 1, "reduce_chunk": 2048, "gru_fused": 0, "csp_gen": 0}
 _PY_OPTS = {k: int(os.environ.get("EFFI_" + k.upper(), v)) for k, v in _PY_OPTION_DEFAULTS.items()}
 LIB_OPTIONS = ("warp_lds_kb", "dyn_form", "dyn_setup_exact", "dyn_xchg", "pixnet_mfma", "force_mr", "mr4_min", "mr4_nt2_max", "mr2_min",
@@ -428,8 +428,10 @@ def homo_warp_bwd(rt, depth, D, grad_out, h, w):
     return g_src
 
 
-def warpcorr_views(ref_nhwc, srcs_nhwc, rt, depth, D):
-    """-> (sim_views [S,D,h,w], entropy [S,h,w])."""
+def warpcorr_views(ref_nhwc, srcs_nhwc, rt, depth, D, x3=False):
+    """-> (sim_views [S,D,h,w], entropy [S,h,w]).  ``x3``: in "split" / "bf16" precision use the matrix-core form
+    (``effi_warpcorr_views_x3_f32``: correlations of the tap pixels as split-precision MFMAs, then interpolated) -- inference only;
+    the default is the exact fp32 kernel (what training and the exact-fp32 precision use)."""
     h, w, Cc = ref_nhwc.shape
     S = len(srcs_nhwc)
     _t(ref_nhwc, "ref_nhwc"), _t(rt, "rt"), _t(depth, "depth", contiguous=False)
@@ -443,6 +445,11 @@ def warpcorr_views(ref_nhwc, srcs_nhwc, rt, depth, D):
     sim = torch.empty(S, D, h, w, device=ref_nhwc.device, dtype=torch.float32)
     ent = torch.empty(S, h, w, device=ref_nhwc.device, dtype=torch.float32)
     work = lambda: {"flops": S * D * h * w * (10.0 * Cc + 20), "bytes": 4.0 * h * w * (S * Cc + Cc + S * D + S)}
+    if x3 and uses_split():
+        check(_call(f"warpcorr_views_c{Cc}", work, _lib.lib().effi_warpcorr_views_x3_f32, _p(ref_nhwc), _ptr_array(srcs_nhwc), S,
+                    _p(rt), _p(depth), dds, dps, Cc, h, w, D, _p(sim), _p(ent), int(_PRECISION == "bf16"), _stream()),
+              "effi_warpcorr_views_x3_f32")
+        return sim, ent
     check(_call(f"warpcorr_views_c{Cc}", work, _lib.lib().effi_warpcorr_views_f32, _p(ref_nhwc), _ptr_array(srcs_nhwc), S,
                 _p(rt), _p(depth), dds, dps, Cc, h, w, D, _p(sim), _p(ent), _stream()), "effi_warpcorr_views_f32")
     return sim, ent
@@ -509,7 +516,7 @@ class ViewTable:
         return C.c_void_p(self.ptrs.data_ptr() + 8 * VIEW_TABLE_ROW * s_)
 
 
-def warpcorr_views_tbl(table, stage, rt, depth, D):
+def warpcorr_views_tbl(table, stage, rt, depth, D, x3=False):
     """``warpcorr_views`` reading its reference / source maps through row ``stage`` of a ViewTable."""
     Cc, h, w = table.shapes[stage]
     S = table.n_views - 1
@@ -520,6 +527,10 @@ def warpcorr_views_tbl(table, stage, rt, depth, D):
     sim = torch.empty(S, D, h, w, device=rt.device, dtype=torch.float32)
     ent = torch.empty(S, h, w, device=rt.device, dtype=torch.float32)
     work = lambda: {"flops": S * D * h * w * (10.0 * Cc + 20), "bytes": 4.0 * h * w * (S * Cc + Cc + S * D + S)}
+    if x3 and uses_split():
+        check(_call(f"warpcorr_views_c{Cc}", work, _lib.lib().effi_warpcorr_views_x3_tbl_f32, table.row(stage), S, _p(rt), _p(depth), dds,
+                    dps, Cc, h, w, D, _p(sim), _p(ent), int(_PRECISION == "bf16"), _stream()), "effi_warpcorr_views_x3_tbl_f32")
+        return sim, ent
     check(_call(f"warpcorr_views_c{Cc}", work, _lib.lib().effi_warpcorr_views_tbl_f32, table.row(stage), S, _p(rt), _p(depth), dds, dps,
                 Cc, h, w, D, _p(sim), _p(ent), _stream()), "effi_warpcorr_views_tbl_f32")
     return sim, ent

@@ -437,6 +437,20 @@ int effi_fusion_dtu_reproject_f32(const float* ref_depth, const float* src_depth
                                   int w, int s, int e, float dist_base, float diff_base, float* mats_scratch, float* out5,
                                   unsigned char* masks, effi_stream_t stream);
 
+/* Split-precision form of effi_warpcorr_views_f32 / effi_warpcorr_views_tbl_f32 (round 4; the same reference lines,
+ * models/Effi_MVS_plus.py:38-44 + models/module.py:303-344): correlation is linear in the warped feature, so the kernel evaluates
+ * G[reference pixel][source pixel] = sum_c ref * src for a row segment's tap pixels on the matrix cores -- every fp32 product as three
+ * bf16 partial products (hi*hi + lo*hi + hi*lo) with fp32 accumulation, the arithmetic of the path's "split" convolutions; hi_only != 0:
+ * bf16 operands (precision "bf16") -- and interpolates the correlations with the bilinear weights (4 values per hypothesis instead of
+ * 4 x C).  C = 32 with hypotheses shared by all pixels (depth_pstride = 0: the cascade's stage 1); any other shape runs the exact
+ * kernels of effi_warpcorr_views_f32.  Exact-fp32 precision and training use the exact entries. */
+int effi_warpcorr_views_x3_f32(const float* ref_nhwc, const float* const* src_nhwc, int S, const float* rt,
+                               const float* depth, long depth_dstride, long depth_pstride,
+                               int C, int h, int w, int D, float* sim_views, float* entropy, int hi_only,
+                               effi_stream_t stream);
+int effi_warpcorr_views_x3_tbl_f32(const float* const* view_table_dev, int S, const float* rt, const float* depth,
+                                   long depth_dstride, long depth_pstride, int C, int h, int w, int D, float* sim_views,
+                                   float* entropy, int hi_only, effi_stream_t stream);
 /* ---- scope row n2, first piece: backward of effi_warpcorr_views_f32's similarity output ------------------------------------
  * sim[v][d][p] = mean_c ref[p][c] * bilinear(src_v)[c] at the warped position (models/module.py:303-344,
  * models/Effi_MVS_plus.py:38-40); the sampling grid carries no gradient (module.py:313).  Inputs as the forward entry;

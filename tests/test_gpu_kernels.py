@@ -190,6 +190,51 @@ def test_warpcorr_views_window_kernel(O, kind, h, w, D, N):
     check_close(f"window vs direct-gather kernel sim [{kind}]", sim, sim_o, rtol=1e-5, atol=2e-5, frac_ok=0.999 if kind != "inside" else 0.97)
 
 
+@pytest.mark.parametrize("kind", ["rig", "rolled", "wide", "inside", "far"])
+@pytest.mark.parametrize("h,w,D,N", [(37, 50, 48, 4), (16, 20, 8, 3), (9, 13, 6, 2), (74, 100, 96, 3), (20, 24, 1, 2), (148, 200, 48, 5)])
+def test_warpcorr_views_matrix_core_form(O, kind, h, w, D, N):
+    """Round 4: in split / bf16 precision the cascade's stage-1 similarity is evaluated CORRELATE FIRST (effi_warpcorr_views_x3_f32):
+    G[reference pixel][tap pixel] = sum_c ref * src on the matrix cores (three bf16 partial products per fp32 product, fp32
+    accumulation -- the arithmetic of the split convolutions), then the bilinear interpolation of the correlations.  Against the
+    oracle with the split convolutions' tolerance (4e-5 of the peak on top of the exact kernel's), against the exact kernel, on the
+    rigs that stress the box logic (slanted / huge / behind-the-camera / out-of-view epipolar segments: boxes that do not fit the
+    wave's LDS region take the direct fp32 form), on hypotheses in any order, and bit for bit repeatable."""
+    from effi_mvs_plus_amd import ops
+    if h * w > 20000 and kind not in ("rig", "rolled"):
+        pytest.skip("the large map runs on two rigs")
+    C = 32
+    feats = synth.smooth_features(N, C, h, w, seed=300 + h)
+    pm = synth.synth_cameras(h * 8, w * 8, N)["stage1"] if kind == "rig" else _edge_cameras(h, w, N, kind)
+    samples = (1.0 / torch.linspace(1 / 935.0, 1 / 425.0, D)) if D > 1 else torch.tensor([600.0])
+    want_sim, want_ent = _oracle_sim_views(O, feats, pm, samples.view(1, D, 1, 1).expand(1, D, h, w))
+    nhwc = ops.to_nhwc([t(f[0], DEV) for f in feats])
+    rt = ops.compose_rel_proj(t(pm[0], DEV))
+    before = ops.get_precision()
+    try:
+        ops.set_precision("split")
+        sim, ent = ops.warpcorr_views(nhwc[0], nhwc[1:], rt, t(samples, DEV), D, x3=True)
+        sim2, ent2 = ops.warpcorr_views(nhwc[0], nhwc[1:], rt, t(samples, DEV), D, x3=True)
+        sim_e, ent_e = ops.warpcorr_views(nhwc[0], nhwc[1:], rt, t(samples, DEV), D)
+        perm = torch.randperm(D, generator=torch.Generator().manual_seed(3))
+        sim_p, _ = ops.warpcorr_views(nhwc[0], nhwc[1:], rt, t(samples[perm], DEV), D, x3=True)
+        ops.set_precision("bf16")
+        sim_b, ent_b = ops.warpcorr_views(nhwc[0], nhwc[1:], rt, t(samples, DEV), D, x3=True)
+        ops.set_precision("fp32")
+        sim_f, ent_f = ops.warpcorr_views(nhwc[0], nhwc[1:], rt, t(samples, DEV), D, x3=True)
+    finally:
+        ops.set_precision(before)
+    assert torch.equal(sim, sim2) and torch.equal(ent, ent2), "repeatable bit for bit"
+    assert torch.equal(sim_f, sim_e) and torch.equal(ent_f, ent_e), "exact-fp32 precision keeps the exact kernel"
+    peak = float(want_sim.abs().max())
+    frac = 0.97 if kind == "inside" else 0.998         # where Z crosses zero the projection is ill-conditioned in fp32 (see the test above)
+    check_close(f"matrix-core sim vs oracle [{kind} {h}x{w} D={D}]", sim, want_sim, rtol=1e-4, atol=2e-4 + 4e-5 * peak, frac_ok=frac)
+    check_close(f"matrix-core entropy vs oracle [{kind}]", ent, want_ent, rtol=1e-4, atol=2e-4 + 4e-4, frac_ok=frac)
+    check_close(f"matrix-core vs exact kernel sim [{kind}]", sim, sim_e, rtol=1e-5, atol=2e-5 + 4e-5 * peak, frac_ok=0.999 if kind != "inside" else 0.97)
+    check_close(f"shuffled hypotheses = the sorted result permuted [{kind}]", sim_p, sim.cpu()[:, perm], rtol=1e-5, atol=2e-5 + 4e-5 * peak,
+                frac_ok=0.999 if kind != "inside" else 0.97)
+    check_close(f"bf16 operands vs exact kernel sim [{kind}]", sim_b, sim_e, rtol=1e-2, atol=1e-2 * max(peak, 1e-3), frac_ok=0.97)
+
+
 def test_warpcorr_views_window_kernel_accepts_any_order_of_hypotheses(O):
     """The reference accepts depth_values in any order (models/Effi_MVS_plus.py:32-61 never sorts them).  The window kernel bounds a
     chunk's source positions by its two END depths, which holds for monotone hypotheses only: a workgroup that finds them

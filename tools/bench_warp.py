@@ -42,6 +42,21 @@ def main():
             alg = 4.0 * h * w * ((N - 1) * 32 + 32 + (N - 1) * D + (N - 1))
             print(f"{name} {h}x{w} D={D} S={N - 1} EFFI_WARP_LDS_KB={mode or 'unset':5s}: {us:8.1f} us  "
                   f"({alg / us / 1e3:.0f} GB/s algorithmic, {(N - 1) * D * h * w * 512 / us / 1e3:.0f} GB/s of taps)")
+        for prec in ("split", "bf16"):                      # the matrix-core form (correlate first: effi_warpcorr_views_x3_f32)
+            ops.set_option("warp_lds_kb", None)
+            ops.set_precision(prec)
+            for _ in range(3):
+                sim, ent = ops.warpcorr_views(nhwc[0], nhwc[1:], rt, hyp, D, x3=True)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                sim, ent = ops.warpcorr_views(nhwc[0], nhwc[1:], rt, hyp, D, x3=True)
+            e1.record()
+            torch.cuda.synchronize()
+            ops.set_precision("split")
+            msg = f"  max |x3 - window| = {float((sim - outs[''][0 if isinstance(outs[''], tuple) else slice(None)]).abs().max()):.3e}" if "" in outs else ""
+            print(f"{name} {h}x{w} D={D} S={N - 1} matrix-core form ({prec:5s}): {e0.elapsed_time(e1) / 50 * 1e3:8.1f} us{msg}")
         if "" in outs and "0" in outs:
             print("   window == global path bitwise:", bool(torch.equal(outs[""], outs["0"])))
         if "" in outs and "-1" in outs:
