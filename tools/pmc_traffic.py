@@ -85,6 +85,9 @@ def key_of(name):
         return f"deconv3d_c{1 if m.group(1) == '1' else 8}_s{m.group(2)}", 1.0
     if n.startswith("warpcorr_views_win_kernel"):
         return "warpcorr_views_c32", 2.0                                               # window rows: long contiguous runs
+    m = re.match(r"warpcorr_dyn_win_kernel<(\d+)", n)                                  # LDS-window form: window rows copied as contiguous runs
+    if m:
+        return f"warpcorr_dyn_c{m.group(1)}", 2.0
     m = re.match(r"warpcorr_dyn_hyp_kernel<(\d+)", n)                                  # a lane reads the C * 4 contiguous bytes of a tap
     if m:
         return f"warpcorr_dyn_c{m.group(1)}", {16: 1.0, 8: 0.5}[int(m.group(1))]
