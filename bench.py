@@ -250,7 +250,8 @@ def main():
     ap.add_argument("--cfg5-scans", type=int, default=22, help="--workload cfg5: scans in the evaluation set (DTU test list: 22)")
     ap.add_argument("--cfg5-images", type=int, default=49, help="--workload cfg5: images = reference views per scan (DTU: 49)")
     ap.add_argument("--gather-batch", type=int, default=8, help="--workload cfg5: views per asynchronous gather to rank 0")
-    ap.add_argument("--cfg5-slots", type=int, default=3, help="--workload cfg5: reference views in flight per rank (lanes)")
+    ap.add_argument("--cfg5-slots", type=int, default=4, help="--workload cfg5: reference views in flight per rank (lanes); 3 / 4 / 5 on one box: "
+                                                               "477 / 482 / 465 views/s (profiles/r04_ag_cfg5_slots.txt)")
     ap.add_argument("--cfg5-check", type=int, default=6, help="--workload cfg5: gathered views recomputed one at a time after the timed "
                                                                "region and compared bitwise (0 = skip)")
     ap.add_argument("--cfg5-size", default=None, help="--workload cfg5: WxH instead of 1600x1184 (rehearsals)")

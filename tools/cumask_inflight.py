@@ -81,6 +81,11 @@ def main():
             st.wait_stream(cur)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        stagger = float(os.environ.get("STAGGER_MS", "0"))       # lane k starts k * STAGGER_MS late (inside the timed region)
+        if stagger > 0:
+            for k in range(1, K):
+                with torch.cuda.stream(streams[k]):
+                    torch.cuda._sleep(int(k * stagger * 1e-3 * 100e6))     # device-side spin, ~100 MHz counter
         for i in range(steps):
             with torch.cuda.stream(streams[i % K]):
                 out = graphed.replay(i % K)
