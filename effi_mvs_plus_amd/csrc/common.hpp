@@ -28,7 +28,7 @@ enum EffiOption {
     EFFI_OPT_WIDE_TILES,         // 0 / 1: 4 x 64 tiles never / always
     EFFI_OPT_ROLL_MR, EFFI_OPT_ROLL_ZT, EFFI_OPT_ROLL_RP,         // rolling 3-D convolution: rows per wave, planes per workgroup, row-pair operand
     EFFI_OPT_DECONV_MR,          // transposed 3-D convolution: rows per wave
-    EFFI_OPT_SR_WAVES,           // split-resident 3x3 convolutions: 8 = 512-thread workgroups where the rule picks 1 or 2 rows per wave
+    EFFI_OPT_SR_WAVES,           // split-resident 3x3 convolutions: unset = 512-thread workgroups for 1 row per wave x 6 N-tiles; 8 = wherever the rule picks 1 or 2 rows per wave; 4 = never
     EFFI_OPT_ENC_GEN_MR3,        // generated-input pair kernel: 0 = 4 rows per wave where the rule says so (default: 3)
     EFFI_OPT_C3_LEAN,            // 3-D end layers (1 -> 8, 8 -> 1 channels): 0 = the general vector-ALU bodies instead of the dedicated kernels
     EFFI_OPT_DYN_WIN,            // stage-2/3 warp kernel: unset = LDS-window form with its full window, n > 0 = window of n pixels, 0 = window form on global loads, -1 = the gather kernel

@@ -1052,8 +1052,13 @@ static int launch_bf16x3(const Conv2dArgs& a, hipStream_t st) {
         return hipPeekAtLastError() == hipSuccess ? EFFI_OK : EFFI_ERR_LAUNCH;
     }
     if constexpr (SR) {
-        // eight waves per workgroup (option sr_waves = 8; A/B): the tile of 4-row waves' workgroup at half the rows per wave
-        if (effi_option(EFFI_OPT_SR_WAVES) == 8 && mr <= 2) {
+        // eight waves per workgroup: the tile of 4-row waves' workgroup at half the rows per wave, twice the pixels behind one copy of
+        // the weight fragments.  Rule (option sr_waves unset): one row per wave AND six N-tiles -- the stage-1 z | r layer, whose 61 KB
+        // of weight fragments per chunk and 64-pixel workgroup are what its launch moves (84.7-87.0 -> 78.4-79.0 us per view,
+        // profiles/r04_ai_sr_waves_ab2.txt); every other layer is equal or slower with eight waves (stage-3 z | r: +12 us).
+        // sr_waves = 8: wherever the rule picks 1 or 2 rows per wave (A/B); sr_waves = 4: never.
+        const long srw = effi_option(EFFI_OPT_SR_WAVES);
+        if ((srw == 8 && mr <= 2) || (srw == EFFI_OPT_UNSET && mr == 1 && NT >= 6)) {
             const int tiles_x = (int)cols, ntiles = tiles_x * effi_cdiv(a.h, 8 * mr);
             const dim3 grid(ntiles, 1);
             if (mr == 2) hipLaunchKernelGGL((conv2d_k3_bf16x3_kernel<NT, 2, EPI, false, false, true, 8>), grid, dim3(512), 0, st, a, tiles_x, ntiles);
