@@ -25,7 +25,9 @@ def main():
     from common import build_model
     from effi_mvs_plus_amd import ops, packing
     from effi_mvs_plus_amd.models.update import _pack
-    sizes = {"cfg2": (576, 800), "cfg3": (1184, 1600), "cfg4": (1056, 1920)}[args.workload]
+    sizes = {"cfg2": (576, 800), "cfg3": (1184, 1600), "cfg4": (1056, 1920),
+             # three / four cfg3 views side by side: what a BATCHED launch of the views in flight would give each layer
+             "cfg3x3": (1184, 4800), "cfg3x4": (1184, 6400)}[args.workload]
     dev = "cuda:0"
     net, _ = build_model("48,8,8", seed=1, device=dev)
     ops.set_precision("split")
